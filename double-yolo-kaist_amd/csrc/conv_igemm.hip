@@ -1,0 +1,354 @@
+// Implicit-GEMM convolution (forward and data gradient) on the CDNA4 matrix cores.
+//
+// GEMM view: M = output channels (A operand = packed weights [tap][Cout][Cin]),
+//            N = launch-grid positions (B operand = channels-last activations),
+//            K = taps x Cin, walked as (Cin chunk outer, tap inner) so that the nine
+//            shifted re-reads of one activation chunk hit L1/L2 instead of HBM.
+// Block = 256 threads = 4 waves, tile BM x 128, K step = BKB bytes of channels
+// (64 or 128 B per row).  Global -> registers -> LDS (XOR-swizzled 16-byte slots,
+// zero fill for padding taps / ragged tiles), double-buffered, one barrier per K step.
+// MFMA: v_mfma_f32_16x16x32_bf16 (bf16) or 4 x v_mfma_f32_16x16x4_f32 (f32) per 16-byte
+// fragment pair; both operands are read from LDS with the same (row = lane&15,
+// slot = lane>>4) pattern so the K permutation inside a fragment cancels.
+// D layout: acc[r] = D[m = (lane>>4)*4 + r][n = lane&15]  -> four consecutive output
+// channels of one pixel per lane = one 8/16-byte channels-last store.
+//
+// Replaces: nn.Conv2d forward at reference models.py:34-42 (+ the BatchNorm2d/activation
+// that follow it at :46-62 when run with the AFFINE epilogue), and autograd's
+// convolution_backward (input gradient) for the same layers.
+#include "dyk_common.h"
+
+namespace {
+
+struct ConvArgs {
+    DykConvDesc d;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ inline void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                      __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static __device__ inline void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+// byte offset of 16-byte slot `slot` of row `row` in a [rows][BKB] tile.
+// BKB=128: 2 rows per 256-B bank row, slot ^= (row>>1)&7 ; BKB=64: 4 rows per bank row,
+// slot ^= 3*((row>>3)&1).  Both make every ds_read_b128 lane group (MI355X_MICROARCH §LDS)
+// hit 16 distinct slots for the (row = lane&15, slot = lane>>4) fragment pattern.
+template <int BKB> __device__ inline int lds_off(int row, int slot) {
+    if (BKB == 128) return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+    return row * 64 + ((slot ^ (((row >> 3) & 1) * 3)) << 4);
+}
+
+template <typename T, int BM, int BKB>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
+    const DykConvDesc& a = args.d;
+    constexpr int BN = 128;
+    constexpr int EPV = 16 / (int)sizeof(T);
+    constexpr int BK = BKB / (int)sizeof(T);
+    constexpr int TPR = BKB / 16;            // threads per tile row
+    constexpr int RPP = 256 / TPR;           // tile rows filled per pass
+    constexpr int NPA = (BM + RPP - 1) / RPP;
+    constexpr int NPB = BN / RPP;
+    constexpr int WM = (BM >= 128) ? 2 : 1;  // waves along M
+    constexpr int WN = 4 / WM;
+    constexpr int WTM = BM / WM;
+    constexpr int WTN = BN / WN;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    constexpr int KK = BKB / 64;
+    constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                          // [2][A_BYTES]
+    char* sB = smem + 2 * A_BYTES;            // [2][B_BYTES]
+    int* t_in = (int*)(smem + 2 * A_BYTES + 2 * B_BYTES);   // [BN] input base offset
+    int* t_out = t_in + BN;                   // [BN] output offset or -1
+    int* t_res = t_out + BN;                  // [BN] residual offset
+    short* t_y = (short*)(t_res + BN);        // [BN] input row of tap (0,0)
+    short* t_x = t_y + BN;                    // [BN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+
+    const int tiles_m = (a.Cout + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (bid % tiles_m) * BM;
+    const int n0 = (bid / tiles_m) * BN;
+    const int HWg = a.Hg * a.Wg;
+    const int Ntot = a.B * HWg;
+
+    if (tid < BN) {
+        const int n = n0 + tid;
+        if (n < Ntot) {
+            const int b = n / HWg;
+            const int r = n - b * HWg;
+            const int yo = r / a.Wg;
+            const int xo = r - yo * a.Wg;
+            const int yi = yo * a.isy, xi = xo * a.isx;
+            t_in[tid] = ((b * a.Hi + yi) * a.Wi + xi) * a.ldx;
+            t_y[tid] = (short)yi;
+            t_x[tid] = (short)xi;
+            const int py = yo * a.osy + a.ooy, px = xo * a.osx + a.oox;
+            t_out[tid] = ((b * a.Ho + py) * a.Wo + px) * a.ldy;
+            t_res[tid] = ((b * a.Ho + py) * a.Wo + px) * a.ldr;
+        } else {
+            t_in[tid] = 0; t_y[tid] = -20000; t_x[tid] = -20000; t_out[tid] = -1; t_res[tid] = 0;
+        }
+    }
+    __syncthreads();
+
+    // ---- loader bookkeeping (per thread: NPA weight rows, NPB pixel rows, one 16-B segment)
+    const int lrow = tid / TPR, seg = tid % TPR;
+    int b_in[NPB]; int b_y[NPB], b_x[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int row = i * RPP + lrow;
+        b_in[i] = t_in[row]; b_y[i] = t_y[row]; b_x[i] = t_x[row];
+    }
+    int a_off[NPA]; bool a_ok[NPA];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int row = i * RPP + lrow;
+        const int co = m0 + row;
+        a_ok[i] = (row < BM) && (co < a.Cout);
+        a_off[i] = co * a.Cin + seg * EPV;
+    }
+    const T* __restrict__ xg = (const T*)a.x;
+    const T* __restrict__ wg = (const T*)a.w;
+
+    uint4 ra[NPA], rb[NPB];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto gload = [&](int c0, int t) {
+        const int dy = a.tdy[t], dx = a.tdx[t];
+        const int toff = (dy * a.Wi + dx) * a.ldx + c0 + seg * EPV;
+        const long wbase = (long)a.twt[t] * a.Cout * a.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i)
+            ra[i] = a_ok[i] ? *(const uint4*)(wg + wbase + a_off[i]) : zero4;
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int yi = b_y[i] + dy, xi = b_x[i] + dx;
+            const bool ok = ((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi);
+            rb[i] = ok ? *(const uint4*)(xg + (long)b_in[i] + toff) : zero4;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int row = i * RPP + lrow;
+            if (row < BM) *(uint4*)(sA + buf * A_BYTES + lds_off<BKB>(row, seg)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int row = i * RPP + lrow;
+            *(uint4*)(sB + buf * B_BYTES + lds_off<BKB>(row, seg)) = rb[i];
+        }
+    };
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int S = (a.Cin / BK) * a.ntaps;
+    if (S > 0) {
+        gload(0, 0);
+        lstore(0);
+    }
+    __syncthreads();
+    int c0 = 0, t = 0;
+    const int frow = lane & 15, fslot = lane >> 4;
+    for (int s = 0; s < S; ++s) {
+        int tn = t + 1, cn = c0;
+        if (tn == a.ntaps) { tn = 0; cn += BK; }
+        const bool more = (s + 1 < S);
+        if (more) gload(cn, tn);
+        const char* pa = sA + (s & 1) * A_BYTES;
+        const char* pb = sB + (s & 1) * B_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            uint4 fa[MI], fb[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                fa[mi] = *(const uint4*)(pa + lds_off<BKB>(wm * WTM + mi * 16 + frow, kk * 4 + fslot));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                fb[ni] = *(const uint4*)(pb + lds_off<BKB>(wn * WTN + ni * 16 + frow, kk * 4 + fslot));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], fa[mi], fb[ni]);
+        }
+        if (more) lstore((s + 1) & 1);
+        __syncthreads();
+        t = tn; c0 = cn;
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    const int flags = a.flags;
+    const int mlane = (lane >> 4) * 4;
+    if (flags & DYK_EPI_STATS) {
+        // per-channel sum / sum of squares of the raw accumulators over this wave's
+        // WTN pixels: reduce over ni in-lane, over the 16 pixel lanes by xor-shuffle,
+        // then one fp64 atomic per channel per wave.
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const float v = acc[mi][ni][r];
+                    s1 += v; s2 += v * v;
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                const int m = m0 + wm * WTM + mi * 16 + mlane + r;
+                if ((lane & 15) == 0 && m < a.Cout) {
+                    atomicAdd(a.stats + m, (double)s1);
+                    atomicAdd(a.stats + a.Cout + m, (double)s2);
+                }
+            }
+        }
+    }
+    const bool affine = flags & DYK_EPI_AFFINE;
+    const bool has_res = flags & DYK_EPI_RESIDUAL;
+    const bool accum = flags & DYK_EPI_ACCUM;
+    const bool out_f32 = (flags & DYK_EPI_OUT_F32) || sizeof(T) == 4;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * WTM + mi * 16 + mlane;
+        if (m >= a.Cout) continue;
+        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (affine) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (m + r < a.Cout) {
+                    if (a.scale) sc[r] = a.scale[m + r];
+                    if (a.shift) sh[r] = a.shift[m + r];
+                }
+        }
+        const bool full = (m + 3 < a.Cout);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int nl = wn * WTN + ni * 16 + (lane & 15);
+            const int po = t_out[nl];
+            if (po < 0) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = acc[mi][ni][r];
+                if (affine) u = u * sc[r] + sh[r];
+                v[r] = act_fwd(a.act, u);
+            }
+            if (has_res) {
+                const T* rp = (const T*)a.res + (long)t_res[nl] + m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < a.Cout) v[r] += ElemTraits<T>::to_f32(rp[r]);
+            }
+            if (out_f32) {
+                float* yp = (float*)a.y + (long)po + m;
+                if (accum) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (m + r < a.Cout) v[r] += yp[r];
+                }
+                if (full) {
+                    *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (m + r < a.Cout) yp[r] = v[r];
+                }
+            } else {
+                bf16_t* yp = (bf16_t*)a.y + (long)po + m;
+                if (accum) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (m + r < a.Cout) v[r] += bf16_to_f32(yp[r]);
+                }
+                if (full) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *(uint2*)yp = pk;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (m + r < a.Cout) yp[r] = f32_to_bf16(v[r]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BKB>
+int launch_conv(const DykConvDesc* d, hipStream_t stream) {
+    constexpr int BN = 128;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * BKB + BN * (3 * sizeof(int) + 2 * sizeof(short));
+    static bool attr_set = false;
+    auto kfn = conv_igemm_kernel<T, BM, BKB>;
+    if (!attr_set) {
+        DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const long Ntot = (long)d->B * d->Hg * d->Wg;
+    const int tiles_n = dyk_div_up(Ntot, BN);
+    const int tiles_m = dyk_div_up(d->Cout, BM);
+    ConvArgs args;
+    args.d = *d;
+    hipLaunchKernelGGL(kfn, dim3(tiles_n * tiles_m), dim3(256), lds, stream, args);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+template <typename T>
+int dispatch_conv(const DykConvDesc* d, hipStream_t stream) {
+    const int row_bytes = d->Cin * (int)sizeof(T);
+    const bool k128 = (row_bytes % 128) == 0;
+    if (!k128 && (row_bytes % 64) != 0) return DYK_ERR_ARG;
+    const int bm = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
+    if (k128) {
+        if (bm == 128) return launch_conv<T, 128, 128>(d, stream);
+        if (bm == 64) return launch_conv<T, 64, 128>(d, stream);
+        return launch_conv<T, 32, 128>(d, stream);
+    }
+    if (bm == 128) return launch_conv<T, 128, 64>(d, stream);
+    if (bm == 64) return launch_conv<T, 64, 64>(d, stream);
+    return launch_conv<T, 32, 64>(d, stream);
+}
+
+}  // namespace
+
+extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
+    if (!d || !d->x || !d->w || !d->y) return DYK_ERR_ARG;
+    if (d->ntaps < 0 || d->ntaps > DYK_MAX_TAPS) return DYK_ERR_ARG;
+    if (d->B <= 0 || d->Hg <= 0 || d->Wg <= 0 || d->Cout <= 0 || d->Cin <= 0) return DYK_ERR_ARG;
+    if ((d->flags & DYK_EPI_STATS) && !d->stats) return DYK_ERR_ARG;
+    if ((d->flags & DYK_EPI_RESIDUAL) && !d->res) return DYK_ERR_ARG;
+    const int epv = d->dtype == DYK_BF16 ? 8 : 4;
+    if (d->ldx % epv || d->ldy % 4) return DYK_ERR_ARG;
+    // 32-bit element offsets inside the kernel
+    if ((long)d->B * d->Hi * d->Wi * d->ldx >= (1L << 31)) return DYK_ERR_ARG;
+    if ((long)d->B * d->Ho * d->Wo * d->ldy >= (1L << 31)) return DYK_ERR_ARG;
+    if (d->Hi > 16000 || d->Wi > 16000) return DYK_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == DYK_BF16) return dispatch_conv<bf16_t>(d, s);
+    if (d->dtype == DYK_F32) return dispatch_conv<float>(d, s);
+    return DYK_ERR_ARG;
+}

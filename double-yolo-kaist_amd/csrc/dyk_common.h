@@ -1,0 +1,146 @@
+// Shared device helpers for the dyk HIP kernels (gfx950 / CDNA4 only).
+//
+// Data layout everywhere below the C ABI: activations are channels-last
+// ("NHWC"), element type T in {bf16 (raw uint16), f32}; a tensor is addressed
+// as base + pixel * ld + channel, with ld >= C so that a tensor can be a
+// channel slice of a wider (concat) buffer.  16-byte vectors (8 bf16 / 4 f32)
+// are the unit of every global and LDS access.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dyk_hip.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 storage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define DYK_WAVE 64
+
+#define DYK_HIP_TRY(expr)                                   \
+    do {                                                    \
+        hipError_t _e = (expr);                             \
+        if (_e != hipSuccess) return DYK_ERR_HIP;           \
+    } while (0)
+
+#define DYK_LAUNCH_CHECK()                                  \
+    do {                                                    \
+        if (hipGetLastError() != hipSuccess) return DYK_ERR_HIP; \
+    } while (0)
+
+// ---------------------------------------------------------------- bf16 <-> f32
+__device__ __host__ inline float bf16_to_f32(bf16_t v) {
+    union { uint32_t u; float f; } c;
+    c.u = ((uint32_t)v) << 16;
+    return c.f;
+}
+// round-to-nearest-even, NaN preserved (same rule as torch.bfloat16 casts)
+__device__ __host__ inline bf16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<bf16_t> {
+    static constexpr int EPV = 8;  // elements per 16-byte vector
+    static __device__ inline float to_f32(bf16_t v) { return bf16_to_f32(v); }
+    static __device__ inline bf16_t from_f32(float f) { return f32_to_bf16(f); }
+};
+template <> struct ElemTraits<float> {
+    static constexpr int EPV = 4;
+    static __device__ inline float to_f32(float v) { return v; }
+    static __device__ inline float from_f32(float f) { return f; }
+};
+
+// 16-byte vector <-> EPV floats
+template <typename T> __device__ inline void vec_unpack(const uint4& v, float* out);
+template <> __device__ inline void vec_unpack<bf16_t>(const uint4& v, float* out) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        out[2 * i]     = __uint_as_float(w[i] << 16);
+        out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+template <> __device__ inline void vec_unpack<float>(const uint4& v, float* out) {
+    out[0] = __uint_as_float(v.x); out[1] = __uint_as_float(v.y);
+    out[2] = __uint_as_float(v.z); out[3] = __uint_as_float(v.w);
+}
+template <typename T> __device__ inline uint4 vec_pack(const float* in);
+template <> __device__ inline uint4 vec_pack<bf16_t>(const float* in) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w[i] = (uint32_t)f32_to_bf16(in[2 * i]) | ((uint32_t)f32_to_bf16(in[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <> __device__ inline uint4 vec_pack<float>(const float* in) {
+    return make_uint4(__float_as_uint(in[0]), __float_as_uint(in[1]),
+                      __float_as_uint(in[2]), __float_as_uint(in[3]));
+}
+
+// ---------------------------------------------------------------- activations
+// Forward value and derivative w.r.t. the pre-activation, matching the
+// torch.nn modules the reference instantiates at models.py:51-62
+// (Mish, ReLU, LeakyReLU(0.1), ReLU6, Hardsigmoid, Hardswish).
+__device__ inline float act_fwd(int act, float x) {
+    switch (act) {
+    case DYK_ACT_LEAKY: return x > 0.f ? x : 0.1f * x;
+    case DYK_ACT_MISH: {
+        // x * tanh(softplus(x)) with tanh(log(1+e^x)) = n / (n + 2), n = e^x (e^x + 2)
+        if (x > 20.f) return x;  // softplus threshold of torch
+        const float e = __expf(x);
+        const float n = e * (e + 2.f);
+        return x * (n / (n + 2.f));
+    }
+    case DYK_ACT_RELU: return x > 0.f ? x : 0.f;
+    case DYK_ACT_RELU6: return fminf(fmaxf(x, 0.f), 6.f);
+    case DYK_ACT_HSIGMOID: return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    case DYK_ACT_HSWISH: return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    default: return x;
+    }
+}
+__device__ inline float act_bwd(int act, float x) {
+    switch (act) {
+    case DYK_ACT_LEAKY: return x > 0.f ? 1.f : 0.1f;
+    case DYK_ACT_MISH: {
+        if (x > 20.f) return 1.f;
+        const float e = __expf(x);
+        const float n = e * (e + 2.f);
+        const float t = n / (n + 2.f);            // tanh(softplus(x))
+        const float sg = e / (1.f + e);           // sigmoid(x)
+        return t + x * (1.f - t * t) * sg;
+    }
+    case DYK_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case DYK_ACT_RELU6: return (x > 0.f && x < 6.f) ? 1.f : 0.f;
+    case DYK_ACT_HSIGMOID: return (x > -3.f && x < 3.f) ? (1.f / 6.f) : 0.f;
+    case DYK_ACT_HSWISH: return x < -3.f ? 0.f : (x <= 3.f ? (x * (1.f / 3.f) + 0.5f) : 1.f);
+    default: return 1.f;
+    }
+}
+
+// ---------------------------------------------------------------- wave helpers
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Bijective XCD-aware block remap (8 XCDs, block b is dispatched to XCD b % 8):
+// consecutive remapped ids land on the same XCD so neighbouring tiles share L2.
+__device__ inline int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+static inline int dyk_div_up(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,188 @@
+"""Operator-level wrappers over the C ABI (one Python function per libdyk_hip.so entry point).
+
+Tensors are torch CUDA tensors used purely as device-memory handles: channels-last
+``[B, H, W, C]`` (bf16 or f32), possibly a channel slice of a wider buffer.  Nothing here
+computes with torch; a missing library or a CPU tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _l
+from .lib import (ACT_CODES, DYK_BF16, DYK_F32, EPI_ACCUM, EPI_AFFINE, EPI_OUT_F32, EPI_RESIDUAL, EPI_STATS,
+                  DykConvDesc, check, load)
+
+
+def dtype_code(dt):
+    if dt == torch.bfloat16:
+        return DYK_BF16
+    if dt == torch.float32:
+        return DYK_F32
+    raise TypeError("dyk supports bf16 and f32 activations, got %s" % dt)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _l.DykError("dyk operators run on the GPU only (got a %s tensor); there is no CPU fallback"
+                              % t.device.type)
+
+
+def nhwc_ld(t):
+    """pixel stride (in elements) of a channels-last [B,H,W,C] tensor / channel-slice view."""
+    B, H, W, C = t.shape
+    ld = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else (t.stride(0) if B > 1 else C))
+    assert t.stride(3) == 1 or C == 1, "channel dim must be innermost"
+    if W > 1 and H > 1:
+        assert t.stride(1) == W * ld, "tensor is not pixel-contiguous"
+    if B > 1 and (H > 1 or W > 1):
+        assert t.stride(0) == H * W * ld, "tensor is not pixel-contiguous"
+    return ld
+
+
+# --------------------------------------------------------------------------- layout / pack
+def to_nhwc(x_nchw, dtype, cpad=None, mul=1.0, out=None):
+    """float32 NCHW -> channels-last `dtype` [B,H,W,cpad] (zero padded channels)."""
+    _require_cuda(x_nchw)
+    assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    B, C, H, W = x_nchw.shape
+    cpad = cpad or C
+    if out is None:
+        out = torch.empty((B, H, W, cpad), dtype=dtype, device=x_nchw.device)
+    check(load().dyk_nchw_to_nhwc(_ptr(x_nchw), _ptr(out), B, C, H, W, cpad, nhwc_ld(out), float(mul),
+                                  dtype_code(dtype), _stream()), "dyk_nchw_to_nhwc")
+    return out
+
+
+def to_nchw(x_nhwc, C=None):
+    _require_cuda(x_nhwc)
+    B, H, W, Cp = x_nhwc.shape
+    C = C or Cp
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x_nhwc.device)
+    check(load().dyk_nhwc_to_nchw(_ptr(x_nhwc), _ptr(out), B, C, H, W, nhwc_ld(x_nhwc),
+                                  dtype_code(x_nhwc.dtype), _stream()), "dyk_nhwc_to_nchw")
+    return out
+
+
+def pack_weight(w_oihw, dtype, transposed=False, cout_pad=None, cin_pad=None, out=None):
+    """torch OIHW float32 -> [taps][rows][cols] `dtype` (rows=Cout, cols=Cin; swapped if transposed)."""
+    _require_cuda(w_oihw)
+    assert w_oihw.dtype == torch.float32 and w_oihw.is_contiguous()
+    Cout, Cin, kh, kw = w_oihw.shape
+    cout_pad = cout_pad or Cout
+    cin_pad = cin_pad or Cin
+    R, C = (cin_pad, cout_pad) if transposed else (cout_pad, cin_pad)
+    if out is None:
+        out = torch.empty((kh * kw, R, C), dtype=dtype, device=w_oihw.device)
+    check(load().dyk_pack_conv_weight(_ptr(w_oihw), _ptr(out), Cout, Cin, kh, kw, cout_pad, cin_pad,
+                                      1 if transposed else 0, dtype_code(dtype), _stream()), "dyk_pack_conv_weight")
+    return out
+
+
+# --------------------------------------------------------------------------- conv tap tables
+def conv_out_size(n, k, stride, pad):
+    return (n + 2 * pad - k) // stride + 1
+
+
+def fwd_taps(k, pad):
+    """(tdy, tdx, twt) of a k x k forward convolution with zero padding `pad`."""
+    taps = []
+    for kh in range(k):
+        for kw in range(k):
+            taps.append((kh - pad, kw - pad, kh * k + kw))
+    return taps
+
+
+def dgrad_classes(k, pad, stride, Hi, Wi):
+    """Data gradient of a stride-s conv as s*s dense launches, one per parity class of the
+    input pixel (yi, xi) = (s*yh + py, s*xh + px).  Yields (py, px, Hg, Wg, taps) where taps are
+    offsets into the *output-gradient* grid: source (yh + tdy, xh + tdx), weight tap twt."""
+    out = []
+    for py in range(stride):
+        for px in range(stride):
+            Hg = (Hi - py + stride - 1) // stride
+            Wg = (Wi - px + stride - 1) // stride
+            if Hg <= 0 or Wg <= 0:
+                continue
+            taps = []
+            for kh in range(k):
+                if (py + pad - kh) % stride:
+                    continue
+                for kw in range(k):
+                    if (px + pad - kw) % stride:
+                        continue
+                    taps.append(((py + pad - kh) // stride, (px + pad - kw) // stride, kh * k + kw))
+            out.append((py, px, Hg, Wg, taps))
+    return out
+
+
+def make_conv_desc(x, w, y, *, Hi, Wi, Cin, Cout, Hg, Wg, Ho, Wo, taps, isy=1, isx=1, osy=1, osx=1, ooy=0, oox=0,
+                   act="linear", scale=None, shift=None, res=None, stats=None, accumulate=False, out_f32=False,
+                   ldx=None, ldy=None, ldr=None, B=None, dtype=None):
+    d = DykConvDesc()
+    d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.shift = shift.data_ptr() if shift is not None else None
+    d.res = res.data_ptr() if res is not None else None
+    d.stats = stats.data_ptr() if stats is not None else None
+    d.dtype = dtype_code(x.dtype) if dtype is None else dtype
+    d.ldx = ldx if ldx is not None else nhwc_ld(x)
+    d.ldy = ldy if ldy is not None else nhwc_ld(y)
+    d.ldr = ldr if ldr is not None else (nhwc_ld(res) if res is not None else 0)
+    d.B = B if B is not None else x.shape[0]
+    d.Hi, d.Wi, d.Cin, d.Cout = Hi, Wi, Cin, Cout
+    d.Hg, d.Wg, d.Ho, d.Wo = Hg, Wg, Ho, Wo
+    d.isy, d.isx, d.osy, d.osx, d.ooy, d.oox = isy, isx, osy, osx, ooy, oox
+    d.ntaps = len(taps)
+    for i, (dy, dx, wt) in enumerate(taps):
+        d.tdy[i], d.tdx[i], d.twt[i] = dy, dx, wt
+    d.act = ACT_CODES[act] if isinstance(act, str) else int(act)
+    flags = 0
+    if scale is not None or shift is not None:
+        flags |= EPI_AFFINE
+    if res is not None:
+        flags |= EPI_RESIDUAL
+    if stats is not None:
+        flags |= EPI_STATS
+    if accumulate:
+        flags |= EPI_ACCUM
+    if out_f32:
+        flags |= EPI_OUT_F32
+    d.flags = flags
+    return d
+
+
+def conv2d_fwd(x, wp, k, stride, pad, Cout, *, act="linear", scale=None, shift=None, res=None, stats=None,
+               out=None, out_f32=False):
+    """y = epilogue(conv(x, w)); x [B,Hi,Wi,Cin] channels-last, wp = pack_weight(w)."""
+    _require_cuda(x, wp)
+    B, Hi, Wi, Cin = x.shape
+    Ho, Wo = conv_out_size(Hi, k, stride, pad), conv_out_size(Wi, k, stride, pad)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    d = make_conv_desc(x, wp, out, Hi=Hi, Wi=Wi, Cin=Cin, Cout=Cout, Hg=Ho, Wg=Wo, Ho=Ho, Wo=Wo,
+                       taps=fwd_taps(k, pad), isy=stride, isx=stride, act=act, scale=scale, shift=shift,
+                       res=res, stats=stats, out_f32=out_f32)
+    check(load().dyk_conv_igemm(ctypes.byref(d), _stream()), "dyk_conv_igemm")
+    return out
+
+
+def conv2d_dgrad(dy, wpt, k, stride, pad, Hi, Wi, Cin, *, out=None, accumulate=False):
+    """dx = conv_transpose(dy, w); dy [B,Ho,Wo,Cout], wpt = pack_weight(w, transposed=True)."""
+    _require_cuda(dy, wpt)
+    B, Ho, Wo, Cout = dy.shape
+    if out is None:
+        out = torch.empty((B, Hi, Wi, Cin), dtype=dy.dtype, device=dy.device)
+    for (py, px, Hg, Wg, taps) in dgrad_classes(k, pad, stride, Hi, Wi):
+        d = make_conv_desc(dy, wpt, out, Hi=Ho, Wi=Wo, Cin=Cout, Cout=Cin, Hg=Hg, Wg=Wg, Ho=Hi, Wo=Wi,
+                           taps=taps, osy=stride, osx=stride, ooy=py, oox=px, accumulate=accumulate)
+        check(load().dyk_conv_igemm(ctypes.byref(d), _stream()), "dyk_conv_igemm(dgrad)")
+    return out

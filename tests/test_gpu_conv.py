@@ -1,0 +1,110 @@
+"""GPU parity of the implicit-GEMM convolution (dyk_conv_igemm) against torch CPU fp32 conv2d.
+
+The checker here is plain torch.nn.functional on the CPU (same arithmetic the oracle uses for
+models.py:34-62); the thing under test is reached only through the C ABI.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (B, Cin, Cout, H, W, k, stride)
+    (2, 32, 64, 16, 20, 3, 1),
+    (2, 64, 32, 17, 23, 3, 1),      # ragged spatial extent
+    (1, 128, 128, 32, 40, 3, 1),
+    (2, 64, 128, 16, 20, 3, 2),
+    (2, 64, 64, 15, 21, 3, 2),      # odd size stride 2
+    (2, 128, 64, 16, 20, 1, 1),
+    (1, 256, 18, 16, 20, 1, 1),     # head: Cout not a multiple of 4*...
+    (1, 64, 160, 8, 12, 1, 1),      # Cout tile tail (160 = 128 + 32)
+    (1, 32, 32, 12, 12, 1, 2),      # 1x1 stride 2
+    (1, 64, 64, 12, 12, 5, 1),      # 25 taps
+]
+
+
+def _ref_nhwc(t):  # NCHW cpu -> channels-last cuda handled by the product converters
+    return t
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_and_dgrad(case, dtype):
+    from dyk import ops
+    B, Cin, Cout, H, W, k, s = case
+    pad = k // 2
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    if dtype == torch.bfloat16:  # the checker sees the same rounded operands
+        x = x.bfloat16().float()
+        w = w.bfloat16().float()
+    y_ref = F.conv2d(x, w, stride=s, padding=pad)
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+
+    xd = ops.to_nhwc(x.cuda(), dtype)
+    wp = ops.pack_weight(w.cuda(), dtype)
+    y = ops.conv2d_fwd(xd, wp, k, s, pad, Cout)
+    y_nchw = ops.to_nchw(y).cpu()
+    err = (y_nchw - y_ref).abs().max().item()
+    assert err <= tol * max(1.0, y_ref.abs().max().item()), "fwd max err %g" % err
+
+    # data gradient: dx = conv_transpose(dy, w)
+    dy = torch.randn(y_ref.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, w, dy, stride=s, padding=pad)
+    dyd = ops.to_nhwc(dy.cuda(), dtype)
+    wpt = ops.pack_weight(w.cuda(), dtype, transposed=True)
+    dx = ops.conv2d_dgrad(dyd, wpt, k, s, pad, H, W, Cin)
+    dx_nchw = ops.to_nchw(dx).cpu()
+    err = (dx_nchw - dx_ref).abs().max().item()
+    assert err <= tol * max(1.0, dx_ref.abs().max().item()), "dgrad max err %g" % err
+    # accumulate flag: second pass adds onto the first
+    ops.conv2d_dgrad(dyd, wpt, k, s, pad, H, W, Cin, out=dx, accumulate=True)
+    err = (ops.to_nchw(dx).cpu() - 2 * dx_ref).abs().max().item()
+    assert err <= 2.5 * tol * max(1.0, dx_ref.abs().max().item()), "dgrad accumulate max err %g" % err
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_epilogue(dtype):
+    """affine + activation + residual + per-channel statistics + fp32 output + channel-slice output."""
+    from dyk import ops
+    B, Cin, Cout, H, W, k = 2, 64, 96, 16, 20, 3
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * 9) ** 0.5
+    res = torch.randn(B, Cout, H, W, generator=g)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g)
+    if dtype == torch.bfloat16:
+        x, w, res = x.bfloat16().float(), w.bfloat16().float(), res.bfloat16().float()
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+    conv = F.conv2d(x, w, padding=1)
+    xd = ops.to_nhwc(x.cuda(), dtype)
+    wp = ops.pack_weight(w.cuda(), dtype)
+    resd = ops.to_nhwc(res.cuda(), dtype)
+    for act, fn in [("leaky", lambda t: F.leaky_relu(t, 0.1)), ("mish", F.mish), ("relu6", F.relu6),
+                    ("hard-swish", F.hardswish), ("hard-sigmoid", F.hardsigmoid), ("relu", F.relu)]:
+        y_ref = fn(conv * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) + res
+        # write into a channel slice [32:128] of a 160-channel buffer
+        buf = torch.zeros(B, H, W, 160, dtype=dtype, device="cuda")
+        out = buf[..., 32:32 + Cout]
+        ops.conv2d_fwd(xd, wp, k, 1, 1, Cout, act=act, scale=scale.cuda(), shift=shift.cuda(), res=resd, out=out)
+        y = ops.to_nchw(out).cpu()
+        err = (y - y_ref).abs().max().item()
+        assert err <= tol * max(1.0, y_ref.abs().max().item()), "%s max err %g" % (act, err)
+        assert buf[..., :32].abs().max().item() == 0 and buf[..., 128:].abs().max().item() == 0
+    # statistics + fp32 output
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device="cuda")
+    y32 = ops.conv2d_fwd(xd, wp, k, 1, 1, Cout, stats=stats, out_f32=True)
+    assert y32.dtype == torch.float32
+    n = B * H * W
+    s = stats.cpu()
+    mean_ref = conv.mean(dim=(0, 2, 3)).double()
+    sq_ref = (conv.double() ** 2).mean(dim=(0, 2, 3))
+    assert (s[:Cout] / n - mean_ref).abs().max().item() < 1e-4
+    assert ((s[Cout:] / n - sq_ref).abs() / sq_ref).max().item() < 1e-3
+    err = (y32.permute(0, 3, 1, 2).cpu() - conv).abs().max().item()
+    assert err <= 1e-3 * max(1.0, conv.abs().max().item())

@@ -1,0 +1,93 @@
+"""Hardware probes + conv micro-benchmarks, run on the GPU box.  Writes gpurun_out/probe.json.
+Usage: python tools/gpu_probe.py [tr16] [mfma] [convbench]"""
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "double-yolo-kaist_amd")
+sys.path[:0] = [ROOT, PKG]
+import torch  # noqa: E402
+
+from dyk import ops  # noqa: E402
+
+OUT = os.path.join(ROOT, "gpurun_out")
+os.makedirs(OUT, exist_ok=True)
+res = {}
+what = sys.argv[1:] or ["tr16", "mfma", "convbench"]
+probe = ctypes.CDLL(os.path.join(PKG, "csrc", "libdyk_probe.so"))
+
+
+def tr16(addrs):
+    a = torch.tensor(addrs, dtype=torch.int32, device="cuda")
+    o = torch.zeros(256, dtype=torch.int16, device="cuda")
+    rc = probe.dyk_probe_tr16(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(o.data_ptr()), None)
+    torch.cuda.synchronize()
+    assert rc == 0
+    return o.cpu().view(64, 4).tolist()
+
+
+if "tr16" in what:
+    # LDS holds u16 element index i at byte 2*i.  Pattern A: lane l -> byte 8*l (contiguous).
+    res["tr16_contig8"] = tr16([8 * l for l in range(64)])
+    # Pattern B: rows of 64 elements (128 B): lane l -> row (l%16)//4 ... see analysis in DESIGN
+    res["tr16_row128_q4"] = tr16([((l % 16) // 4) * 128 + (l % 4) * 8 + (l // 16) * 512 for l in range(64)])
+    # Pattern C: lane l -> row l%16 (128 B rows), col block l//16
+    res["tr16_row128_l16"] = tr16([(l % 16) * 128 + (l // 16) * 8 for l in range(64)])
+    # Pattern D: rows of 32 B (16 elements) : lane -> row (l%16)//4, 8-byte piece l%4, group l//16 -> +128 B
+    res["tr16_row32"] = tr16([((l % 16) // 4) * 32 + (l % 4) * 8 + (l // 16) * 128 for l in range(64)])
+
+if "mfma" in what:
+    g = torch.Generator().manual_seed(0)
+    A = torch.randint(-4, 5, (16, 32), generator=g).float()
+    B = torch.randint(-4, 5, (32, 16), generator=g).float()
+    D = torch.zeros(16, 16, device="cuda")
+    Ad, Bd = A.cuda(), B.cuda()
+    probe.dyk_probe_mfma_layout(ctypes.c_void_p(Ad.data_ptr()), ctypes.c_void_p(Bd.data_ptr()),
+                                ctypes.c_void_p(D.data_ptr()), None)
+    torch.cuda.synchronize()
+    res["mfma_layout_maxerr"] = (D.cpu() - A @ B).abs().max().item()
+
+if "convbench" in what:
+    shapes = [  # (Cin, Cout, H, W, k, s) at B=16 : the dominant C3 problems
+        (128, 128, 64, 80, 3, 1), (256, 256, 32, 40, 3, 1), (512, 512, 16, 20, 3, 1), (64, 64, 128, 160, 3, 1),
+        (512, 1024, 16, 20, 3, 1), (256, 512, 32, 40, 3, 1), (128, 256, 64, 80, 3, 1), (32, 64, 256, 320, 3, 1),
+        (512, 256, 64, 80, 3, 1), (1024, 512, 32, 40, 3, 1), (2048, 1024, 16, 20, 3, 1),
+        (64, 128, 256, 320, 3, 2), (256, 512, 64, 80, 3, 2),
+        (128, 128, 64, 80, 1, 1), (256, 256, 32, 40, 1, 1), (512, 256, 32, 40, 1, 1), (1024, 512, 16, 20, 1, 1),
+        (64, 64, 256, 320, 1, 1),
+    ]
+    rows = []
+    for dt in (torch.bfloat16, torch.float32):
+        for (ci, co, H, W, k, s) in shapes:
+            if dt == torch.float32 and H * W > 64 * 80:
+                continue
+            B = 16
+            x = torch.randn(B, H, W, ci, device="cuda").to(dt)
+            w = torch.randn(co, ci, k, k, device="cuda") * 0.05
+            wp = ops.pack_weight(w, dt)
+            Ho, Wo = ops.conv_out_size(H, k, s, k // 2), ops.conv_out_size(W, k, s, k // 2)
+            out = torch.empty(B, Ho, Wo, co, device="cuda", dtype=dt)
+            for _ in range(3):
+                ops.conv2d_fwd(x, wp, k, s, k // 2, co, out=out)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 20
+            e0.record()
+            for _ in range(n):
+                ops.conv2d_fwd(x, wp, k, s, k // 2, co, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            fl = 2.0 * B * Ho * Wo * co * ci * k * k
+            by = (x.numel() + out.numel() + wp.numel()) * x.element_size()
+            rows.append(dict(dtype=str(dt), cin=ci, cout=co, H=H, W=W, k=k, s=s, ms=ms, tflops=fl / ms / 1e9,
+                             gbps=by / ms / 1e6))
+            print(rows[-1], flush=True)
+    res["convbench"] = rows
+
+with open(os.path.join(OUT, "probe.json"), "w") as f:
+    json.dump(res, f, indent=1)
+print("wrote probe.json")
