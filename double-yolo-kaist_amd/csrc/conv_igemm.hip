@@ -24,6 +24,9 @@ struct ConvArgs {
     DykConvDesc d;
 };
 
+// set by the launcher when y / ldy allow 8/16-byte vector stores
+constexpr int EPI_INTERNAL_VEC = 1 << 30;
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     static __device__ inline void run(f32x4_t& acc, const uint4& a, const uint4& b) {
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
                     if (a.shift) sh[r] = a.shift[m + r];
                 }
         }
-        const bool full = (m + 3 < a.Cout);
+        const bool full = (m + 3 < a.Cout) && (flags & EPI_INTERNAL_VEC);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int nl = wn * WTN + ni * 16 + (lane & 15);
@@ -312,6 +315,9 @@ int launch_conv(const DykConvDesc* d, hipStream_t stream) {
     const int tiles_m = dyk_div_up(d->Cout, BM);
     ConvArgs args;
     args.d = *d;
+    const size_t vec_bytes = ((d->flags & DYK_EPI_OUT_F32) || sizeof(T) == 4) ? 16 : 8;
+    if ((d->ldy % 4) == 0 && ((uintptr_t)d->y % vec_bytes) == 0) args.d.flags |= EPI_INTERNAL_VEC;
+    else args.d.flags &= ~EPI_INTERNAL_VEC;
     hipLaunchKernelGGL(kfn, dim3(tiles_n * tiles_m), dim3(256), lds, stream, args);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
@@ -342,7 +348,7 @@ extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
     if ((d->flags & DYK_EPI_STATS) && !d->stats) return DYK_ERR_ARG;
     if ((d->flags & DYK_EPI_RESIDUAL) && !d->res) return DYK_ERR_ARG;
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
-    if (d->ldx % epv || d->ldy % 4) return DYK_ERR_ARG;
+    if (d->ldx % epv || ((uintptr_t)d->x % 16) || ((uintptr_t)d->w % 16)) return DYK_ERR_ARG;
     // 32-bit element offsets inside the kernel
     if ((long)d->B * d->Hi * d->Wi * d->ldx >= (1L << 31)) return DYK_ERR_ARG;
     if ((long)d->B * d->Ho * d->Wo * d->ldy >= (1L << 31)) return DYK_ERR_ARG;

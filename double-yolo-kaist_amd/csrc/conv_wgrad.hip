@@ -1,0 +1,273 @@
+// Convolution weight gradient on the matrix cores:
+//     dw[t][co][ci] += sum_n dy[n][co] * x[src(n, t)][ci]        (fp32, packed [tap][Cout][Cin])
+// GEMM view per tap: M = Cout, N = Cin, K = output pixels n = (b, yo, xo); split-K over pixel
+// ranges, partial tiles combined with fp32 atomics straight into the gradient buffer (which
+// is therefore also where gradient accumulation over micro-batches happens).
+//
+// Both operands are channels-last, i.e. K (pixels) is the *strided* dimension, so tiles are
+// staged pixel-major in LDS ([k][channel], exactly as they sit in HBM, coalesced 16-byte
+// loads) and transposed on the way to the MFMA operand registers:
+//   bf16: ds_read_b64_tr_b16 -- within a 16-lane group, lane o receives element e of
+//         M[4e + (o>>2)][o&3] where M[i] are the 8 bytes at lane i's address (pinned by
+//         tools/gpu_probe.py on gfx950).  Lane i = 4e+q points at pixel row e, channels
+//         m0+4q.. so lane o ends up with 4 consecutive pixels of channel m0+o.
+//   f32:  one ds_read_b32 per lane (v_mfma_f32_16x16x4_f32 takes one k per lane).
+//
+// Replaces autograd's convolution_backward (weight gradient) for nn.Conv2d at reference
+// models.py:34-42.
+#include "dyk_common.h"
+
+namespace {
+
+typedef short v4i16_t __attribute__((__vector_size__(4 * sizeof(short))));
+#define LDS_AS __attribute__((address_space(3)))
+
+template <typename T> struct WgTraits;
+template <> struct WgTraits<bf16_t> { static constexpr int ROWS = 64; };  // pixels per K step
+template <> struct WgTraits<float>  { static constexpr int ROWS = 32; };
+
+// byte offset of (row, channel) in a [ROWS][C] tile, row bytes RB = C*sizeof(T)
+template <typename T, int C> __device__ inline int wg_off(int row, int ch) {
+    constexpr int RB = C * (int)sizeof(T);
+    if (sizeof(T) == 2) {
+        constexpr int NCH = RB / 32;                     // 32-byte chunks per row
+        const int f = ((row & 3) | (((row >> 3) & 1) << 2)) & (NCH - 1);
+        const int chunk = (ch >> 4) ^ f;
+        return row * RB + chunk * 32 + (ch & 15) * 2;
+    } else {
+        constexpr int NCH = RB / 64;                     // 64-byte chunks per row
+        const int chunk = (ch >> 4) ^ (row & 1 & (NCH - 1));
+        return row * RB + chunk * 64 + (ch & 15) * 4;
+    }
+}
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, const int splits, const int chunk) {
+    constexpr int ROWS = WgTraits<T>::ROWS;
+    constexpr int EPV = 16 / (int)sizeof(T);
+    constexpr int VPR_A = BM / EPV, VPR_B = BN / EPV;          // 16-byte vectors per tile row
+    constexpr int NV_A = ROWS * VPR_A, NV_B = ROWS * VPR_B;
+    constexpr int NPA = (NV_A + 255) / 256, NPB = (NV_B + 255) / 256;
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    constexpr int A_BYTES = ROWS * BM * (int)sizeof(T), B_BYTES = ROWS * BN * (int)sizeof(T);
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                    // [2][A_BYTES]  dy tile
+    char* sB = smem + 2 * A_BYTES;      // [2][B_BYTES]  x tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    const int tiles_m = (a.Cout + BM - 1) / BM;
+    const int tiles_n = (a.Cin + BN - 1) / BN;
+    int bid = blockIdx.x;
+    const int tm = bid % tiles_m; bid /= tiles_m;
+    const int tn = bid % tiles_n; bid /= tiles_n;
+    const int tap = bid % a.ntaps;
+    const int sp = bid / a.ntaps;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int HWo = a.Ho * a.Wo;
+    const int Ntot = a.B * HWo;
+    const int p_begin = sp * chunk;
+    const int p_end = min(Ntot, p_begin + chunk);
+    if (p_begin >= p_end) return;
+    const int tdy = a.tdy[tap], tdx = a.tdx[tap];
+
+    // ---- loader state: each thread owns NPA dy vectors and NPB x vectors per step
+    const T* __restrict__ dyg = (const T*)a.dy;
+    const T* __restrict__ xg = (const T*)a.x;
+    int a_row[NPA], a_ch[NPA];
+    int b_row[NPB], b_ch[NPB];
+    int b_img[NPB], b_yo[NPB], b_xo[NPB];      // decomposition of the pixel of row b_row at step 0
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int v = i * 256 + tid;
+        a_row[i] = v / VPR_A; a_ch[i] = (v % VPR_A) * EPV;
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int v = i * 256 + tid;
+        b_row[i] = v / VPR_B; b_ch[i] = (v % VPR_B) * EPV;
+        const int n = p_begin + b_row[i];
+        const int b = n / HWo, r = n - b * HWo;
+        b_img[i] = b; b_yo[i] = r / a.Wo; b_xo[i] = r - b_yo[i] * a.Wo;
+    }
+    uint4 ra[NPA], rb[NPB];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto gload = [&](int p0) {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int n = p0 + a_row[i];
+            const int c = m0 + a_ch[i];
+            const bool ok = (NV_A % 256 == 0 || i * 256 + tid < NV_A) && n < p_end && c < a.Cout;
+            ra[i] = ok ? *(const uint4*)(dyg + (long)n * a.lddy + c) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int n = p0 + b_row[i];
+            const int c = n0 + b_ch[i];
+            const int yi = b_yo[i] * a.isy + tdy, xi = b_xo[i] * a.isx + tdx;
+            const bool ok = (NV_B % 256 == 0 || i * 256 + tid < NV_B) && n < p_end && c < a.Cin &&
+                            ((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi);
+            rb[i] = ok ? *(const uint4*)(xg + ((long)(b_img[i] * a.Hi + yi) * a.Wi + xi) * a.ldx + c) : zero4;
+            // advance the pixel decomposition by ROWS for the next step
+            int xo = b_xo[i] + ROWS, yo = b_yo[i], bb = b_img[i];
+            while (xo >= a.Wo) { xo -= a.Wo; ++yo; }
+            while (yo >= a.Ho) { yo -= a.Ho; ++bb; }
+            b_xo[i] = xo; b_yo[i] = yo; b_img[i] = bb;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i)
+            if (NV_A % 256 == 0 || i * 256 + tid < NV_A)
+                *(uint4*)(sA + buf * A_BYTES + wg_off<T, BM>(a_row[i], a_ch[i])) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NPB; ++i)
+            if (NV_B % 256 == 0 || i * 256 + tid < NV_B)
+                *(uint4*)(sB + buf * B_BYTES + wg_off<T, BN>(b_row[i], b_ch[i])) = rb[i];
+    };
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int S = (p_end - p_begin + ROWS - 1) / ROWS;
+    gload(p_begin);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+        const bool more = (s + 1 < S);
+        if (more) gload(p_begin + (s + 1) * ROWS);
+        const char* pa = sA + (s & 1) * A_BYTES;
+        const char* pb = sB + (s & 1) * B_BYTES;
+        if constexpr (sizeof(T) == 2) {
+            const int i16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+            for (int kk = 0; kk < ROWS / 32; ++kk) {
+                uint4 fa[MI], fb[NI];
+                const int r0 = kk * 32 + kq * 8 + (i16 >> 2);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int ch = wm * WTM + mi * 16 + 4 * (i16 & 3);
+                    v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS v4i16_t*)(LDS_AS char*)(pa + wg_off<T, BM>(r0, ch)));
+                    v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS v4i16_t*)(LDS_AS char*)(pa + wg_off<T, BM>(r0 + 4, ch)));
+                    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    fa[mi] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int ch = wn * WTN + ni * 16 + 4 * (i16 & 3);
+                    v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS v4i16_t*)(LDS_AS char*)(pb + wg_off<T, BN>(r0, ch)));
+                    v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS v4i16_t*)(LDS_AS char*)(pb + wg_off<T, BN>(r0 + 4, ch)));
+                    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    fb[ni] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, fa[mi]), __builtin_bit_cast(bf16x8_t, fb[ni]), acc[mi][ni], 0, 0, 0);
+            }
+        } else {
+            const int i16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+            for (int kk = 0; kk < ROWS / 4; ++kk) {
+                float fa[MI], fb[NI];
+                const int r0 = kk * 4 + kq;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    fa[mi] = *(const float*)(pa + wg_off<T, BM>(r0, wm * WTM + mi * 16 + i16));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    fb[ni] = *(const float*)(pb + wg_off<T, BN>(r0, wn * WTN + ni * 16 + i16));
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        if (more) lstore((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[r] = D[co = (lane>>4)*4 + r][ci = lane&15]
+    float* dw = a.dw + (long)a.twt[tap] * a.Cout * a.Cin;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = m0 + wm * WTM + mi * 16 + (lane >> 4) * 4 + r;
+            if (co >= a.Cout) continue;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int ci = n0 + wn * WTN + ni * 16 + (lane & 15);
+                if (ci < a.Cin) unsafeAtomicAdd(dw + (long)co * a.Cin + ci, acc[mi][ni][r]);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN>
+int launch_wgrad(const DykWgradDesc* d, hipStream_t stream) {
+    constexpr int ROWS = WgTraits<T>::ROWS;
+    constexpr size_t lds = 2 * (size_t)ROWS * (BM + BN) * sizeof(T);
+    static bool attr_set = false;
+    auto kfn = conv_wgrad_kernel<T, BM, BN>;
+    if (!attr_set) {
+        DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const long Ntot = (long)d->B * d->Ho * d->Wo;
+    const int tiles = dyk_div_up(d->Cout, BM) * dyk_div_up(d->Cin, BN) * d->ntaps;
+    const int ksteps = dyk_div_up(Ntot, ROWS);
+    int splits = d->splits;
+    if (splits <= 0) {
+        splits = dyk_div_up(1536, tiles);            // ~6 blocks per CU
+        const int max_splits = ksteps / 4 > 0 ? ksteps / 4 : 1;   // at least 4 K steps per block
+        if (splits > max_splits) splits = max_splits;
+    }
+    if (splits > ksteps) splits = ksteps;
+    const int chunk = dyk_div_up(ksteps, splits) * ROWS;
+    splits = dyk_div_up(Ntot, chunk);
+    hipLaunchKernelGGL(kfn, dim3(tiles * splits), dim3(256), lds, stream, *d, splits, chunk);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+template <typename T, int BM>
+int dispatch_wgrad_n(const DykWgradDesc* d, hipStream_t s) {
+    if (d->Cin > 64) return launch_wgrad<T, BM, 128>(d, s);
+    if (d->Cin > 32) return launch_wgrad<T, BM, 64>(d, s);
+    return launch_wgrad<T, BM, 32>(d, s);
+}
+template <typename T>
+int dispatch_wgrad(const DykWgradDesc* d, hipStream_t s) {
+    if (d->Cout > 64) return dispatch_wgrad_n<T, 128>(d, s);
+    if (d->Cout > 32) return dispatch_wgrad_n<T, 64>(d, s);
+    return dispatch_wgrad_n<T, 32>(d, s);
+}
+
+}  // namespace
+
+extern "C" int dyk_conv_wgrad(const DykWgradDesc* d, void* stream) {
+    if (!d || !d->x || !d->dy || !d->dw) return DYK_ERR_ARG;
+    if (d->ntaps <= 0 || d->ntaps > DYK_MAX_TAPS) return DYK_ERR_ARG;
+    if (d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0 || d->Cin <= 0) return DYK_ERR_ARG;
+    const int epv = d->dtype == DYK_BF16 ? 8 : 4;
+    // every 16-byte load must stay inside its pixel row: ld >= round_up(C, epv)
+    if (d->ldx % epv || d->lddy % epv) return DYK_ERR_ARG;
+    if (d->ldx < (d->Cin + epv - 1) / epv * epv || d->lddy < (d->Cout + epv - 1) / epv * epv) return DYK_ERR_ARG;
+    if (((uintptr_t)d->x % 16) || ((uintptr_t)d->dy % 16)) return DYK_ERR_ARG;
+    if ((long)d->B * d->Ho * d->Wo >= (1L << 31)) return DYK_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == DYK_BF16) return dispatch_wgrad<bf16_t>(d, s);
+    if (d->dtype == DYK_F32) return dispatch_wgrad<float>(d, s);
+    return DYK_ERR_ARG;
+}

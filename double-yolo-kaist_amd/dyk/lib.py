@@ -43,6 +43,20 @@ class DykConvDesc(ctypes.Structure):
     ]
 
 
+class DykWgradDesc(ctypes.Structure):
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p),
+        ("dtype", ctypes.c_int32), ("ldx", ctypes.c_int32), ("lddy", ctypes.c_int32),
+        ("B", ctypes.c_int32), ("Hi", ctypes.c_int32), ("Wi", ctypes.c_int32), ("Cin", ctypes.c_int32),
+        ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32), ("Cout", ctypes.c_int32),
+        ("isy", ctypes.c_int32), ("isx", ctypes.c_int32),
+        ("ntaps", ctypes.c_int32),
+        ("tdy", ctypes.c_int8 * MAX_TAPS), ("tdx", ctypes.c_int8 * MAX_TAPS), ("twt", ctypes.c_int8 * MAX_TAPS),
+        ("_pad", ctypes.c_int8),
+        ("splits", ctypes.c_int32),
+    ]
+
+
 _lib = None
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against
@@ -52,6 +66,7 @@ SIGNATURES = {
     "dyk_abi_version": (_i32, []),
     "dyk_error_string": (ctypes.c_char_p, [_i32]),
     "dyk_conv_igemm": (_i32, [ctypes.POINTER(DykConvDesc), _vp]),
+    "dyk_conv_wgrad": (_i32, [ctypes.POINTER(DykWgradDesc), _vp]),
     "dyk_pack_conv_weight": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dyk_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dyk_nhwc_to_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

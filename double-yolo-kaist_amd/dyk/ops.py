@@ -10,7 +10,7 @@ import torch
 
 from . import lib as _l
 from .lib import (ACT_CODES, DYK_BF16, DYK_F32, EPI_ACCUM, EPI_AFFINE, EPI_OUT_F32, EPI_RESIDUAL, EPI_STATS,
-                  DykConvDesc, check, load)
+                  DykConvDesc, DykWgradDesc, check, load)
 
 
 def dtype_code(dt):
@@ -186,3 +186,27 @@ def conv2d_dgrad(dy, wpt, k, stride, pad, Hi, Wi, Cin, *, out=None, accumulate=F
                            taps=taps, osy=stride, osx=stride, ooy=py, oox=px, accumulate=accumulate)
         check(load().dyk_conv_igemm(ctypes.byref(d), _stream()), "dyk_conv_igemm(dgrad)")
     return out
+
+
+def conv2d_wgrad(x, dy, k, stride, pad, *, dw=None, splits=0, Cin=None, Cout=None):
+    """dw[t][co][ci] += sum_n dy[n][co] x[src(n,t)][ci]  (fp32, packed tap-major order)."""
+    _require_cuda(x, dy)
+    B, Hi, Wi, Cx = x.shape
+    _, Ho, Wo, Cy = dy.shape
+    Cin = Cin or Cx
+    Cout = Cout or Cy
+    if dw is None:
+        dw = torch.zeros((k * k, Cout, Cin), dtype=torch.float32, device=x.device)
+    d = DykWgradDesc()
+    d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+    d.dtype = dtype_code(x.dtype)
+    d.ldx, d.lddy = nhwc_ld(x), nhwc_ld(dy)
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, Hi, Wi, Cin, Ho, Wo, Cout
+    d.isy = d.isx = stride
+    taps = fwd_taps(k, pad)
+    d.ntaps = len(taps)
+    for i, (ty, tx, wt) in enumerate(taps):
+        d.tdy[i], d.tdx[i], d.twt[i] = ty, tx, wt
+    d.splits = splits
+    check(load().dyk_conv_wgrad(ctypes.byref(d), _stream()), "dyk_conv_wgrad")
+    return dw

@@ -103,6 +103,32 @@ typedef struct DykConvDesc {
 
 int dyk_conv_igemm(const DykConvDesc* desc, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Convolution weight gradient (split-K MFMA GEMM over output pixels, fp32 atomics):
+ *     dw[twt[t]][co][ci] += sum_{b,yo,xo} dy[b,yo,xo,co] * x[b, yo*isy + tdy[t], xo*isx + tdx[t], ci]
+ * dw is the fp32 gradient in the packed [tap][Cout][Cin] order (the order the master weights
+ * are stored in); it is ACCUMULATED into, so the caller zeroes it when a fresh
+ * gradient is wanted.  Replaces autograd's convolution_backward(weight) for models.py:34-42.
+ * Rows of x / dy must be readable up to round_up(C, 16 bytes) (ld >= that).
+ * ---------------------------------------------------------------------------------- */
+typedef struct DykWgradDesc {
+    const void* x;
+    const void* dy;
+    float* dw;
+    int32_t dtype;
+    int32_t ldx, lddy;
+    int32_t B, Hi, Wi, Cin, Ho, Wo, Cout;
+    int32_t isy, isx;
+    int32_t ntaps;
+    int8_t tdy[DYK_MAX_TAPS];
+    int8_t tdx[DYK_MAX_TAPS];
+    int8_t twt[DYK_MAX_TAPS];
+    int8_t _pad;
+    int32_t splits;                 /* K splits; <= 0 selects automatically */
+} DykWgradDesc;
+
+int dyk_conv_wgrad(const DykWgradDesc* desc, void* stream);
+
 /* Weight pack: torch OIHW float32 [Cout][Cin][kh][kw] (nn.Conv2d.weight, models.py:34)
  *   transposed == 0:  out[t][co][ci] = w[co][ci][t]     (forward)
  *   transposed == 1:  out[t][ci][co] = w[co][ci][t]     (data gradient: roles of Cin/Cout swap)

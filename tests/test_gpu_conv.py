@@ -55,8 +55,9 @@ def test_conv_fwd_and_dgrad(case, dtype):
     if dtype == torch.bfloat16:
         dy = dy.bfloat16().float()
     dx_ref = torch.nn.grad.conv2d_input(x.shape, w, dy, stride=s, padding=pad)
-    dyd = ops.to_nhwc(dy.cuda(), dtype)
-    wpt = ops.pack_weight(w.cuda(), dtype, transposed=True)
+    cpad = (Cout + 31) // 32 * 32   # the gradient GEMM's K must be a multiple of 32 channels
+    dyd = ops.to_nhwc(dy.cuda(), dtype, cpad=cpad)
+    wpt = ops.pack_weight(w.cuda(), dtype, transposed=True, cout_pad=cpad)
     dx = ops.conv2d_dgrad(dyd, wpt, k, s, pad, H, W, Cin)
     dx_nchw = ops.to_nchw(dx).cpu()
     err = (dx_nchw - dx_ref).abs().max().item()
@@ -108,3 +109,50 @@ def test_conv_epilogue(dtype):
     assert ((s[Cout:] / n - sq_ref).abs() / sq_ref).max().item() < 1e-3
     err = (y32.permute(0, 3, 1, 2).cpu() - conv).abs().max().item()
     assert err <= 1e-3 * max(1.0, conv.abs().max().item())
+
+
+WG_CASES = [
+    (2, 32, 64, 16, 20, 3, 1), (2, 64, 32, 17, 23, 3, 1), (1, 128, 128, 32, 40, 3, 1), (2, 64, 128, 16, 20, 3, 2),
+    (2, 64, 64, 15, 21, 3, 2), (2, 128, 64, 16, 20, 1, 1), (1, 64, 160, 8, 12, 1, 1), (3, 256, 256, 8, 10, 3, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", WG_CASES)
+def test_conv_wgrad(case, dtype):
+    from dyk import ops
+    B, Cin, Cout, H, W, k, s = case
+    pad = k // 2
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    Ho, Wo = ops.conv_out_size(H, k, s, pad), ops.conv_out_size(W, k, s, pad)
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g)
+    if dtype == torch.bfloat16:
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+    dw_ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, stride=s, padding=pad)
+    xd, dyd = ops.to_nhwc(x.cuda(), dtype), ops.to_nhwc(dy.cuda(), dtype)
+    for splits in (0, 1, 3):
+        dw = ops.conv2d_wgrad(xd, dyd, k, s, pad, splits=splits)          # [t][co][ci]
+        got = dw.view(k, k, Cout, Cin).permute(2, 3, 0, 1).cpu()
+        err = (got - dw_ref).abs().max().item()
+        assert err <= 1e-4 * max(1.0, dw_ref.abs().max().item()), "wgrad splits=%d max err %g" % (splits, err)
+    # accumulation into an existing gradient
+    ops.conv2d_wgrad(xd, dyd, k, s, pad, dw=dw)
+    err = (dw.view(k, k, Cout, Cin).permute(2, 3, 0, 1).cpu() - 2 * dw_ref).abs().max().item()
+    assert err <= 2e-4 * max(1.0, dw_ref.abs().max().item())
+
+
+def test_conv_wgrad_head_padded_ld():
+    """Cout = 18 head gradient living in a ld = 32 buffer (tail channels hold garbage)."""
+    from dyk import ops
+    B, Cin, Cout, H, W = 2, 64, 18, 8, 10
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    dy = torch.randn(B, Cout, H, W, generator=g).bfloat16().float()
+    dw_ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 1, 1), dy)
+    xd = ops.to_nhwc(x.cuda(), torch.bfloat16)
+    buf = torch.full((B, H, W, 32), 1e30, dtype=torch.bfloat16, device="cuda")
+    ops.to_nhwc(dy.cuda(), torch.bfloat16, out=buf[..., :Cout])
+    dw = ops.conv2d_wgrad(xd, buf[..., :Cout], 1, 1, 0)
+    err = (dw.view(Cout, Cin).cpu() - dw_ref.view(Cout, Cin)).abs().max().item()
+    assert err <= 1e-4 * max(1.0, dw_ref.abs().max().item())
