@@ -1,0 +1,256 @@
+// BatchNorm2d (train-mode batch statistics) + activation, forward and backward.  All HBM-bound
+// channels-last kernels, 16-byte vectors, per-channel parameters in fp32, cross-block
+// reductions in fp64 atomics.
+//
+// Forward of nn.Sequential(Conv2d, BatchNorm2d, act) (reference models.py:34-62) in training:
+//   conv kernel (raw output + per-channel sum / sum^2)  ->  dyk_bn_finalize  ->  dyk_bn_act_fwd
+// Backward:
+//   dyk_bn_act_bwd_reduce (sum dact, sum dact*xhat) -> dyk_bn_bwd_params (dgamma, dbeta)
+//   -> dyk_bn_act_bwd_apply (gradient w.r.t. the raw conv output) -> conv dgrad / wgrad.
+#include "dyk_common.h"
+
+namespace {
+
+__global__ void bn_finalize_kernel(DykBnFinalizeDesc d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.C) return;
+    const double n = (double)d.count;
+    const double s1 = d.stats[c], s2 = d.stats[d.C + c];
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)d.eps));
+    const float g = d.gamma ? d.gamma[c] : 1.f, b = d.beta ? d.beta[c] : 0.f;
+    const float sc = g * rstd;
+    d.scale[c] = sc;
+    d.shift[c] = b - (float)mean * sc;
+    if (d.save_mean) d.save_mean[c] = (float)mean;
+    if (d.save_rstd) d.save_rstd[c] = rstd;
+    if (d.running_mean) {
+        const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+        d.running_mean[c] = (1.f - d.momentum) * d.running_mean[c] + d.momentum * (float)mean;
+        d.running_var[c] = (1.f - d.momentum) * d.running_var[c] + d.momentum * (float)unb;
+    }
+    d.stats[c] = 0.0;            // ready for the next step
+    d.stats[d.C + c] = 0.0;
+}
+
+// eval-mode BN folded to scale/shift: scale = gamma / sqrt(running_var + eps)
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                               float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = (gamma ? gamma[c] : 1.f) / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwDesc d) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    const int CV = d.C / EPV;
+    const long total = (long)d.npix * CV;
+    const T* __restrict__ a = (const T*)d.a;
+    const T* __restrict__ r = (const T*)d.b;
+    T* __restrict__ o = (T*)d.out;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+        const long p = v / CV;
+        const int c = (int)(v - p * CV) * EPV;
+        float x[EPV], y[EPV];
+        vec_unpack<T>(*(const uint4*)(a + p * d.lda + c), x);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            const float sc = d.p0 ? d.p0[c + j] : 1.f, sh = d.p1 ? d.p1[c + j] : 0.f;
+            y[j] = act_fwd(d.act, x[j] * sc + sh);
+        }
+        if (r) {
+            float rr[EPV];
+            vec_unpack<T>(*(const uint4*)(r + p * d.ldb + c), rr);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) y[j] += rr[j];
+        }
+        *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(y);
+    }
+}
+
+// block = (CVB channel vectors) x (PY pixel lanes); grid.x over channel-vector groups, grid.y over pixels
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(DykEwDesc d, int CVB) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    __shared__ float red[256 * 2 * 8];
+    const int PY = 256 / CVB;
+    const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
+    const int CV = d.C / EPV;
+    const int cv = blockIdx.x * CVB + tx;
+    const int c = cv * EPV;
+    const bool active = cv < CV;
+    float s1[EPV], s2[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) s1[j] = s2[j] = 0.f;
+    if (active) {
+        float sc[EPV], sh[EPV], mu[EPV], rs[EPV];
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            sc[j] = d.p0[c + j]; sh[j] = d.p1[c + j]; mu[j] = d.p2[c + j]; rs[j] = d.p3[c + j];
+        }
+        const T* __restrict__ dz = (const T*)d.a;
+        const T* __restrict__ y = (const T*)d.b;
+        for (long p = (long)blockIdx.y * PY + ty; p < d.npix; p += (long)gridDim.y * PY) {
+            float g[EPV], yy[EPV];
+            vec_unpack<T>(*(const uint4*)(dz + p * d.lda + c), g);
+            vec_unpack<T>(*(const uint4*)(y + p * d.ldb + c), yy);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                const float da = g[j] * act_bwd(d.act, yy[j] * sc[j] + sh[j]);
+                s1[j] += da;
+                s2[j] += da * ((yy[j] - mu[j]) * rs[j]);
+            }
+        }
+    }
+    // reduce over ty through LDS
+    float* mine = red + threadIdx.x * 2 * 8;
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) { mine[j] = s1[j]; mine[8 + j] = s2[j]; }
+    __syncthreads();
+    if (ty == 0 && active) {
+        for (int q = 1; q < PY; ++q) {
+            const float* o = red + (q * CVB + tx) * 2 * 8;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) { s1[j] += o[j]; s2[j] += o[8 + j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            atomicAdd(d.red + c + j, (double)s1[j]);
+            atomicAdd(d.red + d.C + c + j, (double)s2[j]);
+        }
+    }
+}
+
+__global__ void bn_bwd_params_kernel(const double* red, float* dgamma, float* dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dbeta) dbeta[c] += (float)red[c];
+    if (dgamma) dgamma[c] += (float)red[C + c];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwDesc d) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    const int CV = d.C / EPV;
+    const long total = (long)d.npix * CV;
+    const T* __restrict__ dz = (const T*)d.a;
+    const T* __restrict__ y = (const T*)d.b;
+    T* __restrict__ o = (T*)d.out;
+    const float invn = 1.f / (float)d.npix;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+        const long p = v / CV;
+        const int c = (int)(v - p * CV) * EPV;
+        float g[EPV], yy[EPV], r[EPV];
+        vec_unpack<T>(*(const uint4*)(dz + p * d.lda + c), g);
+        vec_unpack<T>(*(const uint4*)(y + p * d.ldb + c), yy);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            const float sc = d.p0[c + j], sh = d.p1[c + j], mu = d.p2[c + j], rs = d.p3[c + j];
+            const float da = g[j] * act_bwd(d.act, yy[j] * sc + sh);
+            const float xh = (yy[j] - mu) * rs;
+            const float m1 = (float)d.red[c + j] * invn, m2 = (float)d.red[d.C + c + j] * invn;
+            r[j] = sc * (da - m1 - xh * m2);      // sc = gamma * rstd
+        }
+        if (d.flags & DYK_EW_ACCUM) {
+            float old[EPV];
+            vec_unpack<T>(*(const uint4*)(o + p * d.ldo + c), old);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) r[j] += old[j];
+        }
+        *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(r);
+    }
+}
+
+inline int ew_grid(long total_vec) {
+    long g = (total_vec + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+inline int ew_check(const DykEwDesc* d, bool need_b) {
+    if (!d || !d->a || !d->out || d->npix <= 0 || d->C <= 0) return DYK_ERR_ARG;
+    if (need_b && !d->b) return DYK_ERR_ARG;
+    const int epv = d->dtype == DYK_BF16 ? 8 : 4;
+    if (d->dtype != DYK_BF16 && d->dtype != DYK_F32) return DYK_ERR_ARG;
+    if (d->C % epv || d->lda % epv || d->ldo % epv || (d->b && d->ldb % epv)) return DYK_ERR_ARG;
+    return DYK_OK;
+}
+
+}  // namespace
+
+extern "C" int dyk_bn_finalize(const DykBnFinalizeDesc* d, void* stream) {
+    if (!d || !d->stats || !d->scale || !d->shift || d->C <= 0 || d->count <= 0) return DYK_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 127) / 128), dim3(128), 0, (hipStream_t)stream, *d);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_bn_fold(const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float eps, float* scale, float* shift, int32_t C,
+                           void* stream) {
+    if (!running_mean || !running_var || !scale || !shift || C <= 0) return DYK_ERR_ARG;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, scale, shift, C);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_bn_act_fwd(const DykEwDesc* d, void* stream) {
+    const int rc = ew_check(d, false);
+    if (rc) return rc;
+    const int epv = d->dtype == DYK_BF16 ? 8 : 4;
+    const int grid = ew_grid((long)d->npix * (d->C / epv));
+    if (d->dtype == DYK_BF16)
+        hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    else
+        hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_bn_act_bwd_reduce(const DykEwDesc* d, void* stream) {
+    if (!d || !d->a || !d->b || !d->red || !d->p0 || !d->p1 || !d->p2 || !d->p3) return DYK_ERR_ARG;
+    if (d->npix <= 0 || d->C <= 0 || (d->dtype != DYK_BF16 && d->dtype != DYK_F32)) return DYK_ERR_ARG;
+    const int epv = d->dtype == DYK_BF16 ? 8 : 4;
+    if (d->C % epv || d->lda % epv || d->ldb % epv) return DYK_ERR_ARG;
+    const int CV = d->C / epv;
+    int CVB = 1;
+    while (CVB < CV && CVB < 32) CVB <<= 1;
+    const int PY = 256 / CVB;
+    const int gx = (CV + CVB - 1) / CVB;
+    long gy = ((long)d->npix + PY * 8 - 1) / (PY * 8);      // >= 8 pixels per thread
+    const long cap = 2048 / gx > 0 ? 2048 / gx : 1;
+    if (gy > cap) gy = cap;
+    if (gy < 1) gy = 1;
+    if (d->dtype == DYK_BF16)
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_bn_bwd_params(const double* red, float* dgamma, float* dbeta, int32_t C, void* stream) {
+    if (!red || C <= 0) return DYK_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, red, dgamma, dbeta, C);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_bn_act_bwd_apply(const DykEwDesc* d, void* stream) {
+    const int rc = ew_check(d, true);
+    if (rc) return rc;
+    if (!d->red || !d->p0 || !d->p1 || !d->p2 || !d->p3) return DYK_ERR_ARG;
+    const int epv = d->dtype == DYK_BF16 ? 8 : 4;
+    const int grid = ew_grid((long)d->npix * (d->C / epv));
+    if (d->dtype == DYK_BF16)
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}

@@ -1,0 +1,654 @@
+// HBM-bound channels-last kernels around the convolutions: axpby (copy / add / weighted
+// feature fusion), nearest 2x upsample, max-pool with arg-max, squeeze-excitation, YOLO head
+// permute, first-layer patch gather.  Forward and backward of each.
+#include "dyk_common.h"
+
+namespace {
+
+inline int ew_grid(long total_vec) {
+    long g = (total_vec + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+inline int epv_of(int dtype) { return dtype == DYK_BF16 ? 8 : 4; }
+
+// ------------------------------------------------------------------ axpby
+// out = sa*a (+ sb*b), sa = alpha * (p0 ? p0[0] : 1), sb = beta * (p1 ? p1[0] : 1)
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_kernel(DykEwDesc d) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    const int CV = d.C / EPV;
+    const long total = (long)d.npix * CV;
+    const float sa = d.alpha * (d.p0 ? d.p0[0] : 1.f);
+    const float sb = d.beta * (d.p1 ? d.p1[0] : 1.f);
+    const T* __restrict__ a = (const T*)d.a;
+    const T* __restrict__ b = (const T*)d.b;
+    T* __restrict__ o = (T*)d.out;
+    const bool accum = d.flags & DYK_EW_ACCUM;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+        const long p = v / CV;
+        const int c = (int)(v - p * CV) * EPV;
+        float x[EPV];
+        vec_unpack<T>(*(const uint4*)(a + p * d.lda + c), x);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) x[j] *= sa;
+        if (b) {
+            float y[EPV];
+            vec_unpack<T>(*(const uint4*)(b + p * d.ldb + c), y);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) x[j] += sb * y[j];
+        }
+        if (accum) {
+            float y[EPV];
+            vec_unpack<T>(*(const uint4*)(o + p * d.ldo + c), y);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) x[j] += y[j];
+        }
+        *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(x);
+    }
+}
+
+// red[0] += sum a*b  over all pixels/channels (weighted-fusion weight gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void dot_kernel(DykEwDesc d) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    const int CV = d.C / EPV;
+    const long total = (long)d.npix * CV;
+    const T* __restrict__ a = (const T*)d.a;
+    const T* __restrict__ b = (const T*)d.b;
+    float s = 0.f;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+        const long p = v / CV;
+        const int c = (int)(v - p * CV) * EPV;
+        float x[EPV], y[EPV];
+        vec_unpack<T>(*(const uint4*)(a + p * d.lda + c), x);
+        vec_unpack<T>(*(const uint4*)(b + p * d.ldb + c), y);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) s += x[j] * y[j];
+    }
+    __shared__ float ws[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(d.red, (double)(ws[0] + ws[1] + ws[2] + ws[3]));
+}
+
+// weighted feature fusion weights (layers.py:66): weff[i] = sigmoid(w[i]) * 2/n
+__global__ void wfuse_weights_kernel(const float* w, float* weff, int n) {
+    const int i = threadIdx.x;
+    if (i < n) weff[i] = (1.f / (1.f + __expf(-w[i]))) * (2.f / n);
+}
+// dw[i] += red[i] * 2/n * s(1-s)
+__global__ void wfuse_bwd_params_kernel(const float* w, const double* red, float* dw, int n) {
+    const int i = threadIdx.x;
+    if (i < n) {
+        const float s = 1.f / (1.f + __expf(-w[i]));
+        dw[i] += (float)red[i] * (2.f / n) * s * (1.f - s);
+    }
+}
+
+// ------------------------------------------------------------------ nearest 2x upsample
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(DykEwDesc d) {   // a: [B,H,W,C] -> out [B,2H,2W,C]
+    constexpr int EPV = ElemTraits<T>::EPV;
+    const int CV = d.C / EPV;
+    const int Ho = 2 * d.H, Wo = 2 * d.W;
+    const long total = (long)d.B * Ho * Wo * CV;
+    const T* __restrict__ a = (const T*)d.a;
+    T* __restrict__ o = (T*)d.out;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+        const long p = v / CV;
+        const int c = (int)(v - p * CV) * EPV;
+        const int xo = (int)(p % Wo);
+        const long q = p / Wo;
+        const int yo = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        const long pi = ((long)b * d.H + (yo >> 1)) * d.W + (xo >> 1);
+        *(uint4*)(o + p * d.ldo + c) = *(const uint4*)(a + pi * d.lda + c);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(DykEwDesc d) {   // a: dout [B,2H,2W,C] -> out din [B,H,W,C]
+    constexpr int EPV = ElemTraits<T>::EPV;
+    const int CV = d.C / EPV;
+    const int Wo = 2 * d.W;
+    const long total = (long)d.B * d.H * d.W * CV;
+    const T* __restrict__ a = (const T*)d.a;
+    T* __restrict__ o = (T*)d.out;
+    const bool accum = d.flags & DYK_EW_ACCUM;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+        const long p = v / CV;
+        const int c = (int)(v - p * CV) * EPV;
+        const int x = (int)(p % d.W);
+        const long q = p / d.W;
+        const int y = (int)(q % d.H);
+        const int b = (int)(q / d.H);
+        const long p00 = ((long)b * 2 * d.H + 2 * y) * Wo + 2 * x;
+        float s[EPV], t[EPV];
+        vec_unpack<T>(*(const uint4*)(a + p00 * d.lda + c), s);
+        vec_unpack<T>(*(const uint4*)(a + (p00 + 1) * d.lda + c), t);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) s[j] += t[j];
+        vec_unpack<T>(*(const uint4*)(a + (p00 + Wo) * d.lda + c), t);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) s[j] += t[j];
+        vec_unpack<T>(*(const uint4*)(a + (p00 + Wo + 1) * d.lda + c), t);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) s[j] += t[j];
+        if (accum) {
+            vec_unpack<T>(*(const uint4*)(o + p * d.ldo + c), t);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) s[j] += t[j];
+        }
+        *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(s);
+    }
+}
+
+// ------------------------------------------------------------------ max pool k x k, stride 1, pad (k-1)/2
+// idx (uint8, [npix][C]) holds the window position dy*k+dx of the first maximum in scan order
+// (torch CPU max_pool2d keeps the first element for which val > max, so ties go to the earliest).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(DykEwDesc d, uint8_t* __restrict__ idx) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    const int CV = d.C / EPV;
+    const int k = d.k, pad = (k - 1) / 2;
+    const long total = (long)d.B * d.H * d.W * CV;
+    const T* __restrict__ a = (const T*)d.a;
+    T* __restrict__ o = (T*)d.out;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+        const long p = v / CV;
+        const int c = (int)(v - p * CV) * EPV;
+        const int x = (int)(p % d.W);
+        const long q = p / d.W;
+        const int y = (int)(q % d.H);
+        const int b = (int)(q / d.H);
+        float m[EPV]; int mi[EPV];
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) { m[j] = -INFINITY; mi[j] = 0; }
+        bool first = true;
+        for (int dy = 0; dy < k; ++dy) {
+            const int yy = y + dy - pad;
+            if (yy < 0 || yy >= d.H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int xx = x + dx - pad;
+                if (xx < 0 || xx >= d.W) continue;
+                float t[EPV];
+                vec_unpack<T>(*(const uint4*)(a + (((long)b * d.H + yy) * d.W + xx) * d.lda + c), t);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j)
+                    if (first || t[j] > m[j] || t[j] != t[j]) { m[j] = t[j]; mi[j] = dy * k + dx; }
+                first = false;
+            }
+        }
+        *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(m);
+        if (idx) {
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) idx[p * d.C + c + j] = (uint8_t)mi[j];
+        }
+    }
+}
+// a = dout [B,H,W,C], out = din; gather form (no atomics, deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(DykEwDesc d, const uint8_t* __restrict__ idx) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    const int CV = d.C / EPV;
+    const int k = d.k, pad = (k - 1) / 2;
+    const long total = (long)d.B * d.H * d.W * CV;
+    const T* __restrict__ a = (const T*)d.a;
+    T* __restrict__ o = (T*)d.out;
+    const bool accum = d.flags & DYK_EW_ACCUM;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+        const long p = v / CV;
+        const int c = (int)(v - p * CV) * EPV;
+        const int x = (int)(p % d.W);
+        const long q = p / d.W;
+        const int y = (int)(q % d.H);
+        const int b = (int)(q / d.H);
+        float s[EPV];
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) s[j] = 0.f;
+        for (int dy = 0; dy < k; ++dy) {
+            const int yo = y - dy + pad;          // output row whose window position dy is this row
+            if (yo < 0 || yo >= d.H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int xo = x - dx + pad;
+                if (xo < 0 || xo >= d.W) continue;
+                const long po = ((long)b * d.H + yo) * d.W + xo;
+                const int code = dy * k + dx;
+                float g[EPV];
+                vec_unpack<T>(*(const uint4*)(a + po * d.lda + c), g);
+                const uint8_t* ip = idx + po * d.C + c;
+#pragma unroll
+                for (int j = 0; j < EPV; ++j)
+                    if (ip[j] == code) s[j] += g[j];
+            }
+        }
+        if (accum) {
+            float t[EPV];
+            vec_unpack<T>(*(const uint4*)(o + p * d.ldo + c), t);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) s[j] += t[j];
+        }
+        *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(s);
+    }
+}
+
+// ------------------------------------------------------------------ squeeze-excitation
+// pooled[b][c] = alpha * sum_hw a[b,p,c] * (b ? b[b,p,c] : 1)        grid (CV groups, B)
+template <typename T>
+__global__ __launch_bounds__(256) void se_pool_kernel(DykEwDesc d, float* __restrict__ pooled, int CVB) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    __shared__ float red[256 * 8];
+    const int PY = 256 / CVB;
+    const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
+    const int CV = d.C / EPV;
+    const int cv = blockIdx.x * CVB + tx;
+    const int c = cv * EPV;
+    const int b = blockIdx.y;
+    const int HW = d.H * d.W;
+    const bool active = cv < CV;
+    float s[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) s[j] = 0.f;
+    if (active) {
+        const T* __restrict__ a = (const T*)d.a;
+        const T* __restrict__ bb = (const T*)d.b;
+        for (int p = ty; p < HW; p += PY) {
+            const long pp = (long)b * HW + p;
+            float x[EPV];
+            vec_unpack<T>(*(const uint4*)(a + pp * d.lda + c), x);
+            if (bb) {
+                float y[EPV];
+                vec_unpack<T>(*(const uint4*)(bb + pp * d.ldb + c), y);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) s[j] += x[j] * y[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) s[j] += x[j];
+            }
+        }
+    }
+    float* mine = red + threadIdx.x * 8;
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) mine[j] = s[j];
+    __syncthreads();
+    if (ty == 0 && active) {
+        for (int q = 1; q < PY; ++q) {
+            const float* o = red + (q * CVB + tx) * 8;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) s[j] += o[j];
+        }
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) pooled[(long)b * d.C + c + j] = s[j] * d.alpha;
+    }
+}
+
+// one block per image: h = relu(W1 pooled + b1); s = hardsigmoid(W2 h + b2)   (layers.py:185-189)
+__global__ __launch_bounds__(256) void se_fc_fwd_kernel(DykSeFcDesc d) {
+    extern __shared__ float sm[];           // pooled[C] | h[Cs]
+    float* pooled = sm;
+    float* h = sm + d.C;
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < d.C; i += blockDim.x) pooled[i] = d.pooled[(long)b * d.C + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int j = w; j < d.Cs; j += nw) {           // one wave per output
+        float acc = 0.f;
+        for (int i = lane; i < d.C; i += 64) acc += d.w1[(long)j * d.C + i] * pooled[i];
+        acc = wave_sum(acc);
+        if (lane == 0) h[j] = fmaxf(acc + d.b1[j], 0.f);
+    }
+    __syncthreads();
+    for (int c = w; c < d.C; c += nw) {
+        float acc = 0.f;
+        for (int j = lane; j < d.Cs; j += 64) acc += d.w2[(long)c * d.Cs + j] * h[j];
+        acc = wave_sum(acc);
+        if (lane == 0) d.scale[(long)b * d.C + c] = fminf(fmaxf(acc + d.b2[c] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    }
+}
+
+// backward of the two FCs for one image per block; parameter gradients via fp32 atomics.
+// in: dscale[b][c] = sum_hw dz*x ; out: dpooled[b][c] (gradient w.r.t. the pooled mean)
+__global__ __launch_bounds__(256) void se_fc_bwd_kernel(DykSeFcDesc d) {
+    extern __shared__ float sm[];           // pooled[C] | h[Cs] | t1[Cs] | dt2[C] | dt1[Cs]
+    float* pooled = sm;
+    float* h = pooled + d.C;
+    float* t1 = h + d.Cs;
+    float* dt2 = t1 + d.Cs;
+    float* dt1 = dt2 + d.C;
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < d.C; i += blockDim.x) pooled[i] = d.pooled[(long)b * d.C + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int j = w; j < d.Cs; j += nw) {
+        float acc = 0.f;
+        for (int i = lane; i < d.C; i += 64) acc += d.w1[(long)j * d.C + i] * pooled[i];
+        acc = wave_sum(acc);
+        if (lane == 0) { t1[j] = acc + d.b1[j]; h[j] = fmaxf(t1[j], 0.f); }
+    }
+    __syncthreads();
+    for (int c = w; c < d.C; c += nw) {
+        float acc = 0.f;
+        for (int j = lane; j < d.Cs; j += 64) acc += d.w2[(long)c * d.Cs + j] * h[j];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float t2 = acc + d.b2[c];
+            const float g = (t2 > -3.f && t2 < 3.f) ? d.dscale[(long)b * d.C + c] * (1.f / 6.f) : 0.f;
+            dt2[c] = g;
+            if (g != 0.f) unsafeAtomicAdd(d.db2 + c, g);
+        }
+    }
+    __syncthreads();
+    // dW2[c][j] += dt2[c]*h[j] ; dh[j] = sum_c W2[c][j]*dt2[c]
+    for (int i = threadIdx.x; i < d.C * d.Cs; i += blockDim.x) {
+        const int c = i / d.Cs, j = i - c * d.Cs;
+        const float g = dt2[c] * h[j];
+        if (g != 0.f) unsafeAtomicAdd(d.dw2 + i, g);
+    }
+    for (int j = threadIdx.x; j < d.Cs; j += blockDim.x) {
+        float acc = 0.f;
+        for (int c = 0; c < d.C; ++c) acc += d.w2[(long)c * d.Cs + j] * dt2[c];
+        const float g = t1[j] > 0.f ? acc : 0.f;
+        dt1[j] = g;
+        if (g != 0.f) unsafeAtomicAdd(d.db1 + j, g);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < d.C * d.Cs; i += blockDim.x) {
+        const int j = i / d.C, c = i - j * d.C;
+        const float g = dt1[j] * pooled[c];
+        if (g != 0.f) unsafeAtomicAdd(d.dw1 + i, g);
+    }
+    for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int j = 0; j < d.Cs; ++j) acc += d.w1[(long)j * d.C + c] * dt1[j];
+        d.dpooled[(long)b * d.C + c] = acc;
+    }
+}
+
+// out[b,p,c] = a[b,p,c]*p0[b*C+c] (+ p1[b*C+c]*alpha)      (SE scale; backward apply with p1 = dpooled, alpha = 1/HW)
+template <typename T>
+__global__ __launch_bounds__(256) void se_scale_kernel(DykEwDesc d) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    const int CV = d.C / EPV;
+    const int HW = d.H * d.W;
+    const long total = (long)d.B * HW * CV;
+    const T* __restrict__ a = (const T*)d.a;
+    T* __restrict__ o = (T*)d.out;
+    const bool accum = d.flags & DYK_EW_ACCUM;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+        const long p = v / CV;
+        const int c = (int)(v - p * CV) * EPV;
+        const int b = (int)(p / HW);
+        float x[EPV];
+        vec_unpack<T>(*(const uint4*)(a + p * d.lda + c), x);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            x[j] *= d.p0[(long)b * d.C + c + j];
+            if (d.p1) x[j] += d.p1[(long)b * d.C + c + j] * d.alpha;
+        }
+        if (accum) {
+            float y[EPV];
+            vec_unpack<T>(*(const uint4*)(o + p * d.ldo + c), y);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) x[j] += y[j];
+        }
+        *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(x);
+    }
+}
+
+// ------------------------------------------------------------------ YOLO head permute
+// fwd: y [B,ny,nx,ld] fp32 (channel = a*no + o)  ->  p [B,na,ny,nx,no] fp32   (models.py:229)
+__global__ void head_permute_fwd_kernel(const float* __restrict__ y, float* __restrict__ p, int B, int ny, int nx,
+                                        int na, int no, int ld) {
+    const long total = (long)B * na * ny * nx * no;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i % no);
+        long q = i / no;
+        const int x = (int)(q % nx); q /= nx;
+        const int yy = (int)(q % ny); q /= ny;
+        const int a = (int)(q % na);
+        const int b = (int)(q / na);
+        p[i] = y[(((long)b * ny + yy) * nx + x) * ld + a * no + o];
+    }
+}
+// bwd: dp [B,na,ny,nx,no] fp32 -> dy [B,ny,nx,ld] T (channels >= na*no zero)
+template <typename T>
+__global__ void head_permute_bwd_kernel(const float* __restrict__ dp, T* __restrict__ dy, int B, int ny, int nx,
+                                        int na, int no, int ld) {
+    const long total = (long)B * ny * nx * ld;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ld);
+        long q = i / ld;
+        const int x = (int)(q % nx); q /= nx;
+        const int yy = (int)(q % ny);
+        const int b = (int)(q / ny);
+        float v = 0.f;
+        if (c < na * no) {
+            const int a = c / no, o = c - a * no;
+            v = dp[((((long)b * na + a) * ny + yy) * nx + x) * no + o];
+        }
+        dy[i] = ElemTraits<T>::from_f32(v);
+    }
+}
+// bias gradient of the head conv: db[c] += sum_{b,y,x} dp[b, c/no, y, x, c%no]
+__global__ __launch_bounds__(256) void head_bias_grad_kernel(const float* __restrict__ dp, float* __restrict__ db, int B,
+                                                             int ny, int nx, int na, int no) {
+    const int c = blockIdx.x;
+    const int a = c / no, o = c - a * no;
+    const long cells = (long)ny * nx;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < (long)B * cells; i += blockDim.x) {
+        const int b = (int)(i / cells);
+        const long r = i - b * cells;
+        s += dp[(((long)b * na + a) * cells + r) * no + o];
+    }
+    __shared__ float ws[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) db[c] += ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// ------------------------------------------------------------------ first-layer patch gather
+// in NCHW fp32 [B,Cin,H,W] -> out [B,Ho,Wo,ld] T with out[.., (kh*k+kw)*Cin + c] = in[b,c,yo*s+kh-pad,xo*s+kw-pad]*mul
+template <typename T>
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ in, T* __restrict__ out, int B,
+                                                           int Cin, int H, int W, int k, int stride, int pad, int Ho,
+                                                           int Wo, int ld, float mul) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    const int CV = ld / EPV;
+    const long npix = (long)B * Ho * Wo;
+    const long total = npix * CV;
+    const int K = k * k * Cin;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+        const long p = v % npix;               // pixel fastest: coalesced NCHW reads
+        const int j0 = (int)(v / npix) * EPV;
+        const int xo = (int)(p % Wo);
+        const long q = p / Wo;
+        const int yo = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        float val[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const int j = j0 + e;
+            float t = 0.f;
+            if (j < K) {
+                const int c = j % Cin, tap = j / Cin;
+                const int kh = tap / k, kw = tap - kh * k;
+                const int yy = yo * stride + kh - pad, xx = xo * stride + kw - pad;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) t = in[(((long)b * Cin + c) * H + yy) * W + xx] * mul;
+            }
+            val[e] = t;
+        }
+        *(uint4*)(out + p * ld + j0) = vec_pack<T>(val);
+    }
+}
+
+int check_ew(const DykEwDesc* d, bool need_b, bool need_out = true) {
+    if (!d || !d->a || (need_out && !d->out) || (need_b && !d->b)) return DYK_ERR_ARG;
+    if (d->dtype != DYK_BF16 && d->dtype != DYK_F32) return DYK_ERR_ARG;
+    const int epv = epv_of(d->dtype);
+    if (d->C <= 0 || d->C % epv || d->lda % epv || (need_out && d->ldo % epv) || (d->b && d->ldb % epv)) return DYK_ERR_ARG;
+    return DYK_OK;
+}
+
+}  // namespace
+
+#define DISPATCH_T(kern, grid, block, lds, stream, ...)                                              \
+    do {                                                                                             \
+        if (d->dtype == DYK_BF16) hipLaunchKernelGGL(kern<bf16_t>, grid, block, lds, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern<float>, grid, block, lds, stream, __VA_ARGS__);                 \
+        DYK_LAUNCH_CHECK();                                                                          \
+    } while (0)
+
+extern "C" int dyk_axpby(const DykEwDesc* d, void* stream) {
+    const int rc = check_ew(d, false);
+    if (rc) return rc;
+    if (d->npix <= 0) return DYK_ERR_ARG;
+    const int grid = ew_grid((long)d->npix * (d->C / epv_of(d->dtype)));
+    DISPATCH_T(axpby_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    return DYK_OK;
+}
+
+extern "C" int dyk_dot(const DykEwDesc* d, void* stream) {
+    const int rc = check_ew(d, true, false);
+    if (rc) return rc;
+    if (d->npix <= 0 || !d->red) return DYK_ERR_ARG;
+    long g = ((long)d->npix * (d->C / epv_of(d->dtype)) + 256 * 8 - 1) / (256 * 8);
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    DISPATCH_T(dot_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, *d);
+    return DYK_OK;
+}
+
+extern "C" int dyk_wfuse_weights(const float* w, float* weff, int32_t n, void* stream) {
+    if (!w || !weff || n <= 0 || n > 64) return DYK_ERR_ARG;
+    hipLaunchKernelGGL(wfuse_weights_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, weff, n);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_wfuse_bwd_params(const float* w, const double* red, float* dw, int32_t n, void* stream) {
+    if (!w || !red || !dw || n <= 0 || n > 64) return DYK_ERR_ARG;
+    hipLaunchKernelGGL(wfuse_bwd_params_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, red, dw, n);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_upsample2x_fwd(const DykEwDesc* d, void* stream) {
+    const int rc = check_ew(d, false);
+    if (rc) return rc;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0) return DYK_ERR_ARG;
+    const int grid = ew_grid((long)d->B * d->H * d->W * 4 * (d->C / epv_of(d->dtype)));
+    DISPATCH_T(upsample2x_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    return DYK_OK;
+}
+
+extern "C" int dyk_upsample2x_bwd(const DykEwDesc* d, void* stream) {
+    const int rc = check_ew(d, false);
+    if (rc) return rc;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0) return DYK_ERR_ARG;
+    const int grid = ew_grid((long)d->B * d->H * d->W * (d->C / epv_of(d->dtype)));
+    DISPATCH_T(upsample2x_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    return DYK_OK;
+}
+
+extern "C" int dyk_maxpool_fwd(const DykEwDesc* d, uint8_t* argmax, void* stream) {
+    const int rc = check_ew(d, false);
+    if (rc) return rc;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0 || d->k > 15 || !(d->k & 1)) return DYK_ERR_ARG;
+    const int grid = ew_grid((long)d->B * d->H * d->W * (d->C / epv_of(d->dtype)));
+    DISPATCH_T(maxpool_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, argmax);
+    return DYK_OK;
+}
+
+extern "C" int dyk_maxpool_bwd(const DykEwDesc* d, const uint8_t* argmax, void* stream) {
+    const int rc = check_ew(d, false);
+    if (rc) return rc;
+    if (!argmax || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0 || d->k > 15 || !(d->k & 1)) return DYK_ERR_ARG;
+    const int grid = ew_grid((long)d->B * d->H * d->W * (d->C / epv_of(d->dtype)));
+    DISPATCH_T(maxpool_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, argmax);
+    return DYK_OK;
+}
+
+extern "C" int dyk_se_pool(const DykEwDesc* d, float* pooled, void* stream) {
+    const int rc = check_ew(d, false, false);
+    if (rc) return rc;
+    if (!pooled || d->B <= 0 || d->H <= 0 || d->W <= 0) return DYK_ERR_ARG;
+    const int CV = d->C / epv_of(d->dtype);
+    int CVB = 1;
+    while (CVB < CV && CVB < 16) CVB <<= 1;
+    DISPATCH_T(se_pool_kernel, dim3((CV + CVB - 1) / CVB, d->B), dim3(256), 0, (hipStream_t)stream, *d, pooled, CVB);
+    return DYK_OK;
+}
+
+extern "C" int dyk_se_fc_fwd(const DykSeFcDesc* d, void* stream) {
+    if (!d || !d->pooled || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->scale || d->B <= 0 || d->C <= 0 || d->Cs <= 0)
+        return DYK_ERR_ARG;
+    const size_t lds = (size_t)(d->C + d->Cs) * sizeof(float);
+    hipLaunchKernelGGL(se_fc_fwd_kernel, dim3(d->B), dim3(256), lds, (hipStream_t)stream, *d);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_se_fc_bwd(const DykSeFcDesc* d, void* stream) {
+    if (!d || !d->pooled || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->dscale || !d->dpooled || !d->dw1 || !d->db1 ||
+        !d->dw2 || !d->db2 || d->B <= 0 || d->C <= 0 || d->Cs <= 0)
+        return DYK_ERR_ARG;
+    const size_t lds = (size_t)(2 * d->C + 3 * d->Cs) * sizeof(float);
+    hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(d->B), dim3(256), lds, (hipStream_t)stream, *d);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_se_scale(const DykEwDesc* d, void* stream) {
+    const int rc = check_ew(d, false);
+    if (rc) return rc;
+    if (!d->p0 || d->B <= 0 || d->H <= 0 || d->W <= 0) return DYK_ERR_ARG;
+    const int grid = ew_grid((long)d->B * d->H * d->W * (d->C / epv_of(d->dtype)));
+    DISPATCH_T(se_scale_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    return DYK_OK;
+}
+
+extern "C" int dyk_head_permute_fwd(const float* y, float* p, int32_t B, int32_t ny, int32_t nx, int32_t na,
+                                    int32_t no, int32_t ld, void* stream) {
+    if (!y || !p || B <= 0 || ny <= 0 || nx <= 0 || na <= 0 || no <= 0 || ld < na * no) return DYK_ERR_ARG;
+    const int grid = ew_grid((long)B * na * ny * nx * no);
+    hipLaunchKernelGGL(head_permute_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, p, B, ny, nx, na, no, ld);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_head_permute_bwd(const float* dp, void* dy, float* dbias, int32_t B, int32_t ny, int32_t nx,
+                                    int32_t na, int32_t no, int32_t ld, int32_t dtype, void* stream) {
+    if (!dp || !dy || B <= 0 || ny <= 0 || nx <= 0 || na <= 0 || no <= 0 || ld < na * no) return DYK_ERR_ARG;
+    const int grid = ew_grid((long)B * ny * nx * ld);
+    if (dtype == DYK_BF16)
+        hipLaunchKernelGGL(head_permute_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dp, (bf16_t*)dy, B, ny, nx, na, no, ld);
+    else if (dtype == DYK_F32)
+        hipLaunchKernelGGL(head_permute_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dp, (float*)dy, B, ny, nx, na, no, ld);
+    else
+        return DYK_ERR_ARG;
+    DYK_LAUNCH_CHECK();
+    if (dbias) {
+        hipLaunchKernelGGL(head_bias_grad_kernel, dim3(na * no), dim3(256), 0, (hipStream_t)stream, dp, dbias, B, ny, nx, na, no);
+        DYK_LAUNCH_CHECK();
+    }
+    return DYK_OK;
+}
+
+extern "C" int dyk_patch_gather(const float* in, void* out, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t k,
+                                int32_t stride, int32_t pad, int32_t ld, float mul, int32_t dtype, void* stream) {
+    if (!in || !out || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0) return DYK_ERR_ARG;
+    const int epv = epv_of(dtype);
+    if (ld % epv || ld < k * k * Cin) return DYK_ERR_ARG;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const int grid = ew_grid((long)B * Ho * Wo * (ld / epv));
+    if (dtype == DYK_BF16)
+        hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, B, Cin, H, W, k, stride, pad, Ho, Wo, ld, mul);
+    else if (dtype == DYK_F32)
+        hipLaunchKernelGGL(patch_gather_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (float*)out, B, Cin, H, W, k, stride, pad, Ho, Wo, ld, mul);
+    else
+        return DYK_ERR_ARG;
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}

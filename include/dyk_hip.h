@@ -129,6 +129,133 @@ typedef struct DykWgradDesc {
 
 int dyk_conv_wgrad(const DykWgradDesc* desc, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Channels-last elementwise / per-channel kernels share one descriptor; each entry point
+ * documents the fields it reads.  Tensors a, b, out have `dtype`; npix = B*H*W pixels of C
+ * channels with pixel strides lda/ldb/ldo.  p0..p3 are per-channel fp32 vectors, red a
+ * fp64 reduction buffer.
+ * ---------------------------------------------------------------------------------- */
+enum {
+    DYK_EW_ACCUM = 1      /* out += result instead of out = result */
+};
+
+typedef struct DykEwDesc {
+    const void* a;
+    const void* b;
+    void* out;
+    const float* p0;
+    const float* p1;
+    const float* p2;
+    const float* p3;
+    double* red;
+    int32_t dtype;
+    int32_t npix, C;
+    int32_t lda, ldb, ldo;
+    int32_t act, flags;
+    int32_t B, H, W, k;             /* spatial ops (pool / upsample) */
+    float alpha, beta;
+} DykEwDesc;
+
+/* BatchNorm2d, training mode (nn.BatchNorm2d at models.py:47, torch defaults eps=1e-5,
+ * momentum=0.1): from the per-channel sum / sum-of-squares the conv epilogue accumulated in
+ * stats[2C] over `count` pixels, produce scale = gamma*rstd, shift = beta - mean*scale, the
+ * saved mean / rstd for backward, update running_mean / running_var (unbiased variance) and
+ * reset stats to zero. */
+typedef struct DykBnFinalizeDesc {
+    double* stats;              /* [2C] in/out (zeroed on return) */
+    const float* gamma;         /* [C] or NULL */
+    const float* beta;          /* [C] or NULL */
+    float* running_mean;        /* [C] or NULL (no update) */
+    float* running_var;
+    float* scale;               /* [C] out */
+    float* shift;               /* [C] out */
+    float* save_mean;           /* [C] out or NULL */
+    float* save_rstd;           /* [C] out or NULL */
+    int32_t C;
+    int32_t count;
+    float momentum, eps;
+} DykBnFinalizeDesc;
+
+int dyk_bn_finalize(const DykBnFinalizeDesc* desc, void* stream);
+
+/* eval-mode BatchNorm folded to scale/shift from the running statistics */
+int dyk_bn_fold(const float* gamma, const float* beta, const float* running_mean,
+                const float* running_var, float eps, float* scale, float* shift, int32_t C,
+                void* stream);
+
+/* out = act(a*p0[c] + p1[c]) (+ b)           -- BN apply + activation (+ residual add of a
+ * following [shortcut], layers.py:79).  p0/p1 NULL -> 1/0, b NULL -> no residual. */
+int dyk_bn_act_fwd(const DykEwDesc* desc, void* stream);
+
+/* backward of the above w.r.t. the raw conv output y (b):  a = dz, p0 = scale, p1 = shift,
+ * p2 = mean, p3 = rstd.  reduce: red[c] += sum dact, red[C+c] += sum dact*xhat with
+ * dact = dz*act'(y*scale+shift);  params: dbeta += red[c], dgamma += red[C+c];
+ * apply: out = scale*(dact - red[c]/npix - xhat*red[C+c]/npix). */
+int dyk_bn_act_bwd_reduce(const DykEwDesc* desc, void* stream);
+int dyk_bn_bwd_params(const double* red, float* dgamma, float* dbeta, int32_t C, void* stream);
+int dyk_bn_act_bwd_apply(const DykEwDesc* desc, void* stream);
+
+/* out = alpha*s0*a (+ beta*s1*b), s0 = p0 ? p0[0] : 1, s1 = p1 ? p1[0] : 1 (device scalars).
+ * Covers channel-slice copy for [route] concat (layers.py:44), the plain [shortcut] add
+ * (layers.py:79), the weighted fusion x*w0 + a*w1 (layers.py:66-73) and every gradient
+ * accumulation (flags & DYK_EW_ACCUM). */
+int dyk_axpby(const DykEwDesc* desc, void* stream);
+/* red[0] += sum over pixels/channels of a*b   (gradient of a fusion weight) */
+int dyk_dot(const DykEwDesc* desc, void* stream);
+/* WeightedFeatureFusion weights (layers.py:66): weff[i] = sigmoid(w[i]) * 2/n, and its backward
+ * dw[i] += red[i] * 2/n * sigmoid'(w[i]) */
+int dyk_wfuse_weights(const float* w, float* weff, int32_t n, void* stream);
+int dyk_wfuse_bwd_params(const float* w, const double* red, float* dw, int32_t n, void* stream);
+
+/* nn.Upsample(scale_factor=2) nearest (models.py:100-101): a [B,H,W,C] -> out [B,2H,2W,C];
+ * backward: a = dout [B,2H,2W,C] -> out = din [B,H,W,C] (sum of the 2x2 block). */
+int dyk_upsample2x_fwd(const DykEwDesc* desc, void* stream);
+int dyk_upsample2x_bwd(const DykEwDesc* desc, void* stream);
+
+/* nn.MaxPool2d(k, stride=1, padding=(k-1)//2) (models.py:91-94), k odd <= 15.  argmax is a
+ * uint8 [B*H*W][C] map of the window position (dy*k+dx) of the first maximum in scan order
+ * (torch CPU tie rule); backward gathers dout through it (deterministic, no atomics). */
+int dyk_maxpool_fwd(const DykEwDesc* desc, uint8_t* argmax, void* stream);
+int dyk_maxpool_bwd(const DykEwDesc* desc, const uint8_t* argmax, void* stream);
+
+/* SqueezeExcitation (layers.py:175-190).
+ *   dyk_se_pool : pooled[b][c] = alpha * sum_hw a[b,hw,c] * (b ? b[b,hw,c] : 1)
+ *                 (alpha = 1/HW gives adaptive_avg_pool2d; with b = dz it is the gradient of the
+ *                 per-channel scale)
+ *   dyk_se_fc_fwd : scale = hardsigmoid(W2 relu(W1 pooled + b1) + b2), one block per image
+ *   dyk_se_scale  : out[b,hw,c] = a[b,hw,c]*p0[b*C+c] (+ alpha*p1[b*C+c])
+ *   dyk_se_fc_bwd : from dscale = d(loss)/d(scale) produce dpooled and accumulate dW1,db1,dW2,db2 */
+typedef struct DykSeFcDesc {
+    const float* pooled;   /* [B][C] */
+    const float* w1;       /* [Cs][C]  fc1.weight */
+    const float* b1;       /* [Cs] */
+    const float* w2;       /* [C][Cs]  fc2.weight */
+    const float* b2;       /* [C] */
+    float* scale;          /* [B][C] out (fwd) */
+    const float* dscale;   /* [B][C] (bwd) */
+    float* dpooled;        /* [B][C] out (bwd) */
+    float* dw1; float* db1; float* dw2; float* db2;   /* accumulated (bwd) */
+    int32_t B, C, Cs;
+} DykSeFcDesc;
+int dyk_se_pool(const DykEwDesc* desc, float* pooled, void* stream);
+int dyk_se_fc_fwd(const DykSeFcDesc* desc, void* stream);
+int dyk_se_fc_bwd(const DykSeFcDesc* desc, void* stream);
+int dyk_se_scale(const DykEwDesc* desc, void* stream);
+
+/* YOLOLayer training-mode reshape (models.py:229): head conv output y [B,ny,nx,ld] fp32 with
+ * channel = a*no + o  ->  p [B,na,ny,nx,no] fp32.  Backward scatters dp back into a zero-padded
+ * dy [B,ny,nx,ld] of `dtype` and, if dbias != NULL, accumulates the head bias gradient. */
+int dyk_head_permute_fwd(const float* y, float* p, int32_t B, int32_t ny, int32_t nx, int32_t na,
+                         int32_t no, int32_t ld, void* stream);
+int dyk_head_permute_bwd(const float* dp, void* dy, float* dbias, int32_t B, int32_t ny, int32_t nx,
+                         int32_t na, int32_t no, int32_t ld, int32_t dtype, void* stream);
+
+/* First-layer patch gather: torch NCHW fp32 image batch -> channels-last patches
+ * out[b,yo,xo,(kh*k+kw)*Cin + c] = in[b,c,yo*stride+kh-pad,xo*stride+kw-pad]*mul (zero padded up
+ * to ld channels), which turns the Cin=3 stem conv (models.py:35-36) into a 1x1 MFMA conv. */
+int dyk_patch_gather(const float* in, void* out, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t k,
+                     int32_t stride, int32_t pad, int32_t ld, float mul, int32_t dtype, void* stream);
+
 /* Weight pack: torch OIHW float32 [Cout][Cin][kh][kw] (nn.Conv2d.weight, models.py:34)
  *   transposed == 0:  out[t][co][ci] = w[co][ci][t]     (forward)
  *   transposed == 1:  out[t][ci][co] = w[co][ci][t]     (data gradient: roles of Cin/Cout swap)
