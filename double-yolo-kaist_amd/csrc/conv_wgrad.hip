@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
     }
 
     // ---- epilogue: acc[r] = D[co = (lane>>4)*4 + r][ci = lane&15]
-    float* dw = a.dw + (long)a.twt[tap] * a.Cout * a.Cin;
+    const int lddw = a.lddw > 0 ? a.lddw : a.Cin;
+    float* dw = a.dw + (long)a.twt[tap] * a.Cout * lddw;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int ci = n0 + wn * WTN + ni * 16 + (lane & 15);
-                if (ci < a.Cin) unsafeAtomicAdd(dw + (long)co * a.Cin + ci, acc[mi][ni][r]);
+                if (ci < a.Cin) unsafeAtomicAdd(dw + (long)co * lddw + ci, acc[mi][ni][r]);
             }
         }
     }

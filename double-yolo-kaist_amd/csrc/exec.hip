@@ -1,0 +1,213 @@
+// Native command-list executor, parameter staging kernels and the YOLO box decode.
+#include "dyk_common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+    // 4 elements per thread, 16-byte loads
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = ((const float4*)src)[i];
+        if (sizeof(T) == 2) {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+            ((uint2*)dst)[i] = pk;
+        } else {
+            ((float4*)dst)[i] = v;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        dst[i] = ElemTraits<T>::from_f32(src[i]);
+    }
+}
+
+template <typename T>
+__global__ void cast_pad_rows_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int C, int Cpad) {
+    const long total = (long)R * Cpad;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const long r = i / Cpad;
+        dst[i] = ElemTraits<T>::from_f32(c < C ? src[r * C + c] : 0.f);
+    }
+}
+
+// one block = one 32x32 tile of one (entry, tap); dst[t][col][row] = src[t][row][col]
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_taps_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                             const DykTransposeEntry* __restrict__ tab, int n_entries) {
+    __shared__ float tile[32][33];
+    const int tidx = blockIdx.x;
+    int lo = 0, hi = n_entries - 1;           // last entry with tile_begin <= tidx
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].tile_begin <= tidx) lo = mid; else hi = mid - 1;
+    }
+    const DykTransposeEntry e = tab[lo];
+    int local = tidx - e.tile_begin;
+    const int tr = (e.rows + 31) / 32, tc = (e.cols + 31) / 32;
+    const int t = local / (tr * tc);
+    local -= t * tr * tc;
+    const int r0 = (local / tc) * 32, c0 = (local % tc) * 32;
+    const float* s = src + e.src_off + (long)t * e.rows * e.cols;
+    T* d = dst + e.dst_off + (long)t * e.rows * e.cols;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < e.rows && c < e.cols) ? s[(long)r * e.cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < e.cols && r < e.rows) d[(long)c * e.rows + r] = ElemTraits<T>::from_f32(tile[tx][j]);
+    }
+}
+
+__global__ void yolo_decode_kernel(DykDecodeDesc d) {
+    const long cells = (long)d.na * d.ny * d.nx;
+    const long total = (long)d.B * cells;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / cells);
+        const long r = i - (long)b * cells;
+        const int x = (int)(r % d.nx);
+        const int y = (int)((r / d.nx) % d.ny);
+        const int a = (int)(r / ((long)d.nx * d.ny));
+        const float* t = d.p + i * d.no;
+        float* o = d.io + ((long)b * d.rows_total + d.row_offset + r) * d.no;
+        const float aw = d.anchor_vec[2 * a], ah = d.anchor_vec[2 * a + 1];
+        // exact-rounded expf / division: decode values feed the NMS comparisons
+        if (d.v4) {
+            const float sx = 1.f / (1.f + expf(-t[0])), sy = 1.f / (1.f + expf(-t[1]));
+            const float sw = 1.f / (1.f + expf(-t[2])), sh = 1.f / (1.f + expf(-t[3]));
+            o[0] = (sx * 2.f - 0.5f + (float)x) * d.stride;
+            o[1] = (sy * 2.f - 0.5f + (float)y) * d.stride;
+            const float w2 = sw * 2.f, h2 = sh * 2.f;
+            o[2] = (w2 * w2) * aw * d.stride;
+            o[3] = (h2 * h2) * ah * d.stride;
+        } else {
+            o[0] = (1.f / (1.f + expf(-t[0])) + (float)x) * d.stride;
+            o[1] = (1.f / (1.f + expf(-t[1])) + (float)y) * d.stride;
+            o[2] = expf(t[2]) * aw * d.stride;
+            o[3] = expf(t[3]) * ah * d.stride;
+        }
+        for (int k = 4; k < d.no; ++k) o[k] = 1.f / (1.f + expf(-t[k]));
+    }
+}
+
+inline int grid_for(long n, int per_block) {
+    long g = (n + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int dyk_cast_f32(const float* src, void* dst, int64_t n, int32_t dtype, void* stream) {
+    if (!src || !dst || n <= 0) return DYK_ERR_ARG;
+    if (((uintptr_t)src % 16) || ((uintptr_t)dst % 16)) return DYK_ERR_ARG;
+    const int grid = grid_for(n / 4 + 1, 256);
+    if (dtype == DYK_BF16)
+        hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long)n);
+    else if (dtype == DYK_F32)
+        hipLaunchKernelGGL(cast_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, (long)n);
+    else
+        return DYK_ERR_ARG;
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_cast_pad_rows(const float* src, void* dst, int32_t R, int32_t C, int32_t Cpad, int32_t dtype,
+                                 void* stream) {
+    if (!src || !dst || R <= 0 || C <= 0 || Cpad < C) return DYK_ERR_ARG;
+    const int grid = grid_for((long)R * Cpad, 256);
+    if (dtype == DYK_BF16)
+        hipLaunchKernelGGL(cast_pad_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, R, C, Cpad);
+    else if (dtype == DYK_F32)
+        hipLaunchKernelGGL(cast_pad_rows_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, R, C, Cpad);
+    else
+        return DYK_ERR_ARG;
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_transpose_taps(const float* src, void* dst, const DykTransposeEntry* tab, int32_t n_entries,
+                                  int32_t total_tiles, int32_t dtype, void* stream) {
+    if (!src || !dst || !tab || n_entries <= 0 || total_tiles <= 0) return DYK_ERR_ARG;
+    if (dtype == DYK_BF16)
+        hipLaunchKernelGGL(transpose_taps_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, tab, n_entries);
+    else if (dtype == DYK_F32)
+        hipLaunchKernelGGL(transpose_taps_kernel<float>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, tab, n_entries);
+    else
+        return DYK_ERR_ARG;
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_yolo_decode(const DykDecodeDesc* d, void* stream) {
+    if (!d || !d->p || !d->io || d->B <= 0 || d->na <= 0 || d->na > 8 || d->ny <= 0 || d->nx <= 0 || d->no < 5)
+        return DYK_ERR_ARG;
+    if (d->row_offset < 0 || d->row_offset + d->na * d->ny * d->nx > d->rows_total) return DYK_ERR_ARG;
+    const int grid = grid_for((long)d->B * d->na * d->ny * d->nx, 256);
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream, int32_t* failed_index) {
+    if (!cmds || n < 0) return DYK_ERR_ARG;
+    for (int32_t k = 0; k < n; ++k) {
+        const void* dp = cmds[k].desc;
+        int rc = DYK_ERR_ARG;
+        if (dp) {
+            const DykEwDesc* e = (const DykEwDesc*)dp;
+            const DykMiscDesc* m = (const DykMiscDesc*)dp;
+            switch (cmds[k].op) {
+            case DYK_OP_CONV: rc = dyk_conv_igemm((const DykConvDesc*)dp, stream); break;
+            case DYK_OP_WGRAD: rc = dyk_conv_wgrad((const DykWgradDesc*)dp, stream); break;
+            case DYK_OP_BN_FINALIZE: rc = dyk_bn_finalize((const DykBnFinalizeDesc*)dp, stream); break;
+            case DYK_OP_BN_ACT_FWD: rc = dyk_bn_act_fwd(e, stream); break;
+            case DYK_OP_BN_BWD_REDUCE: rc = dyk_bn_act_bwd_reduce(e, stream); break;
+            case DYK_OP_BN_BWD_APPLY: rc = dyk_bn_act_bwd_apply(e, stream); break;
+            case DYK_OP_AXPBY: rc = dyk_axpby(e, stream); break;
+            case DYK_OP_DOT: rc = dyk_dot(e, stream); break;
+            case DYK_OP_UPSAMPLE_FWD: rc = dyk_upsample2x_fwd(e, stream); break;
+            case DYK_OP_UPSAMPLE_BWD: rc = dyk_upsample2x_bwd(e, stream); break;
+            case DYK_OP_MAXPOOL_FWD: rc = dyk_maxpool_fwd(e, (uint8_t*)e->aux, stream); break;
+            case DYK_OP_MAXPOOL_BWD: rc = dyk_maxpool_bwd(e, (const uint8_t*)e->aux, stream); break;
+            case DYK_OP_SE_POOL: rc = dyk_se_pool(e, (float*)e->aux, stream); break;
+            case DYK_OP_SE_FC_FWD: rc = dyk_se_fc_fwd((const DykSeFcDesc*)dp, stream); break;
+            case DYK_OP_SE_FC_BWD: rc = dyk_se_fc_bwd((const DykSeFcDesc*)dp, stream); break;
+            case DYK_OP_SE_SCALE: rc = dyk_se_scale(e, stream); break;
+            case DYK_OP_BN_BWD_PARAMS:
+                rc = dyk_bn_bwd_params((const double*)m->p[0], (float*)m->p[1], (float*)m->p[2], m->i[0], stream); break;
+            case DYK_OP_BN_FOLD:
+                rc = dyk_bn_fold((const float*)m->p[0], (const float*)m->p[1], (const float*)m->p[2], (const float*)m->p[3],
+                                 m->f[0], (float*)m->p[4], (float*)m->p[5], m->i[0], stream); break;
+            case DYK_OP_WFUSE_WEIGHTS: rc = dyk_wfuse_weights((const float*)m->p[0], (float*)m->p[1], m->i[0], stream); break;
+            case DYK_OP_WFUSE_BWD_PARAMS:
+                rc = dyk_wfuse_bwd_params((const float*)m->p[0], (const double*)m->p[1], (float*)m->p[2], m->i[0], stream); break;
+            case DYK_OP_HEAD_PERMUTE_FWD:
+                rc = dyk_head_permute_fwd((const float*)m->p[0], (float*)m->p[1], m->i[0], m->i[1], m->i[2], m->i[3], m->i[4],
+                                          m->i[5], stream); break;
+            case DYK_OP_HEAD_PERMUTE_BWD:
+                rc = dyk_head_permute_bwd((const float*)m->p[0], m->p[1], (float*)m->p[2], m->i[0], m->i[1], m->i[2], m->i[3],
+                                          m->i[4], m->i[5], m->i[6], stream); break;
+            case DYK_OP_PATCH_GATHER:
+                rc = dyk_patch_gather((const float*)m->p[0], m->p[1], m->i[0], m->i[1], m->i[2], m->i[3], m->i[4], m->i[5],
+                                      m->i[6], m->i[7], m->f[0], m->i[8], stream); break;
+            case DYK_OP_MEMSET:
+                rc = (m->p[0] && m->n > 0 && hipMemsetAsync(m->p[0], m->i[0], (size_t)m->n, (hipStream_t)stream) == hipSuccess)
+                         ? DYK_OK : DYK_ERR_HIP;
+                break;
+            case DYK_OP_YOLO_DECODE: rc = dyk_yolo_decode((const DykDecodeDesc*)dp, stream); break;
+            default: rc = DYK_ERR_UNSUPPORTED; break;
+            }
+        }
+        if (rc != DYK_OK) {
+            if (failed_index) *failed_index = k;
+            return rc;
+        }
+    }
+    return DYK_OK;
+}

@@ -1,0 +1,124 @@
+"""Runtime of a compiled YOLO model: owns the parameter store and the plans, and connects the
+native forward / backward command lists to torch autograd so that `loss.backward()` and
+`torch.optim` in an unchanged train loop (reference train_utils/kaist_train_eval_utils.py:75-108)
+keep working.
+"""
+import os
+
+import torch
+
+from . import lib as L
+from .params import ParamStore
+from .plan import compile_plan
+
+
+def _compute_dtype(model):
+    forced = getattr(model, "dyk_dtype", None) or os.environ.get("DYK_DTYPE")
+    if forced:
+        return {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "f32": torch.float32,
+                "float32": torch.float32}[str(forced).replace("torch.", "")]
+    # the reference trains under torch.cuda.amp.autocast (kaist_train_eval_utils.py:74); any autocast
+    # region selects the reduced-precision path, which on MI355X is bf16 MFMA with fp32 accumulation
+    return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+
+
+class _NetFunction(torch.autograd.Function):
+    """forward = native command list; backward = native command list writing parameter gradients
+    directly into the flat gradient buffer (ParamStore.G) that every p.grad is a view of."""
+
+    @staticmethod
+    def forward(ctx, engine, plan, anchor, x, y):
+        engine._run_forward(plan, x, y)
+        ctx.engine, ctx.plan = engine, plan
+        # fresh tensor objects every call (autograd attaches history to what a Function returns)
+        return tuple(p.detach() for p in plan.p_out)
+
+    @staticmethod
+    def backward(ctx, *dps):
+        ctx.engine._run_backward(ctx.plan, dps)
+        return None, None, None, None, None
+
+
+class Engine:
+    def __init__(self, model):
+        self.model = model
+        self.store = ParamStore(model)
+        self.plans = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _prepare(self, x):
+        if not x.is_cuda:
+            raise L.DykError("YOLO.forward runs on the MI355X HIP path only: move the model and the inputs to a "
+                             "cuda device (got %s). There is no CPU fallback." % x.device)
+        L.load()
+        dev = x.device
+        if not self.store.is_adopted(dev):
+            first = next(self.model.parameters())
+            if first.device != dev:
+                raise L.DykError("model parameters are on %s but the input is on %s" % (first.device, dev))
+            self.store.adopt(dev)
+            self.plans = {}
+
+    def get_plan(self, B, H, W, dtype, training, device):
+        key = (B, H, W, dtype, bool(training))
+        plan = self.plans.get(key)
+        if plan is None:
+            if H % 32 or W % 32:
+                raise ValueError("input height/width must be multiples of 32 (reference train.py:49), got %dx%d" % (H, W))
+            plan = compile_plan(self.model, self.store, B, H, W, dtype, training, device)
+            self.plans[key] = plan
+        return plan
+
+    # ------------------------------------------------------------------ execution
+    def _run_forward(self, plan, x, y):
+        stream = torch.cuda.current_stream().cuda_stream
+        self.store.compute_weights(plan.dtype, force=False)
+        xs = {"x": x, "y": y if y is not None else x}
+        keep = []
+        for desc, which in plan.dyn_in:
+            t = xs[which]
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.float().contiguous()
+            keep.append(t)
+            desc.p[0] = t.data_ptr()
+        plan._dyn_keep = keep
+        plan.run("fwd", stream)
+        if plan.training and len(self.store.nbt):
+            self.store.NBT += 1
+
+    def _run_backward(self, plan, dps):
+        stream = torch.cuda.current_stream().cuda_stream
+        self.store.attach_grads()
+        keep = []
+        for desc, hi in plan.dyn_dp:
+            g = dps[hi]
+            if g is None:
+                g = torch.zeros_like(plan.p_out[hi])
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.float().contiguous()
+            keep.append(g)
+            desc.p[0] = g.data_ptr()
+        plan._dyn_keep_b = keep
+        plan.run("bwd", stream)
+
+    # ------------------------------------------------------------------ public
+    def forward(self, x, y=None):
+        model = self.model
+        self._prepare(x)
+        B, _, H, W = x.shape
+        dtype = _compute_dtype(model)
+        training = model.training
+        plan = self.get_plan(B, H, W, dtype, training, x.device)
+        di = "second_index" in model.net_info and y is not None
+        if "second_index" in model.net_info and not di:
+            raise L.DykError("this cfg is dual-stream (second_index set): call model(visible, lwir)")
+        if training:
+            if torch.is_grad_enabled():
+                anchor = next(model.parameters())
+                outs = _NetFunction.apply(self, plan, anchor, x, y)
+                return list(outs)
+            self._run_forward(plan, x, y)
+            return list(plan.p_out)
+        with torch.no_grad():
+            self._run_forward(plan, x, y)
+        return plan.io, tuple(plan.p_out)

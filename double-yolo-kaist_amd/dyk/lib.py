@@ -1,7 +1,7 @@
 """ctypes binding of libdyk_hip.so (C ABI declared in include/dyk_hip.h).
 
-The product path has no CPU fallback: if the shared library cannot be loaded the import
-of any operator that needs it raises ``DykLibraryError``.
+The product path has no CPU fallback: if the shared library cannot be loaded, anything that
+needs it raises ``DykLibraryError``.
 """
 import ctypes
 import os
@@ -13,7 +13,14 @@ LIB_PATH = os.path.join(CSRC_DIR, "libdyk_hip.so")
 DYK_F32, DYK_BF16 = 0, 1
 ACT_CODES = {"linear": 0, "leaky": 1, "mish": 2, "relu": 3, "relu6": 4, "hard-sigmoid": 5, "hard-swish": 6}
 EPI_AFFINE, EPI_RESIDUAL, EPI_STATS, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 4, 8, 16
+EW_ACCUM = 1
 MAX_TAPS = 25
+
+# op codes of DykCommand (include/dyk_hip.h)
+(OP_CONV, OP_WGRAD, OP_BN_FINALIZE, OP_BN_ACT_FWD, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_AXPBY, OP_DOT,
+ OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_SE_POOL, OP_SE_FC_FWD, OP_SE_FC_BWD,
+ OP_SE_SCALE, OP_BN_BWD_PARAMS, OP_BN_FOLD, OP_WFUSE_WEIGHTS, OP_WFUSE_BWD_PARAMS, OP_HEAD_PERMUTE_FWD,
+ OP_HEAD_PERMUTE_BWD, OP_PATCH_GATHER, OP_MEMSET, OP_YOLO_DECODE, OP_DW_CONV) = range(1, 27)
 
 
 class DykLibraryError(RuntimeError):
@@ -24,52 +31,116 @@ class DykError(RuntimeError):
     pass
 
 
+_i8, _i32, _i64, _f32, _vp = ctypes.c_int8, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
 class DykConvDesc(ctypes.Structure):
     _fields_ = [
-        ("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("y", ctypes.c_void_p),
-        ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("res", ctypes.c_void_p),
-        ("stats", ctypes.c_void_p),
-        ("dtype", ctypes.c_int32),
-        ("ldx", ctypes.c_int32), ("ldy", ctypes.c_int32), ("ldr", ctypes.c_int32),
-        ("B", ctypes.c_int32), ("Hi", ctypes.c_int32), ("Wi", ctypes.c_int32),
-        ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32),
-        ("Hg", ctypes.c_int32), ("Wg", ctypes.c_int32), ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32),
-        ("isy", ctypes.c_int32), ("isx", ctypes.c_int32), ("osy", ctypes.c_int32), ("osx", ctypes.c_int32),
-        ("ooy", ctypes.c_int32), ("oox", ctypes.c_int32),
-        ("ntaps", ctypes.c_int32),
-        ("tdy", ctypes.c_int8 * MAX_TAPS), ("tdx", ctypes.c_int8 * MAX_TAPS), ("twt", ctypes.c_int8 * MAX_TAPS),
-        ("_pad", ctypes.c_int8),
-        ("act", ctypes.c_int32), ("flags", ctypes.c_int32),
+        ("x", _vp), ("w", _vp), ("y", _vp), ("scale", _vp), ("shift", _vp), ("res", _vp), ("stats", _vp),
+        ("dtype", _i32), ("ldx", _i32), ("ldy", _i32), ("ldr", _i32),
+        ("B", _i32), ("Hi", _i32), ("Wi", _i32), ("Cin", _i32), ("Cout", _i32),
+        ("Hg", _i32), ("Wg", _i32), ("Ho", _i32), ("Wo", _i32),
+        ("isy", _i32), ("isx", _i32), ("osy", _i32), ("osx", _i32), ("ooy", _i32), ("oox", _i32),
+        ("ntaps", _i32),
+        ("tdy", _i8 * MAX_TAPS), ("tdx", _i8 * MAX_TAPS), ("twt", _i8 * MAX_TAPS), ("_pad", _i8),
+        ("act", _i32), ("flags", _i32),
     ]
 
 
 class DykWgradDesc(ctypes.Structure):
     _fields_ = [
-        ("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p),
-        ("dtype", ctypes.c_int32), ("ldx", ctypes.c_int32), ("lddy", ctypes.c_int32),
-        ("B", ctypes.c_int32), ("Hi", ctypes.c_int32), ("Wi", ctypes.c_int32), ("Cin", ctypes.c_int32),
-        ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32), ("Cout", ctypes.c_int32),
-        ("isy", ctypes.c_int32), ("isx", ctypes.c_int32),
-        ("ntaps", ctypes.c_int32),
-        ("tdy", ctypes.c_int8 * MAX_TAPS), ("tdx", ctypes.c_int8 * MAX_TAPS), ("twt", ctypes.c_int8 * MAX_TAPS),
-        ("_pad", ctypes.c_int8),
-        ("splits", ctypes.c_int32),
+        ("x", _vp), ("dy", _vp), ("dw", _vp),
+        ("dtype", _i32), ("ldx", _i32), ("lddy", _i32),
+        ("B", _i32), ("Hi", _i32), ("Wi", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32), ("Cout", _i32),
+        ("isy", _i32), ("isx", _i32), ("ntaps", _i32),
+        ("tdy", _i8 * MAX_TAPS), ("tdx", _i8 * MAX_TAPS), ("twt", _i8 * MAX_TAPS), ("_pad", _i8),
+        ("splits", _i32), ("lddw", _i32),
     ]
 
 
-_lib = None
+class DykEwDesc(ctypes.Structure):
+    _fields_ = [
+        ("a", _vp), ("b", _vp), ("out", _vp), ("p0", _vp), ("p1", _vp), ("p2", _vp), ("p3", _vp), ("red", _vp),
+        ("aux", _vp),
+        ("dtype", _i32), ("npix", _i32), ("C", _i32), ("lda", _i32), ("ldb", _i32), ("ldo", _i32),
+        ("act", _i32), ("flags", _i32), ("B", _i32), ("H", _i32), ("W", _i32), ("k", _i32),
+        ("alpha", _f32), ("beta", _f32),
+    ]
 
-# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against
-# the declarations in include/dyk_hip.h.
-_i32, _f32, _vp = ctypes.c_int32, ctypes.c_float, ctypes.c_void_p
+
+class DykBnFinalizeDesc(ctypes.Structure):
+    _fields_ = [
+        ("stats", _vp), ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp),
+        ("scale", _vp), ("shift", _vp), ("save_mean", _vp), ("save_rstd", _vp),
+        ("C", _i32), ("count", _i32), ("momentum", _f32), ("eps", _f32),
+    ]
+
+
+class DykSeFcDesc(ctypes.Structure):
+    _fields_ = [
+        ("pooled", _vp), ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("scale", _vp), ("dscale", _vp),
+        ("dpooled", _vp), ("dw1", _vp), ("db1", _vp), ("dw2", _vp), ("db2", _vp),
+        ("B", _i32), ("C", _i32), ("Cs", _i32),
+    ]
+
+
+class DykTransposeEntry(ctypes.Structure):
+    _fields_ = [("src_off", _i64), ("dst_off", _i64), ("taps", _i32), ("rows", _i32), ("cols", _i32),
+                ("tile_begin", _i32)]
+
+
+class DykMiscDesc(ctypes.Structure):
+    _fields_ = [("p", _vp * 6), ("n", _i64), ("i", _i32 * 12), ("f", _f32 * 4)]
+
+
+class DykCommand(ctypes.Structure):
+    _fields_ = [("op", _i32), ("_pad", _i32), ("desc", _vp)]
+
+
+class DykDecodeDesc(ctypes.Structure):
+    _fields_ = [("p", _vp), ("io", _vp), ("B", _i32), ("na", _i32), ("ny", _i32), ("nx", _i32), ("no", _i32),
+                ("rows_total", _i32), ("row_offset", _i32), ("v4", _i32), ("stride", _f32),
+                ("anchor_vec", _f32 * 16)]
+
+
+_lib = None
+_P = ctypes.POINTER
+
+# name -> (restype, argtypes); tests/test_abi.py checks this table against include/dyk_hip.h.
 SIGNATURES = {
     "dyk_abi_version": (_i32, []),
     "dyk_error_string": (ctypes.c_char_p, [_i32]),
-    "dyk_conv_igemm": (_i32, [ctypes.POINTER(DykConvDesc), _vp]),
-    "dyk_conv_wgrad": (_i32, [ctypes.POINTER(DykWgradDesc), _vp]),
+    "dyk_conv_igemm": (_i32, [_P(DykConvDesc), _vp]),
+    "dyk_conv_wgrad": (_i32, [_P(DykWgradDesc), _vp]),
+    "dyk_bn_finalize": (_i32, [_P(DykBnFinalizeDesc), _vp]),
+    "dyk_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp]),
+    "dyk_bn_act_fwd": (_i32, [_P(DykEwDesc), _vp]),
+    "dyk_bn_act_bwd_reduce": (_i32, [_P(DykEwDesc), _vp]),
+    "dyk_bn_bwd_params": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "dyk_bn_act_bwd_apply": (_i32, [_P(DykEwDesc), _vp]),
+    "dyk_axpby": (_i32, [_P(DykEwDesc), _vp]),
+    "dyk_dot": (_i32, [_P(DykEwDesc), _vp]),
+    "dyk_wfuse_weights": (_i32, [_vp, _vp, _i32, _vp]),
+    "dyk_wfuse_bwd_params": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "dyk_upsample2x_fwd": (_i32, [_P(DykEwDesc), _vp]),
+    "dyk_upsample2x_bwd": (_i32, [_P(DykEwDesc), _vp]),
+    "dyk_maxpool_fwd": (_i32, [_P(DykEwDesc), _vp, _vp]),
+    "dyk_maxpool_bwd": (_i32, [_P(DykEwDesc), _vp, _vp]),
+    "dyk_se_pool": (_i32, [_P(DykEwDesc), _vp, _vp]),
+    "dyk_se_fc_fwd": (_i32, [_P(DykSeFcDesc), _vp]),
+    "dyk_se_fc_bwd": (_i32, [_P(DykSeFcDesc), _vp]),
+    "dyk_se_scale": (_i32, [_P(DykEwDesc), _vp]),
+    "dyk_head_permute_fwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dyk_head_permute_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dyk_patch_gather": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dyk_pack_conv_weight": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dyk_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dyk_nhwc_to_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dyk_cast_f32": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "dyk_cast_pad_rows": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "dyk_transpose_taps": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "dyk_run_commands": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
+    "dyk_yolo_decode": (_i32, [_P(DykDecodeDesc), _vp]),
 }
 
 
@@ -88,9 +159,14 @@ def load(path=None):
     except OSError as e:  # pragma: no cover
         raise DykLibraryError("cannot load %s: %s" % (p, e))
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise DykLibraryError("%s does not export %s (stale build?)" % (p, name))
         fn.restype = res
         fn.argtypes = args
+    if lib.dyk_abi_version() != 1:
+        raise DykLibraryError("ABI version mismatch")
     _lib = lib
     return lib
 

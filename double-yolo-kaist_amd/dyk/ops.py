@@ -208,5 +208,6 @@ def conv2d_wgrad(x, dy, k, stride, pad, *, dw=None, splits=0, Cin=None, Cout=Non
     for i, (ty, tx, wt) in enumerate(taps):
         d.tdy[i], d.tdx[i], d.twt[i] = ty, tx, wt
     d.splits = splits
+    d.lddw = 0
     check(load().dyk_conv_wgrad(ctypes.byref(d), _stream()), "dyk_conv_wgrad")
     return dw

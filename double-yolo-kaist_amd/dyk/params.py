@@ -1,0 +1,209 @@
+"""Parameter store: every trainable tensor of a YOLO model lives in ONE flat fp32 device buffer
+(and its gradient in a second one), conv weights in the tap-major order [kh*kw][Cout][Cin] the
+kernels consume.  The nn.Parameters the reference API exposes (`module_list[i].Conv2d.weight`, ...)
+are strided *views* into that buffer with the reference's shapes, so state_dict()/load_state_dict()/
+torch.optim keep working while
+  * the weight-gradient kernel accumulates straight into `.grad` storage,
+  * the compute-dtype copy of all weights is one cast launch, the transposed copy one more,
+  * a data-parallel gradient all-reduce sees one contiguous buffer in layer order.
+"""
+import ctypes
+
+import torch
+
+from . import lib as L
+from .lib import check, load
+
+ALIGN = 64  # elements
+
+
+def _round_up(n, a):
+    return (n + a - 1) // a * a
+
+
+class Entry:
+    __slots__ = ("name", "param", "kind", "shape", "offset", "numel", "layer", "storage_shape", "perm")
+
+
+class ParamStore:
+    def __init__(self, model):
+        self.model = model
+        self.entries = []       # parameters (flat P / G)
+        self.rstats = []        # (module, attr, offset, numel)  running_mean / running_var
+        self.nbt = []           # BatchNorm modules whose num_batches_tracked we own
+        self.by_name = {}
+        off = 0
+        roff = 0
+        import torch.nn as nn
+        for li, mod in enumerate(model.module_list):
+            for mname, sub in mod.named_modules():
+                for pname, p in sub.named_parameters(recurse=False):
+                    e = Entry()
+                    e.name = "module_list.%d.%s%s" % (li, (mname + ".") if mname else "", pname)
+                    e.param, e.layer, e.shape = p, li, tuple(p.shape)
+                    e.numel = p.numel()
+                    if isinstance(sub, nn.Conv2d) and pname == "weight":
+                        co, ci, kh, kw = p.shape
+                        if getattr(sub, "_dyk_stem", False):
+                            e.kind, e.storage_shape, e.perm = "stem_w", (co, kh, kw, ci), (0, 3, 1, 2)
+                        else:
+                            e.kind, e.storage_shape, e.perm = "conv_w", (kh, kw, co, ci), (2, 3, 0, 1)
+                    else:
+                        e.kind, e.storage_shape, e.perm = "vec", tuple(p.shape), None
+                    e.offset = off
+                    off += _round_up(e.numel, ALIGN)
+                    self.entries.append(e)
+                    self.by_name[e.name] = e
+                if isinstance(sub, nn.BatchNorm2d):
+                    for attr in ("running_mean", "running_var"):
+                        n = getattr(sub, attr).numel()
+                        self.rstats.append((sub, attr, roff, n))
+                        roff += _round_up(n, ALIGN)
+                    self.nbt.append(sub)
+        self.total = max(off, ALIGN)
+        self.rtotal = max(roff, ALIGN)
+        self.P = self.G = self.R = self.NBT = None
+        self.device = None
+        self._compute = {}      # dtype -> dict(Wc, Wt, stems, version)
+        self._ttable = None
+        self._dirty = 0
+
+    # ------------------------------------------------------------------ adoption
+    def _view(self, flat, e):
+        s = flat[e.offset:e.offset + e.numel].view(e.storage_shape)
+        return s.permute(*e.perm) if e.perm is not None else s
+
+    def is_adopted(self, device):
+        if self.P is None or self.device != device:
+            return False
+        e0, e1 = self.entries[0], self.entries[-1]
+        ok = e0.param.data.data_ptr() == self.P.data_ptr() + 4 * e0.offset and \
+            e1.param.data.data_ptr() == self.P.data_ptr() + 4 * e1.offset
+        if ok and self.rstats:
+            m, attr, roff, n = self.rstats[-1]
+            ok = getattr(m, attr).data_ptr() == self.R.data_ptr() + 4 * roff
+        return ok
+
+    def adopt(self, device):
+        """(Re)build the flat buffers on `device` from the current parameter values and make the
+        Parameters / BN buffers views into them.  Called lazily, e.g. after model.to(device)."""
+        P = torch.zeros(self.total, dtype=torch.float32, device=device)
+        G = torch.zeros(self.total, dtype=torch.float32, device=device)
+        R = torch.zeros(self.rtotal, dtype=torch.float32, device=device)
+        NBT = torch.zeros(max(len(self.nbt), 1), dtype=torch.long, device=device)
+        with torch.no_grad():
+            for e in self.entries:
+                v = self._view(P, e)
+                v.copy_(e.param.data.to(device=device, dtype=torch.float32))
+                e.param.data = v
+                e.param.grad = None
+            for (m, attr, roff, n) in self.rstats:
+                v = R[roff:roff + n]
+                v.copy_(getattr(m, attr).to(device=device, dtype=torch.float32))
+                m._buffers[attr] = v
+            for i, m in enumerate(self.nbt):
+                NBT[i] = int(m.num_batches_tracked)
+                m._buffers["num_batches_tracked"] = NBT[i]
+        self.P, self.G, self.R, self.NBT, self.device = P, G, R, NBT, device
+        self._compute = {}
+        self._ttable = None
+
+    def grads_attached(self):
+        e0, e1 = self.entries[0], self.entries[-1]
+        for e in (e0, e1):
+            g = e.param.grad
+            if g is None or g.data_ptr() != self.G.data_ptr() + 4 * e.offset:
+                return False
+        return True
+
+    def attach_grads(self):
+        """Make every p.grad the matching view of G.  If they were detached (zero_grad(set_to_none),
+        first step) G is zeroed first, otherwise the kernels keep accumulating into it."""
+        if self.grads_attached():
+            return
+        self.G.zero_()
+        for e in self.entries:
+            e.param.grad = self._view(self.G, e)
+
+    # ------------------------------------------------------------------ pointers
+    def p_ptr(self, name):
+        e = self.by_name[name]
+        return self.P.data_ptr() + 4 * e.offset
+
+    def g_ptr(self, name):
+        e = self.by_name[name]
+        return self.G.data_ptr() + 4 * e.offset
+
+    def r_ptr(self, mod, attr):
+        for (m, a, roff, n) in self.rstats:
+            if m is mod and a == attr:
+                return self.R.data_ptr() + 4 * roff
+        raise KeyError(attr)
+
+    # ------------------------------------------------------------------ compute-dtype staging
+    def _transpose_table(self):
+        if self._ttable is None:
+            ents = [e for e in self.entries if e.kind == "conv_w" and e.shape[0] % 32 == 0]
+            arr = (L.DykTransposeEntry * max(len(ents), 1))()
+            tiles = 0
+            for i, e in enumerate(ents):
+                co, ci, kh, kw = e.shape
+                arr[i].src_off = e.offset
+                arr[i].dst_off = e.offset
+                arr[i].taps, arr[i].rows, arr[i].cols = kh * kw, co, ci
+                arr[i].tile_begin = tiles
+                tiles += kh * kw * ((co + 31) // 32) * ((ci + 31) // 32)
+            raw = bytes(arr)
+            t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            self._ttable = (t, len(ents), tiles)
+        return self._ttable
+
+    def mark_dirty(self):
+        self._dirty += 1
+
+    def compute_weights(self, dtype, force=False):
+        """Return dict(Wc=<tensor same offsets as P>, Wt=<transposed per tap>, stems={name: tensor})
+        for the compute dtype, refreshed iff the master buffer changed since the last call."""
+        st = self._compute.get(dtype)
+        # Parameter.data views do not share a version counter with P, so track the parameters'
+        # own counters (optimizer steps / load_state_dict bump them) plus an explicit dirty flag
+        # for writers that go through `.data` (load_darknet_weights).
+        ver = (sum(e.param._version for e in self.entries), self._dirty)
+        if st is not None and st["version"] == ver and not force:
+            return st
+        lib = load()
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        code = L.DYK_BF16 if dtype == torch.bfloat16 else L.DYK_F32
+        if st is None:
+            st = {"stems": {}, "heads_t": {}}
+            st["Wc"] = self.P if dtype == torch.float32 else torch.empty(self.total, dtype=dtype, device=self.device)
+            st["Wt"] = torch.zeros(self.total, dtype=dtype, device=self.device)
+            for e in self.entries:
+                if e.kind == "stem_w":
+                    co, ci, kh, kw = e.shape
+                    st["stems"][e.name] = torch.zeros((co, _round_up(ci * kh * kw, 32)), dtype=dtype, device=self.device)
+                elif e.kind == "conv_w" and e.shape[0] % 32:
+                    # detection heads (Cout = na*(5+nc)): the data-gradient GEMM needs K padded to 32
+                    co, ci, kh, kw = e.shape
+                    assert kh == 1 and kw == 1, "Cout %% 32 != 0 is only supported for 1x1 convs (%s)" % e.name
+                    st["heads_t"][e.name] = torch.zeros((ci, _round_up(co, 32)), dtype=dtype, device=self.device)
+            self._compute[dtype] = st
+        if dtype != torch.float32:
+            check(lib.dyk_cast_f32(self.P.data_ptr(), st["Wc"].data_ptr(), self.total, code, stream), "dyk_cast_f32")
+        tab, n, tiles = self._transpose_table()
+        if n:
+            check(lib.dyk_transpose_taps(self.P.data_ptr(), st["Wt"].data_ptr(), tab.data_ptr(), n, tiles, code, stream),
+                  "dyk_transpose_taps")
+        for e in self.entries:
+            if e.kind == "stem_w":
+                co, ci, kh, kw = e.shape
+                t = st["stems"][e.name]
+                check(lib.dyk_cast_pad_rows(self.P.data_ptr() + 4 * e.offset, t.data_ptr(), co, ci * kh * kw, t.shape[1],
+                                            code, stream), "dyk_cast_pad_rows")
+        for name, t in st["heads_t"].items():
+            e = self.by_name[name]
+            co, ci, kh, kw = e.shape
+            check(lib.dyk_pack_conv_weight(self.P.data_ptr() + 4 * e.offset, t.data_ptr(), co, ci, 1, 1, t.shape[1], ci, 1,
+                                           code, stream), "dyk_pack_conv_weight")
+        st["version"] = ver
+        return st

@@ -1,0 +1,636 @@
+"""Plan compiler: cfg sections + batch shape + dtype + mode  ->  static device buffers and flat
+command lists (forward, backward) of resolved kernel descriptors that libdyk_hip.so executes
+natively (dyk_run_commands).
+
+This replaces the reference's eager interpreter loop (models.py:291-305: one Python iteration and
+3+ framework launches per cfg section, every step) with a one-time compilation:
+  * shapes, channel strides and buffer offsets are resolved once;
+  * single-input [route] sections become aliases, multi-input ones write into one concat buffer;
+  * BatchNorm statistics are produced by the convolution epilogue, the normalise+activation pass
+    carries the residual of a following plain [shortcut];
+  * the backward list is generated from the forward one with static knowledge of which gradient
+    buffer is written first (store) and which later (accumulate) -- no runtime autograd graph.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import lib as L
+from .ops import conv_out_size, dgrad_classes, fwd_taps
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+HEAD_LD = 32            # head conv outputs / their gradients live in 32-channel rows
+
+
+def _ru(n, a):
+    return (n + a - 1) // a * a
+
+
+class TRef:
+    """A channels-last tensor inside an arena: arena name, byte offset, logical shape, pixel stride."""
+    _next = [0]
+
+    def __init__(self, arena, off, B, H, W, C, ld, esize, tid=None):
+        self.arena, self.off, self.B, self.H, self.W, self.C, self.ld, self.esize = arena, off, B, H, W, C, ld, esize
+        if tid is None:
+            tid = TRef._next[0]
+            TRef._next[0] += 1
+        self.tid = tid
+
+    @property
+    def npix(self):
+        return self.B * self.H * self.W
+
+    def chan_slice(self, c0, C):
+        return TRef(self.arena, self.off + c0 * self.esize, self.B, self.H, self.W, C, self.ld, self.esize)
+
+
+class Arena:
+    def __init__(self, name):
+        self.name, self.size, self.tensor = name, 0, None
+
+    def alloc(self, nbytes, align=256):
+        off = _ru(self.size, align)
+        self.size = off + nbytes
+        return off
+
+    def materialize(self, device, zero=True):
+        n = max(self.size, 256)
+        self.tensor = torch.zeros(n, dtype=torch.uint8, device=device) if zero else \
+            torch.empty(n, dtype=torch.uint8, device=device)
+        return self.tensor
+
+    def ptr(self, off=0):
+        return self.tensor.data_ptr() + off
+
+
+class Plan:
+    """Compiled execution plan.  Build with `compile_plan`."""
+
+    def __init__(self):
+        self.fwd, self.bwd = [], []            # lists of (op, desc)
+        self.dyn_in = []                       # (desc, 'x'|'y')  patch-gather inputs to patch per call
+        self.dyn_dp = []                       # (desc, head index) head-permute-bwd inputs
+        self.p_out = []                        # per head: torch tensor [B,na,ny,nx,no] fp32
+        self.io = None                         # eval: [B, rows, no]
+        self.arenas = {}
+        self._keep = []
+        self._cfwd = self._cbwd = None
+
+    def _pack(self, cmds):
+        arr = (L.DykCommand * max(len(cmds), 1))()
+        for i, (op, desc) in enumerate(cmds):
+            arr[i].op = op
+            arr[i].desc = ctypes.addressof(desc)
+        return arr
+
+    def finalize(self):
+        self._cfwd = self._pack(self.fwd)
+        self._cbwd = self._pack(self.bwd)
+
+    def run(self, which, stream_ptr):
+        arr, n = (self._cfwd, len(self.fwd)) if which == "fwd" else (self._cbwd, len(self.bwd))
+        failed = ctypes.c_int32(-1)
+        rc = L.load().dyk_run_commands(arr, n, ctypes.c_void_p(stream_ptr), ctypes.byref(failed))
+        if rc != 0:
+            cmds = self.fwd if which == "fwd" else self.bwd
+            raise L.DykError("plan %s command %d (op %d) failed: %s" % (
+                which, failed.value, cmds[failed.value][0] if 0 <= failed.value < len(cmds) else -1,
+                L.load().dyk_error_string(rc).decode()))
+
+
+# ======================================================================================
+def compile_plan(model, store, B, H, W, dtype, training, device):
+    """model: models.YOLO ; store: ParamStore (adopted on `device`)."""
+    cw = store.compute_weights(dtype)
+    code = L.DYK_BF16 if dtype == torch.bfloat16 else L.DYK_F32
+    es = 2 if dtype == torch.bfloat16 else 4
+    plan = Plan()
+    act_arena, grad_arena, ws = Arena("act"), Arena("grad"), Arena("ws")
+    plan.arenas = {"act": act_arena, "grad": grad_arena, "ws": ws}
+    pending = []        # closures that fill pointers once the arenas exist
+    defs = model.module_defs
+    mods = model.module_list
+    net = model.net_info
+    second = net.get("second_index", None)
+    v4 = "yolov4" in model.cfg
+
+    def new_act(Bn, Hn, Wn, C, ld=None, esize=None):
+        ld = ld or C
+        esize = esize or es
+        return TRef("act", act_arena.alloc(Bn * Hn * Wn * ld * esize), Bn, Hn, Wn, C, ld, esize)
+
+    def new_ws(nbytes):
+        return ws.alloc(nbytes)
+
+    def ptr_of(t):
+        return plan.arenas[t.arena].ptr(t.off)
+
+    def later(fn):
+        pending.append(fn)
+
+    def ew_desc(a=None, b=None, out=None, C=None, npix=None, act=0, flags=0, alpha=1.0, beta=1.0, Bn=0, Hn=0, Wn=0, k=0):
+        d = L.DykEwDesc()
+        d.dtype = code
+        d.C = C if C is not None else (a.C if a is not None else 0)
+        d.npix = npix if npix is not None else (a.npix if a is not None else 0)
+        d.lda = a.ld if a is not None else 0
+        d.ldb = b.ld if b is not None else 0
+        d.ldo = out.ld if out is not None else 0
+        d.act, d.flags, d.alpha, d.beta = act, flags, alpha, beta
+        d.B, d.H, d.W, d.k = Bn, Hn, Wn, k
+
+        def fill(d=d, a=a, b=b, out=out):
+            d.a = ptr_of(a) if a is not None else None
+            d.b = ptr_of(b) if b is not None else None
+            d.out = ptr_of(out) if out is not None else None
+        later(fill)
+        plan._keep.append(d)
+        return d
+
+    def misc():
+        d = L.DykMiscDesc()
+        plan._keep.append(d)
+        return d
+
+    # ---------------------------------------------------------------- forward
+    outs = []                 # per layer: TRef or None
+    info = []                 # per layer: dict of what backward needs
+    cur = None                # current x
+    img = {"x": None, "y": None}
+    yolo_rows = []
+    head_idx = 0
+    na_no = []
+
+    def conv_forward(i, m, mod, x_in, stem_src):
+        """emit forward commands of a [convolutional] section; returns (out TRef, info dict)"""
+        conv = mod[0]
+        bn = bool(m["batch_normalize"])
+        k = m["size"]
+        stride = m["stride"]
+        pad = k // 2 if m["pad"] else 0
+        cout = m["filters"]
+        act = L.ACT_CODES.get(m["activation"], 0)
+        pre = "module_list.%d." % i
+        rec = {"kind": "conv", "bn": bn, "k": k, "stride": stride, "pad": pad, "cout": cout, "act": act, "i": i,
+               "stem": stem_src is not None}
+        if stem_src is not None:
+            # Cin=3 stem: gather k*k*3 patches (zero padded to 32) and run a 1x1 MFMA conv on them
+            Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+            patches = new_act(B, Ho, Wo, 32)
+            g = misc()
+            g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.i[5], g.i[6], g.i[7], g.i[8] = B, 3, H, W, k, stride, pad, 32, code
+            g.f[0] = 1.0
+            later(lambda g=g, patches=patches: g.p.__setitem__(1, ptr_of(patches)))
+            plan.dyn_in.append((g, stem_src))
+            plan.fwd.append((L.OP_PATCH_GATHER, g))
+            x_in = patches
+            wfwd_ptr = cw["stems"][pre + "Conv2d.weight"].data_ptr()
+            taps, cin_k, cisy = [(0, 0, 0)], 32, 1
+            rec["wgrad"] = dict(x=patches, Cin=k * k * 3, lddw=k * k * 3, taps=[(0, 0, 0)], isy=1, Hi=Ho, Wi=Wo)
+            Hi, Wi = Ho, Wo
+        else:
+            Hi, Wi = x_in.H, x_in.W
+            Ho, Wo = conv_out_size(Hi, k, stride, pad), conv_out_size(Wi, k, stride, pad)
+            e = store.by_name[pre + "Conv2d.weight"]
+            wfwd_ptr = cw["Wc"].data_ptr() + e.offset * es
+            taps, cin_k, cisy = fwd_taps(k, pad), x_in.C, stride
+            assert x_in.C % 32 == 0, "conv input channels must be a multiple of 32 (layer %d)" % i
+            rec["wgrad"] = dict(x=x_in, Cin=x_in.C, lddw=0, taps=taps, isy=stride, Hi=Hi, Wi=Wi)
+        rec["x"] = x_in
+        d = L.DykConvDesc()
+        plan._keep.append(d)
+        d.dtype = code
+        d.w = wfwd_ptr
+        d.B, d.Hi, d.Wi, d.Cin, d.Cout = B, Hi, Wi, cin_k, cout
+        d.Hg, d.Wg, d.Ho, d.Wo = Ho, Wo, Ho, Wo
+        d.isy = d.isx = cisy
+        d.osy = d.osx = 1
+        d.ntaps = len(taps)
+        for q, (ty, tx, wt) in enumerate(taps):
+            d.tdy[q], d.tdx[q], d.twt[q] = ty, tx, wt
+        d.ldx = x_in.ld
+        if bn:
+            bnm = mod[1]
+            if training:
+                y_raw = new_act(B, Ho, Wo, cout)
+                z = new_act(B, Ho, Wo, cout)
+                stats = new_ws(2 * cout * 8)
+                vecs = new_ws(4 * cout * 4)          # scale | shift | mean | rstd
+                d.ldy, d.act, d.flags = y_raw.ld, 0, L.EPI_STATS
+                later(lambda d=d, x_in=x_in, y_raw=y_raw, stats=stats: (
+                    setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", ws.ptr(stats))))
+                plan.fwd.append((L.OP_CONV, d))
+                f = L.DykBnFinalizeDesc()
+                plan._keep.append(f)
+                f.gamma, f.beta = store.p_ptr(pre + "BatchNorm2d.weight"), store.p_ptr(pre + "BatchNorm2d.bias")
+                f.running_mean, f.running_var = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
+                f.C, f.count, f.momentum, f.eps = cout, B * Ho * Wo, BN_MOMENTUM, BN_EPS
+                later(lambda f=f, stats=stats, vecs=vecs: (
+                    setattr(f, "stats", ws.ptr(stats)), setattr(f, "scale", ws.ptr(vecs)),
+                    setattr(f, "shift", ws.ptr(vecs + 4 * cout)), setattr(f, "save_mean", ws.ptr(vecs + 8 * cout)),
+                    setattr(f, "save_rstd", ws.ptr(vecs + 12 * cout))))
+                plan.fwd.append((L.OP_BN_FINALIZE, f))
+                a = ew_desc(a=y_raw, out=z, act=act)
+                later(lambda a=a, vecs=vecs: (setattr(a, "p0", ws.ptr(vecs)), setattr(a, "p1", ws.ptr(vecs + 4 * cout))))
+                plan.fwd.append((L.OP_BN_ACT_FWD, a))
+                rec.update(y_raw=y_raw, z=z, vecs=vecs, bn_act_desc=a)
+                return z, rec
+            # eval: fold running statistics into the conv epilogue
+            z = new_act(B, Ho, Wo, cout)
+            vecs = new_ws(2 * cout * 4)
+            fo = misc()
+            fo.p[0], fo.p[1] = store.p_ptr(pre + "BatchNorm2d.weight"), store.p_ptr(pre + "BatchNorm2d.bias")
+            fo.p[2], fo.p[3] = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
+            fo.i[0], fo.f[0] = cout, BN_EPS
+            later(lambda fo=fo, vecs=vecs: (fo.p.__setitem__(4, ws.ptr(vecs)), fo.p.__setitem__(5, ws.ptr(vecs + 4 * cout))))
+            plan.fwd.append((L.OP_BN_FOLD, fo))
+            d.ldy, d.act, d.flags = z.ld, act, L.EPI_AFFINE
+            later(lambda d=d, x_in=x_in, z=z, vecs=vecs: (
+                setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)),
+                setattr(d, "shift", ws.ptr(vecs + 4 * cout))))
+            plan.fwd.append((L.OP_CONV, d))
+            rec.update(z=z)
+            return z, rec
+        # no BN: bias epilogue; detection heads go to fp32 rows of HEAD_LD channels
+        is_head = (i + 1 < len(defs) and defs[i + 1]["type"] == "yolo")
+        if is_head:
+            assert cout <= HEAD_LD
+            z = new_act(B, Ho, Wo, cout, ld=HEAD_LD, esize=4)
+            d.flags = L.EPI_AFFINE | L.EPI_OUT_F32
+        else:
+            z = new_act(B, Ho, Wo, cout)
+            d.flags = L.EPI_AFFINE
+        d.ldy, d.act = z.ld, act
+        d.shift = store.p_ptr(pre + "Conv2d.bias")
+        later(lambda d=d, x_in=x_in, z=z: (setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(z))))
+        plan.fwd.append((L.OP_CONV, d))
+        rec.update(z=z, is_head=is_head)
+        if act != 0:
+            raise NotImplementedError("activation on a conv without batch_normalize (layer %d)" % i)
+        return z, rec
+
+    for i, m in enumerate(defs):
+        t = m["type"]
+        mod = mods[i]
+        rec = {"kind": t, "i": i}
+        if t == "convolutional":
+            if m.get("groups", 1) != 1:
+                raise NotImplementedError("grouped / depthwise [convolutional] (layer %d) is not built yet" % i)
+            stem = None
+            if i == 0:
+                stem = "x"
+            elif second is not None and i == second:
+                stem = "y"
+            cur, rec = conv_forward(i, m, mod, cur, stem)
+        elif t == "route":
+            layers = mod.layers
+            if len(layers) == 1:
+                cur = outs[layers[0]]
+                rec["alias"] = True
+            else:
+                srcs = [outs[j] for j in layers]
+                ctot = sum(s.C for s in srcs)
+                s0 = srcs[0]
+                cat = new_act(B, s0.H, s0.W, ctot)
+                c0 = 0
+                parts = []
+                for s in srcs:
+                    sl = cat.chan_slice(c0, s.C)
+                    plan.fwd.append((L.OP_AXPBY, ew_desc(a=s, out=sl)))
+                    parts.append((s, c0))
+                    c0 += s.C
+                cur = cat
+                rec.update(parts=parts, out=cat)
+        elif t == "shortcut":
+            layers = mod.layers
+            x_in = cur
+            if len(layers) != 1:
+                raise NotImplementedError("[shortcut] with %d sources" % len(layers))
+            a = outs[layers[0]]
+            C = min(x_in.C, a.C)
+            if x_in.C != a.C:
+                raise NotImplementedError("[shortcut] with mismatched channel counts (layer %d)" % i)
+            z = new_act(B, x_in.H, x_in.W, x_in.C)
+            if mod.weight:
+                weff = new_ws(16)
+                wd = misc()
+                wd.p[0] = store.p_ptr("module_list.%d.w" % i)
+                wd.i[0] = 2
+                later(lambda wd=wd, weff=weff: wd.p.__setitem__(1, ws.ptr(weff)))
+                plan.fwd.append((L.OP_WFUSE_WEIGHTS, wd))
+                e = ew_desc(a=x_in, b=a, out=z, C=C)
+                later(lambda e=e, weff=weff: (setattr(e, "p0", ws.ptr(weff)), setattr(e, "p1", ws.ptr(weff + 4))))
+                plan.fwd.append((L.OP_AXPBY, e))
+                rec.update(weighted=True, weff=weff)
+            else:
+                plan.fwd.append((L.OP_AXPBY, ew_desc(a=x_in, b=a, out=z, C=C)))
+                rec.update(weighted=False)
+            rec.update(x=x_in, a=a, z=z)
+            cur = z
+        elif t == "se":
+            x_in = cur
+            C, Cs = mod.fc1.in_channels, mod.fc1.out_channels
+            pooled = new_ws(B * C * 4)
+            scale = new_ws(B * C * 4)
+            z = new_act(B, x_in.H, x_in.W, C)
+            pd = ew_desc(a=x_in, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W, alpha=1.0 / (x_in.H * x_in.W))
+            later(lambda pd=pd, pooled=pooled: setattr(pd, "aux", ws.ptr(pooled)))
+            plan.fwd.append((L.OP_SE_POOL, pd))
+            pre = "module_list.%d." % i
+            fd = L.DykSeFcDesc()
+            plan._keep.append(fd)
+            fd.w1, fd.b1 = store.p_ptr(pre + "fc1.weight"), store.p_ptr(pre + "fc1.bias")
+            fd.w2, fd.b2 = store.p_ptr(pre + "fc2.weight"), store.p_ptr(pre + "fc2.bias")
+            fd.B, fd.C, fd.Cs = B, C, Cs
+            later(lambda fd=fd, pooled=pooled, scale=scale: (setattr(fd, "pooled", ws.ptr(pooled)), setattr(fd, "scale", ws.ptr(scale))))
+            plan.fwd.append((L.OP_SE_FC_FWD, fd))
+            sd = ew_desc(a=x_in, out=z, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W)
+            later(lambda sd=sd, scale=scale: setattr(sd, "p0", ws.ptr(scale)))
+            plan.fwd.append((L.OP_SE_SCALE, sd))
+            rec.update(x=x_in, z=z, pooled=pooled, scale=scale, C=C, Cs=Cs)
+            cur = z
+        elif t == "maxpool":
+            x_in = cur
+            k, stride = m["size"], m["stride"]
+            if stride != 1:
+                raise NotImplementedError("[maxpool] stride %d" % stride)
+            z = new_act(B, x_in.H, x_in.W, x_in.C)
+            amax = new_ws(x_in.npix * x_in.C) if training else None
+            pd = ew_desc(a=x_in, out=z, Bn=B, Hn=x_in.H, Wn=x_in.W, k=k)
+            if amax is not None:
+                later(lambda pd=pd, amax=amax: setattr(pd, "aux", ws.ptr(amax)))
+            plan.fwd.append((L.OP_MAXPOOL_FWD, pd))
+            rec.update(x=x_in, z=z, amax=amax, k=k)
+            cur = z
+        elif t == "upsample":
+            x_in = cur
+            if m["stride"] != 2:
+                raise NotImplementedError("[upsample] stride %s" % m["stride"])
+            z = new_act(B, 2 * x_in.H, 2 * x_in.W, x_in.C)
+            plan.fwd.append((L.OP_UPSAMPLE_FWD, ew_desc(a=x_in, out=z, Bn=B, Hn=x_in.H, Wn=x_in.W)))
+            rec.update(x=x_in, z=z)
+            cur = z
+        elif t == "yolo":
+            y_in = cur                       # head conv output, fp32, ld = HEAD_LD
+            na, no = mod.na, mod.no
+            ny, nx = y_in.H, y_in.W
+            p = torch.empty((B, na, ny, nx, no), dtype=torch.float32, device=device)
+            plan.p_out.append(p)
+            hd = misc()
+            hd.p[1] = p.data_ptr()
+            hd.i[0], hd.i[1], hd.i[2], hd.i[3], hd.i[4], hd.i[5] = B, ny, nx, na, no, y_in.ld
+            later(lambda hd=hd, y_in=y_in: hd.p.__setitem__(0, ptr_of(y_in)))
+            plan.fwd.append((L.OP_HEAD_PERMUTE_FWD, hd))
+            rec.update(y=y_in, na=na, no=no, ny=ny, nx=nx, head=head_idx, p=p, stride=mod.stride,
+                       anchor_vec=[float(v) for v in mod.anchor_vec.reshape(-1).tolist()])
+            yolo_rows.append(na * ny * nx)
+            head_idx += 1
+        elif t == "dropout":
+            rec["alias"] = True              # identity at inference; training dropout is not on the hot path
+        else:
+            raise NotImplementedError("cfg section [%s] (layer %d) is not built yet" % (t, i))
+        outs.append(cur)
+        info.append(rec)
+
+    # eval: decode every head into one [B, rows, no] buffer (models.py:258,315)
+    if not training:
+        rows_total = sum(yolo_rows)
+        no = info[model.yolo_layers[0]]["no"]
+        plan.io = torch.empty((B, rows_total, no), dtype=torch.float32, device=device)
+        r0 = 0
+        for j in model.yolo_layers:
+            rec = info[j]
+            dd = L.DykDecodeDesc()
+            plan._keep.append(dd)
+            dd.p, dd.io = rec["p"].data_ptr(), plan.io.data_ptr()
+            dd.B, dd.na, dd.ny, dd.nx, dd.no = B, rec["na"], rec["ny"], rec["nx"], rec["no"]
+            dd.rows_total, dd.row_offset, dd.v4, dd.stride = rows_total, r0, 1 if v4 else 0, float(rec["stride"])
+            for q, v in enumerate(rec["anchor_vec"]):
+                dd.anchor_vec[q] = v
+            plan.fwd.append((L.OP_YOLO_DECODE, dd))
+            r0 += rec["na"] * rec["ny"] * rec["nx"]
+
+    # ---------------------------------------------------------------- backward
+    if training:
+        grads = {}           # tid -> TRef in the grad arena
+        ginit = set()        # tids whose gradient buffer holds a value already
+        red_offs = []        # (offset, bytes) fp64 reduction scratch zeroed at the start of backward
+
+        def gref(t, ld=None, C=None):
+            if t.tid not in grads:
+                ldn = ld or t.ld
+                Cn = C or t.C
+                g = TRef("grad", grad_arena.alloc(t.npix * ldn * es), t.B, t.H, t.W, Cn, ldn, es, tid=t.tid)
+                grads[t.tid] = g
+            return grads[t.tid]
+
+        def acc_flag(t):
+            """store on first write, accumulate afterwards"""
+            if t.tid in ginit:
+                return L.EW_ACCUM
+            ginit.add(t.tid)
+            return 0
+
+        def new_red(nbytes):
+            off = new_ws(nbytes)
+            red_offs.append((off, nbytes))
+            return off
+
+        def emit_conv_backward(rec, dy, i):
+            """dy: gradient w.r.t. the conv's raw output (dtype), channels padded to 32 for heads"""
+            pre = "module_list.%d." % i
+            k, stride, pad, cout = rec["k"], rec["stride"], rec["pad"], rec["cout"]
+            wg = rec["wgrad"]
+            wd = L.DykWgradDesc()
+            plan._keep.append(wd)
+            wd.dtype = code
+            wd.dw = store.g_ptr(pre + "Conv2d.weight")
+            wd.ldx, wd.lddy = wg["x"].ld, dy.ld
+            wd.B, wd.Hi, wd.Wi, wd.Cin = B, wg["Hi"], wg["Wi"], wg["Cin"]
+            wd.Ho, wd.Wo, wd.Cout = dy.H, dy.W, cout
+            wd.isy = wd.isx = wg["isy"]
+            wd.ntaps = len(wg["taps"])
+            for q, (ty, tx, wt) in enumerate(wg["taps"]):
+                wd.tdy[q], wd.tdx[q], wd.twt[q] = ty, tx, wt
+            wd.splits, wd.lddw = 0, wg["lddw"]
+            later(lambda wd=wd, x=wg["x"], dy=dy: (setattr(wd, "x", ptr_of(x)), setattr(wd, "dy", ptr_of(dy))))
+            plan.bwd.append((L.OP_WGRAD, wd))
+            if rec["stem"]:
+                return
+            x_in = rec["x"]
+            gx = gref(x_in)
+            first = x_in.tid not in ginit
+            e = store.by_name[pre + "Conv2d.weight"]
+            kpad = _ru(cout, 32)
+            if kpad != cout:
+                wt_ptr = cw["heads_t"][pre + "Conv2d.weight"].data_ptr()
+            else:
+                wt_ptr = cw["Wt"].data_ptr() + e.offset * es
+            classes = dgrad_classes(k, pad, stride, x_in.H, x_in.W)
+            for (py, px, Hg, Wg, taps) in classes:
+                d = L.DykConvDesc()
+                plan._keep.append(d)
+                d.dtype = code
+                d.w = wt_ptr
+                d.B, d.Hi, d.Wi, d.Cin, d.Cout = B, dy.H, dy.W, kpad, x_in.C
+                d.Hg, d.Wg, d.Ho, d.Wo = Hg, Wg, x_in.H, x_in.W
+                d.isy = d.isx = 1
+                d.osy = d.osx = stride
+                d.ooy, d.oox = py, px
+                d.ntaps = len(taps)
+                for q, (ty, tx, wt) in enumerate(taps):
+                    d.tdy[q], d.tdx[q], d.twt[q] = ty, tx, wt
+                d.ldx, d.ldy = dy.ld, gx.ld
+                d.act, d.flags = 0, (0 if first else L.EPI_ACCUM)
+                later(lambda d=d, dy=dy, gx=gx: (setattr(d, "x", ptr_of(dy)), setattr(d, "y", ptr_of(gx))))
+                plan.bwd.append((L.OP_CONV, d))
+            ginit.add(x_in.tid)
+
+        for i in range(len(defs) - 1, -1, -1):
+            rec = info[i]
+            t = rec["kind"]
+            if rec.get("alias"):
+                continue
+            if t == "yolo":
+                y_in = rec["y"]
+                gy = gref(y_in, ld=HEAD_LD)          # dtype rows of 32 channels, zero padded
+                hd = misc()
+                hd.p[2] = store.g_ptr("module_list.%d.Conv2d.bias" % (i - 1))
+                hd.i[0], hd.i[1], hd.i[2], hd.i[3], hd.i[4], hd.i[5], hd.i[6] = B, rec["ny"], rec["nx"], rec["na"], rec["no"], HEAD_LD, code
+                later(lambda hd=hd, gy=gy: hd.p.__setitem__(1, ptr_of(gy)))
+                plan.dyn_dp.append((hd, rec["head"]))
+                plan.bwd.append((L.OP_HEAD_PERMUTE_BWD, hd))
+                ginit.add(y_in.tid)
+            elif t == "conv":
+                z = rec["z"]
+                if z.tid not in ginit:
+                    continue                         # no gradient reaches this layer
+                dz = gref(z)
+                if rec["bn"]:
+                    cout, vecs = rec["cout"], rec["vecs"]
+                    red = new_red(2 * cout * 8)
+                    r = ew_desc(a=dz, b=rec["y_raw"], act=rec["act"])
+                    later(lambda r=r, vecs=vecs, red=red, cout=cout: (
+                        setattr(r, "p0", ws.ptr(vecs)), setattr(r, "p1", ws.ptr(vecs + 4 * cout)),
+                        setattr(r, "p2", ws.ptr(vecs + 8 * cout)), setattr(r, "p3", ws.ptr(vecs + 12 * cout)),
+                        setattr(r, "red", ws.ptr(red))))
+                    plan.bwd.append((L.OP_BN_BWD_REDUCE, r))
+                    pm = misc()
+                    pre = "module_list.%d." % i
+                    pm.p[1], pm.p[2] = store.g_ptr(pre + "BatchNorm2d.weight"), store.g_ptr(pre + "BatchNorm2d.bias")
+                    pm.i[0] = cout
+                    later(lambda pm=pm, red=red: pm.p.__setitem__(0, ws.ptr(red)))
+                    plan.bwd.append((L.OP_BN_BWD_PARAMS, pm))
+                    ap = ew_desc(a=dz, b=rec["y_raw"], out=dz, act=rec["act"])      # in place: dz -> dy_raw
+                    later(lambda ap=ap, vecs=vecs, red=red, cout=cout: (
+                        setattr(ap, "p0", ws.ptr(vecs)), setattr(ap, "p1", ws.ptr(vecs + 4 * cout)),
+                        setattr(ap, "p2", ws.ptr(vecs + 8 * cout)), setattr(ap, "p3", ws.ptr(vecs + 12 * cout)),
+                        setattr(ap, "red", ws.ptr(red))))
+                    plan.bwd.append((L.OP_BN_BWD_APPLY, ap))
+                emit_conv_backward(rec, dz, i)
+            elif t == "route":
+                out = rec["out"]
+                if out.tid not in ginit:
+                    continue
+                go = gref(out)
+                for (s, c0) in rec["parts"]:
+                    gs = gref(s)
+                    fl = acc_flag(s)
+                    plan.bwd.append((L.OP_AXPBY, ew_desc(a=go.chan_slice(c0, s.C), out=gs, C=s.C, flags=fl)))
+            elif t == "shortcut":
+                z = rec["z"]
+                if z.tid not in ginit:
+                    continue
+                dz = gref(z)
+                x_in, a = rec["x"], rec["a"]
+                if rec["weighted"]:
+                    red = new_red(16)
+                    d0 = ew_desc(a=dz, b=x_in)
+                    later(lambda d0=d0, red=red: setattr(d0, "red", ws.ptr(red)))
+                    plan.bwd.append((L.OP_DOT, d0))
+                    d1 = ew_desc(a=dz, b=a)
+                    later(lambda d1=d1, red=red: setattr(d1, "red", ws.ptr(red + 8)))
+                    plan.bwd.append((L.OP_DOT, d1))
+                    pm = misc()
+                    pm.p[0], pm.p[2] = store.p_ptr("module_list.%d.w" % i), store.g_ptr("module_list.%d.w" % i)
+                    pm.i[0] = 2
+                    later(lambda pm=pm, red=red: pm.p.__setitem__(1, ws.ptr(red)))
+                    plan.bwd.append((L.OP_WFUSE_BWD_PARAMS, pm))
+                    weff = rec["weff"]
+                    for (tgt, woff) in ((x_in, weff), (a, weff + 4)):
+                        g = gref(tgt)
+                        e = ew_desc(a=dz, out=g, flags=acc_flag(tgt))
+                        later(lambda e=e, woff=woff: setattr(e, "p0", ws.ptr(woff)))
+                        plan.bwd.append((L.OP_AXPBY, e))
+                else:
+                    for tgt in (x_in, a):
+                        g = gref(tgt)
+                        plan.bwd.append((L.OP_AXPBY, ew_desc(a=dz, out=g, flags=acc_flag(tgt))))
+            elif t == "se":
+                z = rec["z"]
+                if z.tid not in ginit:
+                    continue
+                dz = gref(z)
+                x_in, C, Cs = rec["x"], rec["C"], rec["Cs"]
+                dscale = new_ws(B * C * 4)
+                dpooled = new_ws(B * C * 4)
+                pd = ew_desc(a=dz, b=x_in, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W, alpha=1.0)
+                later(lambda pd=pd, dscale=dscale: setattr(pd, "aux", ws.ptr(dscale)))
+                plan.bwd.append((L.OP_SE_POOL, pd))
+                pre = "module_list.%d." % i
+                fd = L.DykSeFcDesc()
+                plan._keep.append(fd)
+                fd.w1, fd.b1 = store.p_ptr(pre + "fc1.weight"), store.p_ptr(pre + "fc1.bias")
+                fd.w2, fd.b2 = store.p_ptr(pre + "fc2.weight"), store.p_ptr(pre + "fc2.bias")
+                fd.dw1, fd.db1 = store.g_ptr(pre + "fc1.weight"), store.g_ptr(pre + "fc1.bias")
+                fd.dw2, fd.db2 = store.g_ptr(pre + "fc2.weight"), store.g_ptr(pre + "fc2.bias")
+                fd.B, fd.C, fd.Cs = B, C, Cs
+                later(lambda fd=fd, rec=rec, dscale=dscale, dpooled=dpooled: (
+                    setattr(fd, "pooled", ws.ptr(rec["pooled"])), setattr(fd, "dscale", ws.ptr(dscale)),
+                    setattr(fd, "dpooled", ws.ptr(dpooled))))
+                plan.bwd.append((L.OP_SE_FC_BWD, fd))
+                gx = gref(x_in)
+                sd = ew_desc(a=dz, out=gx, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W, alpha=1.0 / (x_in.H * x_in.W), flags=acc_flag(x_in))
+                later(lambda sd=sd, rec=rec, dpooled=dpooled: (setattr(sd, "p0", ws.ptr(rec["scale"])), setattr(sd, "p1", ws.ptr(dpooled))))
+                plan.bwd.append((L.OP_SE_SCALE, sd))
+            elif t == "maxpool":
+                z = rec["z"]
+                if z.tid not in ginit:
+                    continue
+                dz = gref(z)
+                x_in = rec["x"]
+                gx = gref(x_in)
+                pd = ew_desc(a=dz, out=gx, Bn=B, Hn=x_in.H, Wn=x_in.W, k=rec["k"], flags=acc_flag(x_in))
+                later(lambda pd=pd, rec=rec: setattr(pd, "aux", ws.ptr(rec["amax"])))
+                plan.bwd.append((L.OP_MAXPOOL_BWD, pd))
+            elif t == "upsample":
+                z = rec["z"]
+                if z.tid not in ginit:
+                    continue
+                dz = gref(z)
+                x_in = rec["x"]
+                gx = gref(x_in)
+                plan.bwd.append((L.OP_UPSAMPLE_BWD, ew_desc(a=dz, out=gx, C=x_in.C, Bn=B, Hn=x_in.H, Wn=x_in.W, flags=acc_flag(x_in))))
+        # zero the fp64 reduction scratch before anything accumulates into it
+        if red_offs:
+            lo = min(o for o, n in red_offs)
+            hi = max(o + n for o, n in red_offs)
+            ms = misc()
+            ms.n, ms.i[0] = hi - lo, 0
+            later(lambda ms=ms, lo=lo: ms.p.__setitem__(0, ws.ptr(lo)))
+            plan.bwd.insert(0, (L.OP_MEMSET, ms))
+
+    # ---------------------------------------------------------------- materialise
+    for a in plan.arenas.values():
+        a.materialize(device)
+    for fn in pending:
+        fn()
+    plan.finalize()
+    plan.info = info
+    plan.outs = outs
+    plan.shape = (B, H, W)
+    plan.dtype = dtype
+    plan.training = training
+    return plan

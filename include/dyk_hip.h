@@ -125,6 +125,7 @@ typedef struct DykWgradDesc {
     int8_t twt[DYK_MAX_TAPS];
     int8_t _pad;
     int32_t splits;                 /* K splits; <= 0 selects automatically */
+    int32_t lddw;                   /* row stride of dw in floats; <= 0 means Cin */
 } DykWgradDesc;
 
 int dyk_conv_wgrad(const DykWgradDesc* desc, void* stream);
@@ -148,6 +149,7 @@ typedef struct DykEwDesc {
     const float* p2;
     const float* p3;
     double* red;
+    void* aux;                      /* op-specific extra pointer (max-pool argmax map, SE pooled vector) */
     int32_t dtype;
     int32_t npix, C;
     int32_t lda, ldb, ldo;
@@ -270,6 +272,96 @@ int dyk_nchw_to_nhwc(const float* in, void* out, int32_t B, int32_t C, int32_t H
                      int32_t Cpad, int32_t ldo, float mul, int32_t dtype, void* stream);
 int dyk_nhwc_to_nchw(const void* in, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
                      int32_t ldi, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Parameter staging.  Master parameters and gradients are fp32, conv weights stored
+ * tap-major [kh*kw][Cout][Cin] (DESIGN.md "parameter store").
+ *   dyk_cast_f32       : dst[i] = (dtype) src[i]                      (whole flat buffer, one launch)
+ *   dyk_cast_pad_rows  : dst[r][c] = src[r][c] (c < C), 0 (C <= c < Cpad)   (stem weights, K padded)
+ *   dyk_transpose_taps : for each entry e of a device table: dst_e[t][ci][co] = src_e[t][co][ci]
+ *                        (weights for the data-gradient GEMM), one launch for all layers.
+ * ---------------------------------------------------------------------------------- */
+typedef struct DykTransposeEntry {
+    int64_t src_off;      /* element offset into src (fp32) */
+    int64_t dst_off;      /* element offset into dst (dtype) */
+    int32_t taps, rows, cols;   /* src is [taps][rows][cols] */
+    int32_t tile_begin;   /* first 32x32 tile index of this entry (exclusive prefix sum) */
+} DykTransposeEntry;
+int dyk_cast_f32(const float* src, void* dst, int64_t n, int32_t dtype, void* stream);
+int dyk_cast_pad_rows(const float* src, void* dst, int32_t R, int32_t C, int32_t Cpad, int32_t dtype, void* stream);
+int dyk_transpose_taps(const float* src, void* dst, const DykTransposeEntry* table_dev, int32_t n_entries,
+                       int32_t total_tiles, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Command lists.  A compiled plan (one per cfg x batch shape x dtype x mode) is a flat array of
+ * commands whose descriptors already hold resolved device pointers; dyk_run_commands enqueues
+ * them in order on `stream` from native code (no per-kernel Python / ctypes overhead).
+ * desc points at the struct named next to each op code; DykMiscDesc carries the arguments of the
+ * entry points that take scalars (slot assignment listed per op).
+ * ---------------------------------------------------------------------------------- */
+typedef struct DykMiscDesc {
+    void* p[6];
+    int64_t n;
+    int32_t i[12];
+    float f[4];
+} DykMiscDesc;
+
+enum {
+    DYK_OP_CONV = 1,            /* DykConvDesc        -> dyk_conv_igemm */
+    DYK_OP_WGRAD = 2,           /* DykWgradDesc       -> dyk_conv_wgrad */
+    DYK_OP_BN_FINALIZE = 3,     /* DykBnFinalizeDesc  -> dyk_bn_finalize */
+    DYK_OP_BN_ACT_FWD = 4,      /* DykEwDesc */
+    DYK_OP_BN_BWD_REDUCE = 5,   /* DykEwDesc */
+    DYK_OP_BN_BWD_APPLY = 6,    /* DykEwDesc */
+    DYK_OP_AXPBY = 7,           /* DykEwDesc */
+    DYK_OP_DOT = 8,             /* DykEwDesc */
+    DYK_OP_UPSAMPLE_FWD = 9,    /* DykEwDesc */
+    DYK_OP_UPSAMPLE_BWD = 10,   /* DykEwDesc */
+    DYK_OP_MAXPOOL_FWD = 11,    /* DykEwDesc, aux = argmax */
+    DYK_OP_MAXPOOL_BWD = 12,    /* DykEwDesc, aux = argmax */
+    DYK_OP_SE_POOL = 13,        /* DykEwDesc, aux = pooled */
+    DYK_OP_SE_FC_FWD = 14,      /* DykSeFcDesc */
+    DYK_OP_SE_FC_BWD = 15,      /* DykSeFcDesc */
+    DYK_OP_SE_SCALE = 16,       /* DykEwDesc */
+    DYK_OP_BN_BWD_PARAMS = 17,  /* Misc: p0=red p1=dgamma p2=dbeta i0=C */
+    DYK_OP_BN_FOLD = 18,        /* Misc: p0=gamma p1=beta p2=rmean p3=rvar p4=scale p5=shift i0=C f0=eps */
+    DYK_OP_WFUSE_WEIGHTS = 19,  /* Misc: p0=w p1=weff i0=n */
+    DYK_OP_WFUSE_BWD_PARAMS = 20, /* Misc: p0=w p1=red p2=dw i0=n */
+    DYK_OP_HEAD_PERMUTE_FWD = 21, /* Misc: p0=y p1=p i0=B i1=ny i2=nx i3=na i4=no i5=ld */
+    DYK_OP_HEAD_PERMUTE_BWD = 22, /* Misc: p0=dp p1=dy p2=dbias i0..i5 as fwd, i6=dtype */
+    DYK_OP_PATCH_GATHER = 23,   /* Misc: p0=in p1=out i0=B i1=Cin i2=H i3=W i4=k i5=stride i6=pad i7=ld i8=dtype f0=mul */
+    DYK_OP_MEMSET = 24,         /* Misc: p0=ptr n=bytes i0=value */
+    DYK_OP_YOLO_DECODE = 25,    /* DykDecodeDesc */
+    DYK_OP_DW_CONV = 26,        /* reserved: depthwise conv */
+    DYK_OP_COUNT_
+};
+
+typedef struct DykCommand {
+    int32_t op;
+    int32_t _pad;
+    const void* desc;
+} DykCommand;
+
+/* Enqueue cmds[0..n) in order.  Stops at the first failure and returns its code; *failed_index
+ * (may be NULL) receives the index of the failing command. */
+int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream, int32_t* failed_index);
+
+/* ------------------------------------------------------------------------------------
+ * YOLOLayer inference decode (models.py:234-258): p [B,na,ny,nx,no] fp32 raw logits ->
+ * io rows [row_offset + (a*ny + y)*nx + x] of a [B, rows_total, no] fp32 buffer:
+ *   v3: xy = (sigmoid(t) + grid)*stride, wh = exp(t)*anchor_vec*stride, rest = sigmoid
+ *   v4: s = sigmoid(t); xy = (s*2 - 0.5 + grid)*stride, wh = (s*2)^2*anchor_vec*stride, rest = s
+ * ---------------------------------------------------------------------------------- */
+typedef struct DykDecodeDesc {
+    const float* p;
+    float* io;
+    int32_t B, na, ny, nx, no;
+    int32_t rows_total, row_offset;
+    int32_t v4;
+    float stride;
+    float anchor_vec[2 * 8];        /* (w, h) per anchor, already divided by stride (models.py:182) */
+} DykDecodeDesc;
+int dyk_yolo_decode(const DykDecodeDesc* desc, void* stream);
 
 #ifdef __cplusplus
 }
