@@ -211,3 +211,42 @@ def conv2d_wgrad(x, dy, k, stride, pad, *, dw=None, splits=0, Cin=None, Cout=Non
     d.lddw = 0
     check(load().dyk_conv_wgrad(ctypes.byref(d), _stream()), "dyk_conv_wgrad")
     return dw
+
+
+# --------------------------------------------------------------------------- elementwise family
+def ew_desc(a=None, b=None, out=None, *, C=None, npix=None, act="linear", flags=0, alpha=1.0, beta=1.0,
+            p0=None, p1=None, p2=None, p3=None, red=None, aux=None, B=0, H=0, W=0, k=0):
+    """Build a DykEwDesc from channels-last tensors ([B,H,W,C] views)."""
+    d = _l.DykEwDesc()
+    ref = a if a is not None else out
+    d.dtype = dtype_code(ref.dtype)
+    d.C = C if C is not None else ref.shape[3]
+    d.npix = npix if npix is not None else ref.shape[0] * ref.shape[1] * ref.shape[2]
+    d.a, d.b, d.out = _ptr(a), _ptr(b), _ptr(out)
+    d.lda = nhwc_ld(a) if a is not None else 0
+    d.ldb = nhwc_ld(b) if b is not None else 0
+    d.ldo = nhwc_ld(out) if out is not None else 0
+    d.p0, d.p1, d.p2, d.p3, d.red, d.aux = _ptr(p0), _ptr(p1), _ptr(p2), _ptr(p3), _ptr(red), _ptr(aux)
+    d.act = ACT_CODES[act] if isinstance(act, str) else int(act)
+    d.flags, d.alpha, d.beta = flags, alpha, beta
+    d.B, d.H, d.W, d.k = B, H, W, k
+    return d
+
+
+def call(name, desc, *extra):
+    fn = getattr(load(), name)
+    check(fn(ctypes.byref(desc), *[_ptr(e) if isinstance(e, torch.Tensor) else e for e in extra], _stream()), name)
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
+    C = gamma.numel()
+    dev = stats.device
+    scale, shift, mean, rstd = (torch.empty(C, device=dev) for _ in range(4))
+    d = _l.DykBnFinalizeDesc()
+    d.stats, d.gamma, d.beta = stats.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    d.running_mean = running_mean.data_ptr() if running_mean is not None else None
+    d.running_var = running_var.data_ptr() if running_var is not None else None
+    d.scale, d.shift, d.save_mean, d.save_rstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    d.C, d.count, d.momentum, d.eps = C, count, momentum, eps
+    call("dyk_bn_finalize", d)
+    return scale, shift, mean, rstd

@@ -13,6 +13,7 @@ This replaces the reference's eager interpreter loop (models.py:291-305: one Pyt
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -523,12 +524,16 @@ def compile_plan(model, store, B, H, W, dtype, training, device):
                     pm.i[0] = cout
                     later(lambda pm=pm, red=red: pm.p.__setitem__(0, ws.ptr(red)))
                     plan.bwd.append((L.OP_BN_BWD_PARAMS, pm))
-                    ap = ew_desc(a=dz, b=rec["y_raw"], out=dz, act=rec["act"])      # in place: dz -> dy_raw
+                    dyr = dz
+                    if os.environ.get("DYK_DEBUG_PLAN"):      # keep dz intact for per-layer gradient dumps
+                        dyr = TRef("grad", grad_arena.alloc(dz.npix * dz.ld * es), dz.B, dz.H, dz.W, dz.C, dz.ld, es)
+                    ap = ew_desc(a=dz, b=rec["y_raw"], out=dyr, act=rec["act"])     # in place: dz -> dy_raw
                     later(lambda ap=ap, vecs=vecs, red=red, cout=cout: (
                         setattr(ap, "p0", ws.ptr(vecs)), setattr(ap, "p1", ws.ptr(vecs + 4 * cout)),
                         setattr(ap, "p2", ws.ptr(vecs + 8 * cout)), setattr(ap, "p3", ws.ptr(vecs + 12 * cout)),
                         setattr(ap, "red", ws.ptr(red))))
                     plan.bwd.append((L.OP_BN_BWD_APPLY, ap))
+                    dz = dyr
                 emit_conv_backward(rec, dz, i)
             elif t == "route":
                 out = rec["out"]
@@ -629,6 +634,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device):
         fn()
     plan.finalize()
     plan.info = info
+    plan.grads = grads if training else {}
     plan.outs = outs
     plan.shape = (B, H, W)
     plan.dtype = dtype

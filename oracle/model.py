@@ -184,6 +184,7 @@ class OracleNet:
         di = self.second_index is not None and y is not None
         yolo_out, out = [], []
         every = []
+        self.raw = {}
         for i, L in enumerate(self.layers):
             t = L["kind"]
             pre = "module_list.%d." % i
@@ -192,6 +193,8 @@ class OracleNet:
                     x = y                                           # models.py:299-301 stream switch
                 x = F.conv2d(x, sd[pre + "Conv2d.weight"], sd.get(pre + "Conv2d.bias"), L["stride"], L["pad"], 1,
                              L["groups"])
+                if keep_all:
+                    self.raw[i] = x
                 if L["bn"]:
                     x = self._bn(sd, pre + "BatchNorm2d.", x, training)
                 x = _act(L["act"], x)

@@ -2,6 +2,7 @@
 usage: python tools/gpu_debug_model.py <cfg-name> [fp32|bf16] [train|eval] [bwd]"""
 import os
 import sys
+os.environ["DYK_DEBUG_PLAN"] = "1"
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "double-yolo-kaist_amd"), os.path.join(ROOT, "tests")]
@@ -46,6 +47,10 @@ def main():
             if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
                 v.requires_grad_(True)
     (ref, every) = net.forward(sd, x, y, training=training, keep_all=True)
+    if training and bwd:
+        for t in every:
+            if t.requires_grad and not t.is_leaf:
+                t.retain_grad()
     out = model(x.cuda(), y.cuda())
     torch.cuda.synchronize()
     plan = list(model.engine.plans.values())[0]
@@ -61,7 +66,7 @@ def main():
         err = (got - r).abs().max().item()
         rel = err / max(r.abs().max().item(), 1e-6)
         flag = " <<<<" if rel > (1e-3 if dtype == "fp32" else 8e-2) else ""
-        if flag or i % 20 == 0:
+        if flag or i % 20 == 0 or 236 <= i <= 262:
             print("layer %3d %-12s max|ref| %.3e err %.3e rel %.2e%s" % (i, plan.info[i]["kind"], r.abs().max().item(), err, rel, flag))
         worst = max(worst, rel)
     print("worst layer rel err %.3e" % worst)
@@ -78,6 +83,33 @@ def main():
         loss.backward()
         torch.cuda.synchronize()
         print("loss ref %.6f got %.6f" % (loss_ref.item(), loss.item()))
+        import ctypes
+        for i in (279, 278, 268, 257, 250):
+            rec = plan.info[i]
+            if rec["kind"] != "conv" or not rec["bn"]:
+                continue
+            yr = tref_to_nchw(plan, rec["y_raw"])
+            ref_raw = net.raw[i].detach()
+            cout = rec["cout"]
+            ws = plan.arenas["ws"].tensor
+            v = ws[rec["vecs"]:rec["vecs"] + 16 * cout].view(torch.float32).cpu().view(4, cout)
+            mean_ref = ref_raw.mean((0, 2, 3))
+            var_ref = ref_raw.var((0, 2, 3), unbiased=False)
+            print("layer %d y_raw err %.3e (max %.3e) mean err %.3e rstd err %.3e (max rstd %.3e)" % (
+                i, (yr - ref_raw).abs().max().item(), ref_raw.abs().max().item(), (v[2] - mean_ref).abs().max().item(),
+                (v[3] - 1 / torch.sqrt(var_ref + 1e-5)).abs().max().item(), v[3].abs().max().item()))
+        for i in range(len(plan.outs) - 1, -1, -1):
+            t = plan.outs[i]
+            kind = plan.info[i]["kind"]
+            if t is None or kind in ("yolo",) or plan.info[i].get("alias") or t.tid not in plan.grads:
+                continue
+            gr = every[i].grad
+            if gr is None:
+                continue
+            got = tref_to_nchw(plan, plan.grads[t.tid])
+            err = (got - gr).abs().max().item()
+            rel = err / max(gr.abs().max().item(), 1e-12)
+            print("dL/d(out %3d %-9s) max|ref| %.3e err %.3e rel %.2e%s" % (i, kind, gr.abs().max().item(), err, rel, " <<<<" if rel > 1e-2 else ""))
         bad = 0
         for k, p in model.named_parameters():
             gr = sd[k].grad
@@ -85,10 +117,11 @@ def main():
             err = (gg - gr).abs().max().item()
             rel = err / max(gr.abs().max().item(), 1e-8)
             tol = 2e-3 if dtype == "fp32" else 1.5e-1
+            li = int(k.split(".")[1])
             if rel > tol:
                 bad += 1
-                if bad < 40:
-                    print("GRAD %-45s max|ref| %.3e err %.3e rel %.2e" % (k, gr.abs().max().item(), err, rel))
+            if li >= 268 or li < 3:
+                print("GRAD %-45s max|ref| %.3e err %.3e rel %.2e %s" % (k, gr.abs().max().item(), err, rel, "BAD" if rel > tol else "ok"))
         print("params with grad mismatch: %d of %d" % (bad, len(list(model.parameters()))))
         # running stats
         sdm = model.state_dict()
