@@ -1,0 +1,156 @@
+"""Host side of the loss / target-assignment / NMS kernels (dyk_yolo_loss, dyk_build_targets, dyk_nms)."""
+import ctypes
+
+import torch
+
+from . import lib as L
+from .lib import check, load
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _model_of(model):
+    # build_targets tolerates a DataParallel / DDP wrapper (reference utils.py:315,321)
+    return model.module if hasattr(model, "module") and hasattr(model.module, "module_list") else model
+
+
+def _targets_desc(shapes, targets, model):
+    """shapes: list of (B, na, ny, nx, no).  Returns (desc, keepalive dict)."""
+    m = _model_of(model)
+    dev = targets.device
+    nt = int(targets.shape[0])
+    nheads = len(shapes)
+    na = shapes[0][1]
+    cap = max(na * nt, 1)
+    t = L.DykTargetsDesc()
+    tg = targets.detach().to(torch.float32).contiguous()
+    keep = {"targets": tg}
+    t.targets = tg.data_ptr() if nt else None
+    t.nt, t.nheads, t.na = nt, nheads, na
+    for h, (j, shp) in enumerate(zip(m.yolo_layers, shapes)):
+        t.ny[h], t.nx[h] = shp[2], shp[3]
+        av = m.module_list[j].anchor_vec.detach().float().cpu().reshape(-1).tolist()
+        for q, v in enumerate(av):
+            t.anchor_vec[h][q] = v
+    t.iou_t = float(m.hyp["iou_t"])
+    keep["counts"] = torch.zeros(nheads, dtype=torch.int32, device=dev)
+    keep["indices"] = torch.zeros((nheads, 4, cap), dtype=torch.int64, device=dev)
+    keep["tbox"] = torch.zeros((nheads, cap, 4), dtype=torch.float32, device=dev)
+    keep["anch"] = torch.zeros((nheads, cap, 2), dtype=torch.float32, device=dev)
+    keep["tcls"] = torch.zeros((nheads, cap), dtype=torch.int64, device=dev)
+    t.counts, t.indices, t.tbox = keep["counts"].data_ptr(), keep["indices"].data_ptr(), keep["tbox"].data_ptr()
+    t.anch, t.tcls = keep["anch"].data_ptr(), keep["tcls"].data_ptr()
+    return t, keep
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise L.DykError("%s runs on the MI355X HIP path only (got a %s tensor); there is no CPU fallback" % (what, t.device.type))
+
+
+def build_targets(p, targets, model):
+    """reference build_utils/utils.py:296-384 -> (tcls, tbox, indices, anch), lists over heads."""
+    _require_cuda(p[0], "build_targets")
+    t, keep = _targets_desc([tuple(pi.shape) for pi in p], targets.to(p[0].device), model)
+    check(load().dyk_build_targets(ctypes.byref(t), _stream()), "dyk_build_targets")
+    counts = keep["counts"].cpu().tolist()
+    tcls, tbox, indices, anch = [], [], [], []
+    nc = _model_of(model).nc
+    for h, n in enumerate(counts):
+        ib = keep["indices"][h, :, :n]
+        indices.append((ib[0], ib[1], ib[2], ib[3]))
+        tbox.append(keep["tbox"][h, :n])
+        anch.append(keep["anch"][h, :n])
+        c = keep["tcls"][h, :n]
+        tcls.append(c)
+        if n:
+            assert int(c.max()) < nc, ("Model accepts %g classes labeled from 0-%g, however you labelled a class %g. "
+                                       % (nc, nc - 1, int(c.max())))
+    return tcls, tbox, indices, anch
+
+
+class _LossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, targets, *p):
+        m = _model_of(model)
+        h = m.hyp
+        if h.get("fl_gamma", 0.0) > 0:
+            raise NotImplementedError("focal loss (fl_gamma > 0) is off in both reference hyp files and not built")
+        dev = p[0].device
+        ps = [pi.detach().float().contiguous() for pi in p]
+        t, keep = _targets_desc([tuple(pi.shape) for pi in ps], targets.to(dev), model)
+        d = L.DykLossDesc()
+        dps, tobjs = [], []
+        for i, pi in enumerate(ps):
+            dp = torch.empty_like(pi)
+            tobj = torch.empty(pi.shape[:4], dtype=torch.float32, device=dev)
+            d.p[i], d.dp[i], d.tobj[i] = pi.data_ptr(), dp.data_ptr(), tobj.data_ptr()
+            dps.append(dp)
+            tobjs.append(tobj)
+        d.nheads, d.B, d.no = len(ps), ps[0].shape[0], ps[0].shape[4]
+        d.nc = d.no - 5
+        if m.nc != d.nc:
+            raise ValueError("model.nc = %d but the heads predict %d classes" % (m.nc, d.nc))
+        d.v4 = 1 if "yolov4" in m.cfg else 0
+        d.ciou = 1 if "ciou" in h else 0
+        d.hyp_box, d.hyp_obj, d.hyp_cls = float(h["box"]), float(h["obj"]), float(h["cls"])
+        d.cls_pw, d.obj_pw, d.gr = float(h["cls_pw"]), float(h["obj_pw"]), float(m.gr)
+        acc = torch.empty(12, dtype=torch.float64, device=dev)
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        d.acc, d.out, d.flag = acc.data_ptr(), out.data_ptr(), flag.data_ptr()
+        check(load().dyk_yolo_loss(ctypes.byref(d), ctypes.byref(t), _stream()), "dyk_yolo_loss")
+        ctx.dps = dps
+        ctx.no = d.no
+        m._dyk_loss_flag = flag          # bit 0: a target fell outside the grid (reference: IndexError)
+        m._dyk_loss_keep = (keep, tobjs, acc, ps)
+        return out[0:1].clone(), out[1:2].clone(), out[2:3].clone()
+
+    @staticmethod
+    def backward(ctx, gbox, gobj, gcls):
+        dev = ctx.dps[0].device
+        g = torch.cat([x.reshape(1).float() if x is not None else torch.zeros(1, device=dev) for x in (gbox, gobj, gcls)])
+        lib = load()
+        for dp in ctx.dps:
+            check(lib.dyk_loss_scale_grads(dp.data_ptr(), dp.numel(), ctx.no, g.data_ptr(), _stream()), "dyk_loss_scale_grads")
+        return (None, None) + tuple(ctx.dps)
+
+
+def compute_loss(p, targets, model):
+    """reference build_utils/utils.py:209-293 -> {'box_loss','obj_loss','class_loss'}, each shape [1]."""
+    _require_cuda(p[0], "compute_loss")
+    lbox, lobj, lcls = _LossFunction.apply(model, targets, *p)
+    return {"box_loss": lbox, "obj_loss": lobj, "class_loss": lcls}
+
+
+def non_max_suppression(prediction, conf_thres=0.1, iou_thres=0.6, multi_label=True, classes=None, agnostic=False,
+                        max_num=100, return_rows=False):
+    """reference build_utils/utils.py:387-464 -> list (per image) of [n,6] tensors or None."""
+    _require_cuda(prediction, "non_max_suppression")
+    pred = prediction.detach().float().contiguous()
+    B, N, no = pred.shape
+    nc = no - 5
+    multi = bool(multi_label) and nc > 1
+    lib = load()
+    d = L.DykNmsDesc()
+    per = int(lib.dyk_nms_workspace_bytes(N, no, 1 if multi else 0))
+    ws = torch.empty(B * per, dtype=torch.uint8, device=pred.device)
+    out = torch.zeros((B, max_num, 6), dtype=torch.float32, device=pred.device)
+    rows = torch.zeros((B, max_num), dtype=torch.int32, device=pred.device)
+    counts = torch.zeros(B, dtype=torch.int32, device=pred.device)
+    d.pred, d.out, d.out_rows, d.counts, d.ws, d.ws_per_image = pred.data_ptr(), out.data_ptr(), rows.data_ptr(), counts.data_ptr(), ws.data_ptr(), per
+    d.B, d.N, d.no = B, N, no
+    d.conf_thres, d.iou_thres = float(conf_thres), float(iou_thres)
+    d.multi_label, d.agnostic, d.max_num = 1 if multi else 0, 1 if agnostic else 0, int(max_num)
+    cl = list(classes) if classes else []
+    d.n_classes = len(cl)
+    for i, c in enumerate(cl[:16]):
+        d.classes[i] = int(c)
+    check(lib.dyk_nms(ctypes.byref(d), _stream()), "dyk_nms")
+    cnt = counts.cpu().tolist()                    # the one host sync of the eval step
+    res = [out[b, :n] if n else None for b, n in enumerate(cnt)]
+    if return_rows:
+        return res, [rows[b, :n].long() if n else None for b, n in enumerate(cnt)]
+    return res

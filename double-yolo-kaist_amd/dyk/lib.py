@@ -103,6 +103,25 @@ class DykDecodeDesc(ctypes.Structure):
                 ("anchor_vec", _f32 * 16)]
 
 
+class DykTargetsDesc(ctypes.Structure):
+    _fields_ = [("targets", _vp), ("nt", _i32), ("nheads", _i32), ("na", _i32), ("ny", _i32 * 3), ("nx", _i32 * 3),
+                ("anchor_vec", (_f32 * 16) * 3), ("iou_t", _f32), ("counts", _vp), ("indices", _vp), ("tbox", _vp),
+                ("anch", _vp), ("tcls", _vp)]
+
+
+class DykLossDesc(ctypes.Structure):
+    _fields_ = [("p", _vp * 3), ("dp", _vp * 3), ("tobj", _vp * 3), ("nheads", _i32), ("B", _i32), ("no", _i32),
+                ("nc", _i32), ("v4", _i32), ("ciou", _i32), ("hyp_box", _f32), ("hyp_obj", _f32), ("hyp_cls", _f32),
+                ("cls_pw", _f32), ("obj_pw", _f32), ("gr", _f32), ("acc", _vp), ("out", _vp), ("flag", _vp)]
+
+
+class DykNmsDesc(ctypes.Structure):
+    _fields_ = [("pred", _vp), ("out", _vp), ("out_rows", _vp), ("counts", _vp), ("ws", _vp), ("ws_per_image", _i64),
+                ("B", _i32), ("N", _i32), ("no", _i32), ("conf_thres", _f32), ("iou_thres", _f32),
+                ("multi_label", _i32), ("agnostic", _i32), ("max_num", _i32), ("n_classes", _i32),
+                ("classes", _i32 * 16)]
+
+
 _lib = None
 _P = ctypes.POINTER
 
@@ -141,6 +160,11 @@ SIGNATURES = {
     "dyk_transpose_taps": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "dyk_run_commands": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
     "dyk_yolo_decode": (_i32, [_P(DykDecodeDesc), _vp]),
+    "dyk_build_targets": (_i32, [_P(DykTargetsDesc), _vp]),
+    "dyk_yolo_loss": (_i32, [_P(DykLossDesc), _P(DykTargetsDesc), _vp]),
+    "dyk_nms_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "dyk_nms": (_i32, [_P(DykNmsDesc), _vp]),
+    "dyk_loss_scale_grads": (_i32, [_vp, _i64, _i32, _vp, _vp]),
 }
 
 

@@ -363,6 +363,78 @@ typedef struct DykDecodeDesc {
 } DykDecodeDesc;
 int dyk_yolo_decode(const DykDecodeDesc* desc, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Target assignment and loss (build_utils/utils.py:209-384).
+ * dyk_build_targets: for every head h and every (anchor a, target t) pair in anchor-major order,
+ *   keep the pair iff wh_iou(anchor_vec[h][a], (w,h)*grid) > iou_t and emit
+ *   indices[h][0..3][m] = (image, anchor, gj, gi) (int64, truncation, no clamping), tbox[h][m] =
+ *   (gx-gi, gy-gj, gw, gh), anch[h][m], tcls[h][m]; counts[h] = number of matches.  Arrays are
+ *   sized for cap = na*nt matches per head: indices [nheads][4][cap], tbox [nheads][cap][4],
+ *   anch [nheads][cap][2], tcls [nheads][cap].  targets is [nt][6] = (image, class, xc, yc, w, h).
+ * dyk_yolo_loss: runs the assignment, then the CIoU/GIoU box loss, the objectness BCE over all
+ *   cells (targets scattered with last-match-wins) and the class BCE (nc > 1), writes
+ *   out[0..2] = (box, obj, cls) * hyp gains and the gradient of each term w.r.t. the logits into
+ *   dp[h] (box -> channels 0..3, obj -> 4, cls -> 5..): the three terms touch disjoint channels, so
+ *   dyk_loss_scale_grads can apply the three upstream gradients afterwards.
+ *   *flag gets bit 0 set if a target indexed outside the grid (the reference raises IndexError).
+ * ---------------------------------------------------------------------------------- */
+typedef struct DykTargetsDesc {
+    const float* targets;
+    int32_t nt, nheads, na;
+    int32_t ny[3], nx[3];
+    float anchor_vec[3][16];
+    float iou_t;
+    int32_t* counts;       /* [nheads] */
+    int64_t* indices;
+    float* tbox;
+    float* anch;
+    int64_t* tcls;
+} DykTargetsDesc;
+
+typedef struct DykLossDesc {
+    const float* p[3];     /* [B][na][ny][nx][no] raw logits */
+    float* dp[3];          /* same shape, out */
+    float* tobj[3];        /* [B][na][ny][nx] scratch */
+    int32_t nheads, B, no, nc;
+    int32_t v4;            /* box parameterisation: 'yolov4' in cfg (utils.py:252) */
+    int32_t ciou;          /* 'ciou' in hyp (utils.py:264), else GIoU */
+    float hyp_box, hyp_obj, hyp_cls, cls_pw, obj_pw, gr;
+    double* acc;           /* [12] scratch */
+    float* out;            /* [3] */
+    int32_t* flag;
+} DykLossDesc;
+
+int dyk_build_targets(const DykTargetsDesc* desc, void* stream);
+int dyk_yolo_loss(const DykLossDesc* desc, const DykTargetsDesc* targets, void* stream);
+int dyk_loss_scale_grads(float* dp, int64_t n, int32_t no, const float* g3, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * non_max_suppression (build_utils/utils.py:387-464) incl. torchvision.ops.nms (:448), one
+ * workgroup per image.  pred [B][N][no] decoded boxes (cx,cy,w,h,obj,cls...).  Per image b:
+ *   counts[b] = k <= max_num, out[b][0..k) = (x1,y1,x2,y2,conf,cls) in descending-score order,
+ *   out_rows[b][0..k) = row of pred each detection came from.
+ * Semantics: strict `>` thresholds, 2 < w,h < 4096, conf = obj*cls, best class unless
+ * multi_label (and nc > 1), optional class filter, per-class offset 4096 unless agnostic, greedy
+ * suppression of IoU > iou_thres in stable descending score order, first max_num kept.  The
+ * reference's 10 s wall-clock bail-out (:461-462) is deliberately not reproduced.
+ * ws: B * ws_per_image bytes, ws_per_image >= dyk_nms_workspace_bytes(N, no, multi_label).
+ * ---------------------------------------------------------------------------------- */
+typedef struct DykNmsDesc {
+    const float* pred;
+    float* out;            /* [B][max_num][6] */
+    int32_t* out_rows;     /* [B][max_num] */
+    int32_t* counts;       /* [B] */
+    void* ws;
+    int64_t ws_per_image;
+    int32_t B, N, no;
+    float conf_thres, iou_thres;
+    int32_t multi_label, agnostic, max_num;
+    int32_t n_classes;     /* 0 = no class filter */
+    int32_t classes[16];
+} DykNmsDesc;
+int64_t dyk_nms_workspace_bytes(int32_t N, int32_t no, int32_t multi_label);
+int dyk_nms(const DykNmsDesc* desc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
