@@ -1,0 +1,229 @@
+"""Benchmark of the hot path named by BASELINE.json: paired RGB+LWIR images/s of a full train step
+(forward + loss + backward + gradient all-reduce + optimizer) of Double-YOLOv4-Fshare-Global-CSE3
+(kaist_dyolov4_fshare_global_concat_se3.cfg, 640x512, batch 16 per GPU, bf16 MFMA / fp32 accumulate).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job pairs/s, plus
+  "roofline"     for the dominant kernel (implicit-GEMM MFMA conv), measured live with HIP events
+                 around every command of one extra profiling pass on the launch stream, and
+  "cpu_baseline" the oracle (CPU restatement of the reference path) timed on the host cores on a
+                 bounded sample (rank 0, N=1 only).
+Synthetic data per SURVEY.md §8(d): uint8 uniform paired images, 4 boxes per image, seeds 1234+rank.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "double-yolo-kaist_amd")
+sys.path[:0] = [ROOT, PKG]
+
+import torch  # noqa: E402
+
+CFG = "kaist_dyolov4_fshare_global_concat_se3"
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+
+
+def synth_batch(B, H, W, rank, device):
+    g = torch.Generator().manual_seed(1234 + rank)
+    v = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=g)
+    l = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=g)
+    nb = 4
+    t = torch.zeros(B * nb, 6)
+    t[:, 0] = torch.arange(B).repeat_interleave(nb).float()
+    t[:, 2:4] = torch.rand(B * nb, 2, generator=g) * 0.8 + 0.1
+    t[:, 4] = (torch.rand(B * nb, generator=g) * 60 + 16) / 640
+    t[:, 5] = (torch.rand(B * nb, generator=g) * 120 + 32) / 512
+    return v.to(device), l.to(device), t.to(device)
+
+
+def load_hyp(img_size=512, nc=1):
+    with open(os.path.join(PKG, "config", "hyp.scratch.4.json")) as f:
+        hyp = json.load(f)
+    hyp["cls"] *= nc / 80          # reference train.py:70-71
+    hyp["obj"] *= img_size / 320
+    return hyp
+
+
+def conv_flops(plan):
+    """algorithmic conv flops of one forward pass of the plan: 2*B*Ho*Wo*Cout*Cin*k*k per [convolutional]"""
+    total = 0.0
+    for rec in plan.info:
+        if rec.get("kind") != "conv":
+            continue
+        z = rec["z"]
+        cin = 3 if rec["stem"] else rec["x"].C
+        total += 2.0 * z.B * z.H * z.W * rec["cout"] * cin * rec["k"] * rec["k"]
+    return total
+
+
+def profile_plan(plan, stream):
+    """per-op-kind kernel time (ms) of one forward and one backward pass, HIP events on `stream`"""
+    from dyk import lib as L
+    res = {}
+    for which in ("fwd", "bwd"):
+        cmds = plan.fwd if which == "fwd" else plan.bwd
+        arr = plan._cfwd if which == "fwd" else plan._cbwd
+        ms = (ctypes.c_float * len(cmds))()
+        L.check(L.load().dyk_run_commands_timed(arr, len(cmds), ctypes.c_void_p(stream), ms), "dyk_run_commands_timed")
+        agg = {}
+        for (op, _), t in zip(cmds, ms):
+            a = agg.setdefault(op, [0, 0.0])
+            a[0] += 1
+            a[1] += float(t)
+        res[which] = agg
+    return res
+
+
+def cpu_baseline(cfg_name, steps=1):
+    """oracle (CPU restatement of the reference's train step: forward + loss + backward) on B=2, 512x640"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from build_utils.parse_config import sections_from_json
+    from oracle.model import OracleNet
+    from oracle import loss as oloss
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    net = OracleNet(sections_from_json(os.path.join(PKG, "config", "netdefs", cfg_name + ".json")), "config/%s.cfg" % cfg_name)
+    sd = net.synth_state(0)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    B = 2
+    v, l, t = synth_batch(B, 512, 640, 0, "cpu")
+    hyp = load_hyp()
+    av = net.anchor_vecs()
+    t0 = time.time()
+    for _ in range(steps):
+        p = net.forward(sd, v.float() / 255, l.float() / 255, training=True)
+        ld = oloss.compute_loss(p, t, av, hyp, 1, 1.0, net.v4)
+        (ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]).backward()
+    dt = time.time() - t0
+    return {"value": B * steps / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": "%d train step(s) (forward+loss+backward, fp32) of %s, batch %d, 512x640, oracle/ on host CPU, %.1f s"
+                      % (steps, cfg_name, B, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (pairs)")
+    ap.add_argument("--cfg", default=CFG)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    from build_utils.parse_config import materialize_cfg
+    from build_utils.utils import compute_loss
+    from dyk.ddp import GradAllReduce
+    from dyk.optim import FusedAdam
+    from models import YOLO
+
+    torch.manual_seed(0)
+    model = YOLO(materialize_cfg(args.cfg))
+    model.nc, model.hyp, model.gr = 1, load_hyp(), 1.0
+    model.dyk_dtype = args.dtype
+    model = model.to(device).train()
+    hyp = model.hyp
+    B, H, W = args.batch, 512, 640
+    v8, l8, targets = synth_batch(B, H, W, rank, device)
+    opt = FusedAdam(model, lr=hyp["lr0"], betas=(hyp["momentum"], 0.999), weight_decay=hyp["weight_decay"])
+    reducer = GradAllReduce(model, dist) if world > 1 else None
+    if reducer is not None:
+        opt.grad_scale = 1.0 / world
+
+    def step():
+        v = v8.float() / 255.0                       # kaist_train_eval_utils.py:54-55
+        l = l8.float() / 255.0
+        pred = model(v, l)
+        ld = compute_loss(pred, targets, model)
+        loss = ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]
+        loss.backward()
+        if reducer is not None:
+            reducer.all_reduce()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    final_loss = float(loss.item())
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        pairs = B * world * args.steps / dt
+        out = {"metric": "paired RGB+LWIR images/sec (train step)", "value": pairs, "unit": "pairs/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "%s.cfg train step (fwd+loss+bwd+Adam%s), 640x512 pairs, batch %d/GPU"
+                                      % (args.cfg, "+RCCL grad all-reduce" if world > 1 else "", B),
+                          "global_batch": B * world, "parallelism": "dp%d" % world},
+               "final_loss": final_loss}
+        if not args.no_roofline:
+            plan = model.engine.plans[(B, H, W, torch.bfloat16 if args.dtype == "bf16" else torch.float32, True)]
+            from dyk import lib as L
+            prof = profile_plan(plan, torch.cuda.current_stream().cuda_stream)
+            f1 = conv_flops(plan)
+            ig_ms = prof["fwd"].get(L.OP_CONV, [0, 0.0])[1] + prof["bwd"].get(L.OP_CONV, [0, 0.0])[1]
+            ig_n = prof["fwd"].get(L.OP_CONV, [0, 0.0])[0] + prof["bwd"].get(L.OP_CONV, [0, 0.0])[0]
+            wg_n, wg_ms = prof["bwd"].get(L.OP_WGRAD, [0, 0.0])
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+            ach = 2.0 * f1 / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0      # forward + data-gradient launches
+            tot_ms = sum(a[1] for w in prof.values() for a in w.values())
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1),
+                "flops_per_launch": 2.0 * f1 / max(ig_n, 1),
+                "detail": {
+                    "conv_fwd_flops_per_step": f1,
+                    "wgrad_tflops": (f1 / (wg_ms * 1e-3) / 1e12) if wg_ms > 0 else 0.0, "wgrad_ms": wg_ms, "wgrad_launches": wg_n,
+                    "igemm_ms": ig_ms, "all_kernels_ms": tot_ms,
+                    "step_mfma_frac": 3.0 * f1 / (ms * 1e-3) / 1e12 / peak,
+                    "per_op_ms": {w: {str(k): [a[0], round(a[1], 4)] for k, a in prof[w].items()} for w in prof}}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cfg)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

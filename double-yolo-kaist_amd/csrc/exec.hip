@@ -211,3 +211,24 @@ extern "C" int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream,
     }
     return DYK_OK;
 }
+
+extern "C" int dyk_run_commands_timed(const DykCommand* cmds, int32_t n, void* stream, float* ms_out) {
+    if (!cmds || n <= 0 || !ms_out) return DYK_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t* ev = new hipEvent_t[n + 1];
+    for (int i = 0; i <= n; ++i)
+        if (hipEventCreate(&ev[i]) != hipSuccess) { delete[] ev; return DYK_ERR_HIP; }
+    int rc = DYK_OK;
+    hipEventRecord(ev[0], s);
+    for (int k = 0; k < n && rc == DYK_OK; ++k) {
+        rc = dyk_run_commands(cmds + k, 1, stream, nullptr);
+        hipEventRecord(ev[k + 1], s);
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) rc = DYK_ERR_HIP;
+    if (rc == DYK_OK)
+        for (int k = 0; k < n; ++k)
+            if (hipEventElapsedTime(&ms_out[k], ev[k], ev[k + 1]) != hipSuccess) { rc = DYK_ERR_HIP; break; }
+    for (int i = 0; i <= n; ++i) hipEventDestroy(ev[i]);
+    delete[] ev;
+    return rc;
+}

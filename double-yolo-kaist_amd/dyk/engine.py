@@ -44,6 +44,7 @@ class Engine:
         self.model = model
         self.store = ParamStore(model)
         self.plans = {}
+        self.grad_sync = None           # set by dyk.ddp.GradAllReduce
 
     # ------------------------------------------------------------------ helpers
     def _prepare(self, x):
@@ -99,7 +100,14 @@ class Engine:
             keep.append(g)
             desc.p[0] = g.data_ptr()
         plan._dyn_keep_b = keep
-        plan.run("bwd", stream)
+        if self.grad_sync is None:
+            plan.run("bwd", stream)
+        else:
+            # data parallel: launch the backward in segments and hand every finished gradient bucket to
+            # the all-reduce while the remaining (earlier) layers are still being differentiated
+            for (c0, c1, lo, hi) in self.grad_sync.segments(plan):
+                plan.run("bwd", stream, c0, c1)
+                self.grad_sync.bucket_ready(lo, hi)
 
     # ------------------------------------------------------------------ public
     def forward(self, x, y=None):

@@ -115,6 +115,12 @@ class DykLossDesc(ctypes.Structure):
                 ("cls_pw", _f32), ("obj_pw", _f32), ("gr", _f32), ("acc", _vp), ("out", _vp), ("flag", _vp)]
 
 
+class DykOptimDesc(ctypes.Structure):
+    _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("wc", _vp), ("n", _i64), ("lr", _f32), ("beta1", _f32),
+                ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("grad_scale", _f32), ("step", _i32),
+                ("zero_grad", _i32)]
+
+
 class DykNmsDesc(ctypes.Structure):
     _fields_ = [("pred", _vp), ("out", _vp), ("out_rows", _vp), ("counts", _vp), ("ws", _vp), ("ws_per_image", _i64),
                 ("B", _i32), ("N", _i32), ("no", _i32), ("conf_thres", _f32), ("iou_thres", _f32),
@@ -164,6 +170,9 @@ SIGNATURES = {
     "dyk_yolo_loss": (_i32, [_P(DykLossDesc), _P(DykTargetsDesc), _vp]),
     "dyk_nms_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "dyk_nms": (_i32, [_P(DykNmsDesc), _vp]),
+    "dyk_adam_step": (_i32, [_P(DykOptimDesc), _vp]),
+    "dyk_sgd_step": (_i32, [_P(DykOptimDesc), _vp]),
+    "dyk_run_commands_timed": (_i32, [_P(DykCommand), _i32, _vp, _P(_f32)]),
     "dyk_loss_scale_grads": (_i32, [_vp, _i64, _i32, _vp, _vp]),
 }
 

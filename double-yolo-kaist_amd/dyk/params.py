@@ -161,14 +161,17 @@ class ParamStore:
     def mark_dirty(self):
         self._dirty += 1
 
-    def compute_weights(self, dtype, force=False):
+    def version_key(self):
+        return (sum(e.param._version for e in self.entries), self._dirty)
+
+    def compute_weights(self, dtype, force=False, skip_cast=False):
         """Return dict(Wc=<tensor same offsets as P>, Wt=<transposed per tap>, stems={name: tensor})
         for the compute dtype, refreshed iff the master buffer changed since the last call."""
         st = self._compute.get(dtype)
         # Parameter.data views do not share a version counter with P, so track the parameters'
         # own counters (optimizer steps / load_state_dict bump them) plus an explicit dirty flag
         # for writers that go through `.data` (load_darknet_weights).
-        ver = (sum(e.param._version for e in self.entries), self._dirty)
+        ver = self.version_key()
         if st is not None and st["version"] == ver and not force:
             return st
         lib = load()
@@ -188,7 +191,7 @@ class ParamStore:
                     assert kh == 1 and kw == 1, "Cout %% 32 != 0 is only supported for 1x1 convs (%s)" % e.name
                     st["heads_t"][e.name] = torch.zeros((ci, _round_up(co, 32)), dtype=dtype, device=self.device)
             self._compute[dtype] = st
-        if dtype != torch.float32:
+        if dtype != torch.float32 and not skip_cast:
             check(lib.dyk_cast_f32(self.P.data_ptr(), st["Wc"].data_ptr(), self.total, code, stream), "dyk_cast_f32")
         tab, n, tiles = self._transpose_table()
         if n:

@@ -90,10 +90,16 @@ class Plan:
         self._cfwd = self._pack(self.fwd)
         self._cbwd = self._pack(self.bwd)
 
-    def run(self, which, stream_ptr):
+    def run(self, which, stream_ptr, start=0, end=None):
         arr, n = (self._cfwd, len(self.fwd)) if which == "fwd" else (self._cbwd, len(self.bwd))
+        end = n if end is None else end
+        if end <= start:
+            return
+        sub = ctypes.cast(ctypes.addressof(arr) + start * ctypes.sizeof(L.DykCommand), ctypes.POINTER(L.DykCommand))
         failed = ctypes.c_int32(-1)
-        rc = L.load().dyk_run_commands(arr, n, ctypes.c_void_p(stream_ptr), ctypes.byref(failed))
+        rc = L.load().dyk_run_commands(sub, end - start, ctypes.c_void_p(stream_ptr), ctypes.byref(failed))
+        if rc != 0 and failed.value >= 0:
+            failed.value += start
         if rc != 0:
             cmds = self.fwd if which == "fwd" else self.bwd
             raise L.DykError("plan %s command %d (op %d) failed: %s" % (
@@ -489,9 +495,13 @@ def compile_plan(model, store, B, H, W, dtype, training, device):
                 plan.bwd.append((L.OP_CONV, d))
             ginit.add(x_in.tid)
 
+        memset_desc = misc()
+        plan.bwd.append((L.OP_MEMSET, memset_desc))          # slot 0: clears the fp64 reduction scratch
+        plan.bwd_marks = []                                  # (number of commands emitted, layer index) in backward order
         for i in range(len(defs) - 1, -1, -1):
             rec = info[i]
             t = rec["kind"]
+            plan.bwd_marks.append((len(plan.bwd), i))
             if rec.get("alias"):
                 continue
             if t == "yolo":
@@ -619,13 +629,13 @@ def compile_plan(model, store, B, H, W, dtype, training, device):
                 gx = gref(x_in)
                 plan.bwd.append((L.OP_UPSAMPLE_BWD, ew_desc(a=dz, out=gx, C=x_in.C, Bn=B, Hn=x_in.H, Wn=x_in.W, flags=acc_flag(x_in))))
         # zero the fp64 reduction scratch before anything accumulates into it
-        if red_offs:
-            lo = min(o for o, n in red_offs)
-            hi = max(o + n for o, n in red_offs)
-            ms = misc()
-            ms.n, ms.i[0] = hi - lo, 0
-            later(lambda ms=ms, lo=lo: ms.p.__setitem__(0, ws.ptr(lo)))
-            plan.bwd.insert(0, (L.OP_MEMSET, ms))
+        plan.bwd_marks.append((len(plan.bwd), -1))
+        if not red_offs:
+            red_offs.append((new_ws(256), 256))
+        lo = min(o for o, n in red_offs)
+        hi = max(o + n for o, n in red_offs)
+        memset_desc.n, memset_desc.i[0] = hi - lo, 0
+        later(lambda ms=memset_desc, lo=lo: ms.p.__setitem__(0, ws.ptr(lo)))
 
     # ---------------------------------------------------------------- materialise
     for a in plan.arenas.values():

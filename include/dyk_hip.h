@@ -435,6 +435,35 @@ typedef struct DykNmsDesc {
 int64_t dyk_nms_workspace_bytes(int32_t N, int32_t no, int32_t multi_label);
 int dyk_nms(const DykNmsDesc* desc, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Fused optimizer step over the flat parameter store (replaces the per-tensor torch.optim.Adam /
+ * optim.SGD(nesterov=True) updates of reference train.py:85-91; same update rule incl. L2
+ * weight_decay added to the gradient).  n must be a multiple of 4, pointers 16-byte aligned.
+ *   grad_scale : multiplies the gradient first (1/world_size after an all-reduce SUM, 1/loss_scale)
+ *   wc         : if not NULL, also writes the bf16 copy of the updated parameters (same offsets)
+ *   zero_grad  : if non-zero, clears g after use (next backward accumulates into zeros)
+ * dyk_adam_step : m = exp_avg, v = exp_avg_sq, beta1/beta2/eps, step = 1-based step count
+ * dyk_sgd_step  : m = momentum buffer, beta1 = momentum, Nesterov, dampening 0 (v, beta2, eps unused)
+ * ---------------------------------------------------------------------------------- */
+typedef struct DykOptimDesc {
+    float* p;
+    float* g;
+    float* m;
+    float* v;
+    void* wc;
+    int64_t n;
+    float lr, beta1, beta2, eps, weight_decay, grad_scale;
+    int32_t step;
+    int32_t zero_grad;
+} DykOptimDesc;
+int dyk_adam_step(const DykOptimDesc* desc, void* stream);
+int dyk_sgd_step(const DykOptimDesc* desc, void* stream);
+
+/* Profiling variant of dyk_run_commands: brackets every command with HIP events on `stream`
+ * and, after synchronising the stream, writes each command's duration in milliseconds to
+ * ms_out[0..n).  Used by bench.py's roofline pass, never in a timed throughput region. */
+int dyk_run_commands_timed(const DykCommand* cmds, int32_t n, void* stream, float* ms_out_host);
+
 #ifdef __cplusplus
 }
 #endif
