@@ -15,7 +15,13 @@ __global__ void bn_finalize_kernel(DykBnFinalizeDesc d) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.C) return;
     const double n = (double)d.count;
-    const double s1 = d.stats[c], s2 = d.stats[d.C + c];
+    const int slots = d.slots > 0 ? d.slots : 1;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < slots; ++r) {
+        double* st = d.stats + (size_t)r * 2 * d.C;
+        s1 += st[c]; s2 += st[d.C + c];
+        st[c] = 0.0; st[d.C + c] = 0.0;          // ready for the next step
+    }
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -31,8 +37,6 @@ __global__ void bn_finalize_kernel(DykBnFinalizeDesc d) {
         d.running_mean[c] = (1.f - d.momentum) * d.running_mean[c] + d.momentum * (float)mean;
         d.running_var[c] = (1.f - d.momentum) * d.running_var[c] + d.momentum * (float)unb;
     }
-    d.stats[c] = 0.0;            // ready for the next step
-    d.stats[d.C + c] = 0.0;
 }
 
 // eval-mode BN folded to scale/shift: scale = gamma / sqrt(running_var + eps)
@@ -45,24 +49,30 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
     shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
 }
 
+// Elementwise kernels use a 2-D thread mapping: tx = channel vector inside a group of CVB, ty = pixel
+// lane; grid.x walks channel-vector groups, grid.y strides over pixels.  No integer division in the
+// loop, per-channel parameters live in registers, and a wave touches CVB*16 contiguous bytes per pixel
+// row (whole rows for C <= 256 bf16), i.e. fully coalesced when ld == C.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwDesc d) {
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwDesc d, int CVB) {
     constexpr int EPV = ElemTraits<T>::EPV;
-    const int CV = d.C / EPV;
-    const long total = (long)d.npix * CV;
+    const int PY = 256 / CVB;
+    const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
+    const int cv = blockIdx.x * CVB + tx;
+    if (cv * EPV >= d.C) return;
+    const int c = cv * EPV;
+    float sc[EPV], sh[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) { sc[j] = d.p0 ? d.p0[c + j] : 1.f; sh[j] = d.p1 ? d.p1[c + j] : 0.f; }
     const T* __restrict__ a = (const T*)d.a;
     const T* __restrict__ r = (const T*)d.b;
     T* __restrict__ o = (T*)d.out;
-    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
-        const long p = v / CV;
-        const int c = (int)(v - p * CV) * EPV;
+    const int act = d.act;
+    for (long p = (long)blockIdx.y * PY + ty; p < d.npix; p += (long)gridDim.y * PY) {
         float x[EPV], y[EPV];
         vec_unpack<T>(*(const uint4*)(a + p * d.lda + c), x);
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) {
-            const float sc = d.p0 ? d.p0[c + j] : 1.f, sh = d.p1 ? d.p1[c + j] : 0.f;
-            y[j] = act_fwd(d.act, x[j] * sc + sh);
-        }
+        for (int j = 0; j < EPV; ++j) y[j] = act_fwd(act, x[j] * sc[j] + sh[j]);
         if (r) {
             float rr[EPV];
             vec_unpack<T>(*(const uint4*)(r + p * d.ldb + c), rr);
@@ -118,45 +128,56 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(DykEwDesc d, int
 #pragma unroll
             for (int j = 0; j < EPV; ++j) { s1[j] += o[j]; s2[j] += o[8 + j]; }
         }
+        double* rd = d.red + (size_t)(blockIdx.y % (unsigned)(d.slots > 0 ? d.slots : 1)) * 2 * d.C;
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
-            atomicAdd(d.red + c + j, (double)s1[j]);
-            atomicAdd(d.red + d.C + c + j, (double)s2[j]);
+            atomicAdd(rd + c + j, (double)s1[j]);
+            atomicAdd(rd + d.C + c + j, (double)s2[j]);
         }
     }
 }
 
-__global__ void bn_bwd_params_kernel(const double* red, float* dgamma, float* dbeta, int C) {
+__global__ void bn_bwd_params_kernel(double* red, float* dgamma, float* dbeta, int C, int slots) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    if (dbeta) dbeta[c] += (float)red[c];
-    if (dgamma) dgamma[c] += (float)red[C + c];
+    double s1 = red[c], s2 = red[C + c];
+    for (int r = 1; r < slots; ++r) { s1 += red[(size_t)r * 2 * C + c]; s2 += red[(size_t)r * 2 * C + C + c]; }
+    red[c] = s1; red[C + c] = s2;            // replica 0 now holds the totals (read by the apply kernel)
+    if (dbeta) dbeta[c] += (float)s1;
+    if (dgamma) dgamma[c] += (float)s2;
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwDesc d) {
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwDesc d, int CVB) {
     constexpr int EPV = ElemTraits<T>::EPV;
-    const int CV = d.C / EPV;
-    const long total = (long)d.npix * CV;
+    const int PY = 256 / CVB;
+    const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
+    const int cv = blockIdx.x * CVB + tx;
+    if (cv * EPV >= d.C) return;
+    const int c = cv * EPV;
+    const float invn = 1.f / (float)d.npix;
+    float sc[EPV], sh[EPV], mu[EPV], rs[EPV], m1[EPV], m2[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+        sc[j] = d.p0[c + j]; sh[j] = d.p1[c + j]; mu[j] = d.p2[c + j]; rs[j] = d.p3[c + j];
+        m1[j] = (float)d.red[c + j] * invn; m2[j] = (float)d.red[d.C + c + j] * invn;
+    }
     const T* __restrict__ dz = (const T*)d.a;
     const T* __restrict__ y = (const T*)d.b;
     T* __restrict__ o = (T*)d.out;
-    const float invn = 1.f / (float)d.npix;
-    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
-        const long p = v / CV;
-        const int c = (int)(v - p * CV) * EPV;
+    const int act = d.act;
+    const bool accum = d.flags & DYK_EW_ACCUM;
+    for (long p = (long)blockIdx.y * PY + ty; p < d.npix; p += (long)gridDim.y * PY) {
         float g[EPV], yy[EPV], r[EPV];
         vec_unpack<T>(*(const uint4*)(dz + p * d.lda + c), g);
         vec_unpack<T>(*(const uint4*)(y + p * d.ldb + c), yy);
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
-            const float sc = d.p0[c + j], sh = d.p1[c + j], mu = d.p2[c + j], rs = d.p3[c + j];
-            const float da = g[j] * act_bwd(d.act, yy[j] * sc + sh);
-            const float xh = (yy[j] - mu) * rs;
-            const float m1 = (float)d.red[c + j] * invn, m2 = (float)d.red[d.C + c + j] * invn;
-            r[j] = sc * (da - m1 - xh * m2);      // sc = gamma * rstd
+            const float da = g[j] * act_bwd(act, yy[j] * sc[j] + sh[j]);
+            const float xh = (yy[j] - mu[j]) * rs[j];
+            r[j] = sc[j] * (da - m1[j] - xh * m2[j]);      // sc = gamma * rstd
         }
-        if (d.flags & DYK_EW_ACCUM) {
+        if (accum) {
             float old[EPV];
             vec_unpack<T>(*(const uint4*)(o + p * d.ldo + c), old);
 #pragma unroll
@@ -166,9 +187,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwDesc d) {
     }
 }
 
-inline int ew_grid(long total_vec) {
-    long g = (total_vec + 255) / 256;
-    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+// grid for the 2-D elementwise mapping: returns CVB, fills gx / gy
+inline int ew_grid2d(int CV, long npix, int* gx, int* gy) {
+    int CVB = 1;
+    while (CVB < CV && CVB < 32) CVB <<= 1;
+    const int PY = 256 / CVB;
+    *gx = (CV + CVB - 1) / CVB;
+    long g = (npix + (long)PY * 4 - 1) / ((long)PY * 4);        // >= 4 pixels per thread
+    const long cap = 4096 / *gx > 0 ? 4096 / *gx : 1;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    *gy = (int)g;
+    return CVB;
 }
 
 inline int ew_check(const DykEwDesc* d, bool need_b) {
@@ -203,11 +233,12 @@ extern "C" int dyk_bn_act_fwd(const DykEwDesc* d, void* stream) {
     const int rc = ew_check(d, false);
     if (rc) return rc;
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
-    const int grid = ew_grid((long)d->npix * (d->C / epv));
+    int gx, gy;
+    const int CVB = ew_grid2d(d->C / epv, d->npix, &gx, &gy);
     if (d->dtype == DYK_BF16)
-        hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+        hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
     else
-        hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+        hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -234,9 +265,10 @@ extern "C" int dyk_bn_act_bwd_reduce(const DykEwDesc* d, void* stream) {
     return DYK_OK;
 }
 
-extern "C" int dyk_bn_bwd_params(const double* red, float* dgamma, float* dbeta, int32_t C, void* stream) {
+extern "C" int dyk_bn_bwd_params(double* red, float* dgamma, float* dbeta, int32_t C, int32_t slots, void* stream) {
     if (!red || C <= 0) return DYK_ERR_ARG;
-    hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, red, dgamma, dbeta, C);
+    hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, red, dgamma, dbeta, C,
+                       slots > 0 ? slots : 1);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -246,11 +278,12 @@ extern "C" int dyk_bn_act_bwd_apply(const DykEwDesc* d, void* stream) {
     if (rc) return rc;
     if (!d->red || !d->p0 || !d->p1 || !d->p2 || !d->p3) return DYK_ERR_ARG;
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
-    const int grid = ew_grid((long)d->npix * (d->C / epv));
+    int gx, gy;
+    const int CVB = ew_grid2d(d->C / epv, d->npix, &gx, &gy);
     if (d->dtype == DYK_BF16)
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
     else
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

@@ -222,8 +222,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
                 }
                 const int m = m0 + wm * WTM + mi * 16 + mlane + r;
                 if ((lane & 15) == 0 && m < a.Cout) {
-                    atomicAdd(a.stats + m, (double)s1);
-                    atomicAdd(a.stats + a.Cout + m, (double)s2);
+                    double* st = a.stats + (size_t)(blockIdx.x % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
+                    atomicAdd(st + m, (double)s1);
+                    atomicAdd(st + a.Cout + m, (double)s2);
                 }
             }
         }

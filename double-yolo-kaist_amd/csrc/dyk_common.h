@@ -94,7 +94,7 @@ __device__ inline float act_fwd(int act, float x) {
         if (x > 20.f) return x;  // softplus threshold of torch
         const float e = __expf(x);
         const float n = e * (e + 2.f);
-        return x * (n / (n + 2.f));
+        return x * (n * __builtin_amdgcn_rcpf(n + 2.f));      // v_rcp_f32: 1 ulp, no IEEE-division expansion
     }
     case DYK_ACT_RELU: return x > 0.f ? x : 0.f;
     case DYK_ACT_RELU6: return fminf(fmaxf(x, 0.f), 6.f);
@@ -110,8 +110,8 @@ __device__ inline float act_bwd(int act, float x) {
         if (x > 20.f) return 1.f;
         const float e = __expf(x);
         const float n = e * (e + 2.f);
-        const float t = n / (n + 2.f);            // tanh(softplus(x))
-        const float sg = e / (1.f + e);           // sigmoid(x)
+        const float t = n * __builtin_amdgcn_rcpf(n + 2.f);   // tanh(softplus(x))
+        const float sg = e * __builtin_amdgcn_rcpf(1.f + e);  // sigmoid(x)
         return t + x * (1.f - t * t) * sg;
     }
     case DYK_ACT_RELU: return x > 0.f ? 1.f : 0.f;

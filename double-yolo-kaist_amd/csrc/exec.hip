@@ -180,7 +180,7 @@ extern "C" int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream,
             case DYK_OP_SE_FC_BWD: rc = dyk_se_fc_bwd((const DykSeFcDesc*)dp, stream); break;
             case DYK_OP_SE_SCALE: rc = dyk_se_scale(e, stream); break;
             case DYK_OP_BN_BWD_PARAMS:
-                rc = dyk_bn_bwd_params((const double*)m->p[0], (float*)m->p[1], (float*)m->p[2], m->i[0], stream); break;
+                rc = dyk_bn_bwd_params((double*)m->p[0], (float*)m->p[1], (float*)m->p[2], m->i[0], m->i[1], stream); break;
             case DYK_OP_BN_FOLD:
                 rc = dyk_bn_fold((const float*)m->p[0], (const float*)m->p[1], (const float*)m->p[2], (const float*)m->p[3],
                                  m->f[0], (float*)m->p[4], (float*)m->p[5], m->i[0], stream); break;

@@ -43,7 +43,7 @@ class DykConvDesc(ctypes.Structure):
         ("isy", _i32), ("isx", _i32), ("osy", _i32), ("osx", _i32), ("ooy", _i32), ("oox", _i32),
         ("ntaps", _i32),
         ("tdy", _i8 * MAX_TAPS), ("tdx", _i8 * MAX_TAPS), ("twt", _i8 * MAX_TAPS), ("_pad", _i8),
-        ("act", _i32), ("flags", _i32),
+        ("act", _i32), ("flags", _i32), ("stats_slots", _i32),
     ]
 
 
@@ -64,7 +64,7 @@ class DykEwDesc(ctypes.Structure):
         ("aux", _vp),
         ("dtype", _i32), ("npix", _i32), ("C", _i32), ("lda", _i32), ("ldb", _i32), ("ldo", _i32),
         ("act", _i32), ("flags", _i32), ("B", _i32), ("H", _i32), ("W", _i32), ("k", _i32),
-        ("alpha", _f32), ("beta", _f32),
+        ("alpha", _f32), ("beta", _f32), ("slots", _i32),
     ]
 
 
@@ -72,7 +72,7 @@ class DykBnFinalizeDesc(ctypes.Structure):
     _fields_ = [
         ("stats", _vp), ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp),
         ("scale", _vp), ("shift", _vp), ("save_mean", _vp), ("save_rstd", _vp),
-        ("C", _i32), ("count", _i32), ("momentum", _f32), ("eps", _f32),
+        ("C", _i32), ("count", _i32), ("momentum", _f32), ("eps", _f32), ("slots", _i32),
     ]
 
 
@@ -141,7 +141,7 @@ SIGNATURES = {
     "dyk_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp]),
     "dyk_bn_act_fwd": (_i32, [_P(DykEwDesc), _vp]),
     "dyk_bn_act_bwd_reduce": (_i32, [_P(DykEwDesc), _vp]),
-    "dyk_bn_bwd_params": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "dyk_bn_bwd_params": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dyk_bn_act_bwd_apply": (_i32, [_P(DykEwDesc), _vp]),
     "dyk_axpby": (_i32, [_P(DykEwDesc), _vp]),
     "dyk_dot": (_i32, [_P(DykEwDesc), _vp]),

@@ -22,6 +22,7 @@ from .ops import conv_out_size, dgrad_classes, fwd_taps
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 HEAD_LD = 32            # head conv outputs / their gradients live in 32-channel rows
+STAT_SLOTS = 32         # replicas of every per-channel fp64 reduction buffer (bounds atomic contention)
 
 
 def _ru(n, a):
@@ -223,9 +224,9 @@ def compile_plan(model, store, B, H, W, dtype, training, device):
             if training:
                 y_raw = new_act(B, Ho, Wo, cout)
                 z = new_act(B, Ho, Wo, cout)
-                stats = new_ws(2 * cout * 8)
+                stats = new_ws(STAT_SLOTS * 2 * cout * 8)
                 vecs = new_ws(4 * cout * 4)          # scale | shift | mean | rstd
-                d.ldy, d.act, d.flags = y_raw.ld, 0, L.EPI_STATS
+                d.ldy, d.act, d.flags, d.stats_slots = y_raw.ld, 0, L.EPI_STATS, STAT_SLOTS
                 later(lambda d=d, x_in=x_in, y_raw=y_raw, stats=stats: (
                     setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", ws.ptr(stats))))
                 plan.fwd.append((L.OP_CONV, d))
@@ -233,7 +234,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device):
                 plan._keep.append(f)
                 f.gamma, f.beta = store.p_ptr(pre + "BatchNorm2d.weight"), store.p_ptr(pre + "BatchNorm2d.bias")
                 f.running_mean, f.running_var = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
-                f.C, f.count, f.momentum, f.eps = cout, B * Ho * Wo, BN_MOMENTUM, BN_EPS
+                f.C, f.count, f.momentum, f.eps, f.slots = cout, B * Ho * Wo, BN_MOMENTUM, BN_EPS, STAT_SLOTS
                 later(lambda f=f, stats=stats, vecs=vecs: (
                     setattr(f, "stats", ws.ptr(stats)), setattr(f, "scale", ws.ptr(vecs)),
                     setattr(f, "shift", ws.ptr(vecs + 4 * cout)), setattr(f, "save_mean", ws.ptr(vecs + 8 * cout)),
@@ -521,8 +522,9 @@ def compile_plan(model, store, B, H, W, dtype, training, device):
                 dz = gref(z)
                 if rec["bn"]:
                     cout, vecs = rec["cout"], rec["vecs"]
-                    red = new_red(2 * cout * 8)
+                    red = new_red(STAT_SLOTS * 2 * cout * 8)
                     r = ew_desc(a=dz, b=rec["y_raw"], act=rec["act"])
+                    r.slots = STAT_SLOTS
                     later(lambda r=r, vecs=vecs, red=red, cout=cout: (
                         setattr(r, "p0", ws.ptr(vecs)), setattr(r, "p1", ws.ptr(vecs + 4 * cout)),
                         setattr(r, "p2", ws.ptr(vecs + 8 * cout)), setattr(r, "p3", ws.ptr(vecs + 12 * cout)),
@@ -531,7 +533,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device):
                     pm = misc()
                     pre = "module_list.%d." % i
                     pm.p[1], pm.p[2] = store.g_ptr(pre + "BatchNorm2d.weight"), store.g_ptr(pre + "BatchNorm2d.bias")
-                    pm.i[0] = cout
+                    pm.i[0], pm.i[1] = cout, STAT_SLOTS
                     later(lambda pm=pm, red=red: pm.p.__setitem__(0, ws.ptr(red)))
                     plan.bwd.append((L.OP_BN_BWD_PARAMS, pm))
                     dyr = dz

@@ -73,7 +73,9 @@ const char* dyk_error_string(int code);
 enum {
     DYK_EPI_AFFINE = 1,   /* v = acc*scale[co] + shift[co]  (scale==NULL -> 1, shift==NULL -> 0) */
     DYK_EPI_RESIDUAL = 2, /* v += res[b, y, x, co]   (after the activation) */
-    DYK_EPI_STATS = 4,    /* atomically add sum(acc), sum(acc^2) per channel into stats[0..Cout), stats[Cout..2Cout) */
+    DYK_EPI_STATS = 4,    /* atomically add sum(acc), sum(acc^2) per channel into one of `stats_slots` replicas of
+                             stats[0..Cout) / stats[Cout..2Cout): replica (workgroup id % stats_slots), 2*Cout doubles each
+                             (replication bounds the atomic contention per address; dyk_bn_finalize sums the replicas) */
     DYK_EPI_ACCUM = 8,    /* y = y_old + v (gradient accumulation) */
     DYK_EPI_OUT_F32 = 16  /* y is float regardless of dtype */
 };
@@ -99,6 +101,7 @@ typedef struct DykConvDesc {
     int8_t _pad;
     int32_t act;                    /* DYK_ACT_* applied after the affine */
     int32_t flags;                  /* DYK_EPI_* */
+    int32_t stats_slots;            /* number of stats replicas (>= 1; 0 is read as 1) */
 } DykConvDesc;
 
 int dyk_conv_igemm(const DykConvDesc* desc, void* stream);
@@ -156,6 +159,7 @@ typedef struct DykEwDesc {
     int32_t act, flags;
     int32_t B, H, W, k;             /* spatial ops (pool / upsample) */
     float alpha, beta;
+    int32_t slots;                  /* replicas of `red` (reductions; 0 is read as 1) */
 } DykEwDesc;
 
 /* BatchNorm2d, training mode (nn.BatchNorm2d at models.py:47, torch defaults eps=1e-5,
@@ -176,6 +180,7 @@ typedef struct DykBnFinalizeDesc {
     int32_t C;
     int32_t count;
     float momentum, eps;
+    int32_t slots;              /* replicas of stats written by the conv epilogue (0 is read as 1) */
 } DykBnFinalizeDesc;
 
 int dyk_bn_finalize(const DykBnFinalizeDesc* desc, void* stream);
@@ -191,10 +196,11 @@ int dyk_bn_act_fwd(const DykEwDesc* desc, void* stream);
 
 /* backward of the above w.r.t. the raw conv output y (b):  a = dz, p0 = scale, p1 = shift,
  * p2 = mean, p3 = rstd.  reduce: red[c] += sum dact, red[C+c] += sum dact*xhat with
- * dact = dz*act'(y*scale+shift);  params: dbeta += red[c], dgamma += red[C+c];
+ * dact = dz*act'(y*scale+shift), spread over `slots` replicas of red (2C doubles each);
+ * params: folds the replicas into replica 0, then dbeta += red[c], dgamma += red[C+c];
  * apply: out = scale*(dact - red[c]/npix - xhat*red[C+c]/npix). */
 int dyk_bn_act_bwd_reduce(const DykEwDesc* desc, void* stream);
-int dyk_bn_bwd_params(const double* red, float* dgamma, float* dbeta, int32_t C, void* stream);
+int dyk_bn_bwd_params(double* red, float* dgamma, float* dbeta, int32_t C, int32_t slots, void* stream);
 int dyk_bn_act_bwd_apply(const DykEwDesc* desc, void* stream);
 
 /* out = alpha*s0*a (+ beta*s1*b), s0 = p0 ? p0[0] : 1, s1 = p1 ? p1[0] : 1 (device scalars).
@@ -323,7 +329,7 @@ enum {
     DYK_OP_SE_FC_FWD = 14,      /* DykSeFcDesc */
     DYK_OP_SE_FC_BWD = 15,      /* DykSeFcDesc */
     DYK_OP_SE_SCALE = 16,       /* DykEwDesc */
-    DYK_OP_BN_BWD_PARAMS = 17,  /* Misc: p0=red p1=dgamma p2=dbeta i0=C */
+    DYK_OP_BN_BWD_PARAMS = 17,  /* Misc: p0=red p1=dgamma p2=dbeta i0=C i1=slots */
     DYK_OP_BN_FOLD = 18,        /* Misc: p0=gamma p1=beta p2=rmean p3=rvar p4=scale p5=shift i0=C f0=eps */
     DYK_OP_WFUSE_WEIGHTS = 19,  /* Misc: p0=w p1=weff i0=n */
     DYK_OP_WFUSE_BWD_PARAMS = 20, /* Misc: p0=w p1=red p2=dw i0=n */

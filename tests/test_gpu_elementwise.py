@@ -57,11 +57,14 @@ def test_bn_act_train_fwd_bwd(dtype, act):
     _close(ops.to_nchw(z).cpu(), z_ref.detach(), tol, "fwd")
     # backward
     dzd = ops.to_nhwc(dz.cuda(), dtype)
-    red = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
-    ops.call("dyk_bn_act_bwd_reduce", ops.ew_desc(a=dzd, b=yd, act=act, p0=scale, p1=shift, p2=mean, p3=rstd, red=red))
+    slots = 4                                                    # replicated reduction buffers
+    red = torch.zeros(slots * 2 * C, dtype=torch.float64, device="cuda")
+    rd = ops.ew_desc(a=dzd, b=yd, act=act, p0=scale, p1=shift, p2=mean, p3=rstd, red=red)
+    rd.slots = slots
+    ops.call("dyk_bn_act_bwd_reduce", rd)
     dgamma, dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
     from dyk.lib import check, load
-    check(load().dyk_bn_bwd_params(red.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), C, None))
+    check(load().dyk_bn_bwd_params(red.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), C, slots, None))
     _close(dgamma.cpu(), gamma.grad, 10 * tol, "dgamma")
     _close(dbeta.cpu(), beta.grad, 10 * tol, "dbeta")
     dy = torch.empty_like(dzd)
