@@ -63,21 +63,35 @@ def conv_flops(plan):
     return total
 
 
-def profile_plan(plan, stream):
+def profile_plan(plan, stream, dump=None):
     """per-op-kind kernel time (ms) of one forward and one backward pass, HIP events on `stream`"""
     from dyk import lib as L
     res = {}
+    rows = []
     for which in ("fwd", "bwd"):
         cmds = plan.fwd if which == "fwd" else plan.bwd
         arr = plan._cfwd if which == "fwd" else plan._cbwd
         ms = (ctypes.c_float * len(cmds))()
         L.check(L.load().dyk_run_commands_timed(arr, len(cmds), ctypes.c_void_p(stream), ms), "dyk_run_commands_timed")
         agg = {}
-        for (op, _), t in zip(cmds, ms):
+        for (op, desc), t in zip(cmds, ms):
             a = agg.setdefault(op, [0, 0.0])
             a[0] += 1
             a[1] += float(t)
+            if dump is not None and op in (L.OP_CONV, L.OP_WGRAD):
+                if op == L.OP_CONV:
+                    rows.append(dict(pass_=which, op="conv", Cin=desc.Cin, Cout=desc.Cout, Hg=desc.Hg, Wg=desc.Wg, taps=desc.ntaps,
+                                     isy=desc.isy, osy=desc.osy, flags=desc.flags, ms=float(t),
+                                     tflops=2.0 * desc.B * desc.Hg * desc.Wg * desc.Cin * desc.Cout * desc.ntaps / max(float(t), 1e-6) / 1e9))
+                else:
+                    rows.append(dict(pass_=which, op="wgrad", Cin=desc.Cin, Cout=desc.Cout, Hg=desc.Ho, Wg=desc.Wo, taps=desc.ntaps,
+                                     isy=desc.isy, ms=float(t),
+                                     tflops=2.0 * desc.B * desc.Ho * desc.Wo * desc.Cin * desc.Cout * desc.ntaps / max(float(t), 1e-6) / 1e9))
         res[which] = agg
+    if dump is not None:
+        os.makedirs(os.path.dirname(dump), exist_ok=True)
+        with open(dump, "w") as f:
+            json.dump(rows, f)
     return res
 
 
@@ -119,6 +133,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-layers", default=None, help="write per-conv-launch timings to this JSON file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -198,7 +213,7 @@ def main():
         if not args.no_roofline:
             plan = model.engine.plans[(B, H, W, torch.bfloat16 if args.dtype == "bf16" else torch.float32, True)]
             from dyk import lib as L
-            prof = profile_plan(plan, torch.cuda.current_stream().cuda_stream)
+            prof = profile_plan(plan, torch.cuda.current_stream().cuda_stream, args.dump_layers)
             f1 = conv_flops(plan)
             ig_ms = prof["fwd"].get(L.OP_CONV, [0, 0.0])[1] + prof["bwd"].get(L.OP_CONV, [0, 0.0])[1]
             ig_n = prof["fwd"].get(L.OP_CONV, [0, 0.0])[0] + prof["bwd"].get(L.OP_CONV, [0, 0.0])[0]

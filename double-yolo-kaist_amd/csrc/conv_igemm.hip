@@ -16,6 +16,7 @@
 // Replaces: nn.Conv2d forward at reference models.py:34-42 (+ the BatchNorm2d/activation
 // that follow it at :46-62 when run with the AFFINE epilogue), and autograd's
 // convolution_backward (input gradient) for the same layers.
+#include <stdlib.h>
 #include "dyk_common.h"
 
 namespace {
@@ -52,7 +53,28 @@ template <int BKB> __device__ inline int lds_off(int row, int slot) {
     return row * 64 + ((slot ^ (((row >> 3) & 1) * 3)) << 4);
 }
 
-template <typename T, int BM, int BKB>
+// all-zero source for padding taps / ragged rows of the LDS-DMA path
+__device__ uint4 dyk_zero_page[8];
+
+#define DYK_AS3 __attribute__((address_space(3)))
+
+// One LDS-DMA wave instruction: 64 lanes x 16 B from per-lane global addresses to the wave-uniform
+// LDS byte address `lds_addr` + lane*16.  Issued through inline asm on purpose: hipcc drains
+// vmcnt(0) in front of every ds_read while a *builtin* LDS-DMA is in flight (it cannot prove the
+// ring slots disjoint), which serialises the pipeline; hidden in asm, the DMA is ordered solely by
+// the counted s_waitcnt vmcnt(N) + s_barrier below (cdna_hip_programming.md §5.7).
+__device__ inline void glds16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+__device__ inline unsigned lds_addr_of(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(DYK_AS3 const char*)p);
+}
+
+template <typename T, int BM, int BKB, bool DMA>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
     const DykConvDesc& a = args.d;
     constexpr int BN = 128;
@@ -69,15 +91,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
     constexpr int MI = WTM / 16, NI = WTN / 16;
     constexpr int KK = BKB / 64;
     constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
+    constexpr int NSTAGE = DMA ? 3 : 2;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                          // [2][A_BYTES]
-    char* sB = smem + 2 * A_BYTES;            // [2][B_BYTES]
-    int* t_in = (int*)(smem + 2 * A_BYTES + 2 * B_BYTES);   // [BN] input base offset
+    char* sA = smem;                               // [NSTAGE][A_BYTES]
+    char* sB = smem + NSTAGE * A_BYTES;            // [NSTAGE][B_BYTES]
+    int* t_in = (int*)(smem + NSTAGE * (A_BYTES + B_BYTES));   // [BN] input base offset
     int* t_out = t_in + BN;                   // [BN] output offset or -1
     int* t_res = t_out + BN;                  // [BN] residual offset
     short* t_y = (short*)(t_res + BN);        // [BN] input row of tap (0,0)
     short* t_x = t_y + BN;                    // [BN]
+    char* sink = (char*)(t_x + BN);           // [1024] target of dummy LDS-DMA writes (DMA path only)
+    int* tap_x = (int*)(sink + 1024);         // [32] activation element offset of a tap: (dy*Wi + dx)*ldx
+    int* tap_w = tap_x + 32;                  // [32] weight element offset of a tap: twt*Cout*Cin
+    int* tap_dy = tap_w + 32;                 // [32]
+    int* tap_dx = tap_dy + 32;                // [32]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -107,9 +135,129 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
             t_in[tid] = 0; t_y[tid] = -20000; t_x[tid] = -20000; t_out[tid] = -1; t_res[tid] = 0;
         }
     }
+    if (tid >= 128 && tid < 128 + a.ntaps) {   // tap tables in LDS: no vector-memory loads inside the K loop
+        const int q = tid - 128;
+        const int dy = a.tdy[q], dx = a.tdx[q];
+        tap_dy[q] = dy; tap_dx[q] = dx;
+        tap_x[q] = (dy * a.Wi + dx) * a.ldx;
+        tap_w[q] = a.twt[q] * a.Cout * a.Cin;
+    }
     __syncthreads();
 
-    // ---- loader bookkeeping (per thread: NPA weight rows, NPB pixel rows, one 16-B segment)
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const T* __restrict__ xg = (const T*)a.x;
+    const T* __restrict__ wg = (const T*)a.w;
+    const int S = (a.Cin / BK) * a.ntaps;
+    const int frow = lane & 15, fslot = lane >> 4;
+
+    auto compute = [&](const char* pa, const char* pb) {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            uint4 fa[MI], fb[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                fa[mi] = *(const uint4*)(pa + lds_off<BKB>(wm * WTM + mi * 16 + frow, kk * 4 + fslot));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                fb[ni] = *(const uint4*)(pb + lds_off<BKB>(wn * WTN + ni * 16 + frow, kk * 4 + fslot));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], fa[mi], fb[ni]);
+        }
+    };
+
+    if constexpr (DMA) {
+        // ---- LDS-DMA pipeline: global_load_lds (16 B per lane, 1 KiB per wave instruction) straight
+        // into a 3-deep ring of swizzled tiles; step s+2 is in flight while step s feeds the MFMAs.
+        // A wave instruction fills RPI consecutive tile rows; lane -> (row, physical slot); the XOR
+        // swizzle is applied on the SOURCE side (the LDS image of an LDS-DMA is lane-linear).
+        constexpr int SPR = BKB / 16;                  // 16-byte slots per tile row
+        constexpr int RPI = 64 / SPR;                  // tile rows per wave instruction
+        constexpr int NI_A = BM * BKB / 1024, NI_B = BN * BKB / 1024;
+        constexpr int NIA_W = (NI_A + 3) / 4, NIB_W = NI_B / 4;
+        constexpr int NPW = NIA_W + NIB_W;             // DMA instructions per wave per step (uniform count)
+        const int wv = __builtin_amdgcn_readfirstlane(wid);
+        const int lrow = lane / SPR, pslot = lane % SPR;
+        int a_off[NIA_W]; bool a_ok[NIA_W];
+#pragma unroll
+        for (int j = 0; j < NIA_W; ++j) {
+            const int inst = j * 4 + wv;
+            const int row = inst * RPI + lrow;
+            const int co = m0 + row;
+            const int ls = (lds_off<BKB>(row, pslot) - row * BKB) >> 4;    // logical slot stored at this physical slot
+            a_ok[j] = (inst < NI_A) && (co < a.Cout);
+            a_off[j] = co * a.Cin + ls * EPV;
+        }
+        int b_off[NIB_W]; unsigned b_mask[NIB_W];
+#pragma unroll
+        for (int j = 0; j < NIB_W; ++j) {
+            const int inst = j * 4 + wv;
+            const int row = inst * RPI + lrow;
+            const int ls = (lds_off<BKB>(row, pslot) - row * BKB) >> 4;
+            b_off[j] = t_in[row] + ls * EPV;
+            const int y0 = t_y[row], x0 = t_x[row];
+            unsigned m = 0;
+            for (int q = 0; q < a.ntaps; ++q) {
+                const int yi = y0 + tap_dy[q], xi = x0 + tap_dx[q];
+                if (((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi)) m |= 1u << q;
+            }
+            b_mask[j] = m;
+        }
+        const T* zero = (const T*)dyk_zero_page;
+        auto stage = [&](int buf, int c0, int t) {
+            const int toff = tap_x[t] + c0;
+            const long wbase = (long)tap_w[t] + c0;
+            char* da = sA + buf * A_BYTES;
+            char* db = sB + buf * B_BYTES;
+#pragma unroll
+            for (int j = 0; j < NIA_W; ++j) {
+                const int inst = j * 4 + wv;
+                if (NI_A % 4 == 0 || inst < NI_A) {
+                    const T* src = a_ok[j] ? wg + wbase + a_off[j] : zero;
+                    glds16(src, lds_addr_of(da + inst * 1024));
+                } else {
+                    // keep the per-wave DMA count uniform so that one counted vmcnt fits all waves
+                    glds16(zero, lds_addr_of(sink));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NIB_W; ++j) {
+                const int inst = j * 4 + wv;
+                const T* src = ((b_mask[j] >> t) & 1u) ? xg + (long)b_off[j] + toff : zero;
+                glds16(src, lds_addr_of(db + inst * 1024));
+            }
+        };
+        // staging iterator (runs two steps ahead of the compute iterator)
+        int sc0 = 0, st = 0;
+        auto stage_next = [&](int buf) {
+            stage(buf, sc0, st);
+            if (++st == a.ntaps) { st = 0; sc0 += BK; }
+        };
+        if (S > 0) stage_next(0);
+        if (S > 1) stage_next(1);
+        if (S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0, nxt = 2;
+        for (int s = 0; s < S; ++s) {
+            const bool more = (s + 2 < S);
+            if (more) stage_next(nxt);
+            compute(sA + cur * A_BYTES, sB + cur * B_BYTES);
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur = (cur == 2) ? 0 : cur + 1;
+            nxt = (nxt == 2) ? 0 : nxt + 1;
+        }
+    } else {
+    // ---- register-staged pipeline (global -> VGPR -> LDS), double-buffered
     const int lrow = tid / TPR, seg = tid % TPR;
     int b_in[NPB]; int b_y[NPB], b_x[NPB];
 #pragma unroll
@@ -125,16 +273,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
         a_ok[i] = (row < BM) && (co < a.Cout);
         a_off[i] = co * a.Cin + seg * EPV;
     }
-    const T* __restrict__ xg = (const T*)a.x;
-    const T* __restrict__ wg = (const T*)a.w;
-
     uint4 ra[NPA], rb[NPB];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
     auto gload = [&](int c0, int t) {
-        const int dy = a.tdy[t], dx = a.tdx[t];
-        const int toff = (dy * a.Wi + dx) * a.ldx + c0 + seg * EPV;
-        const long wbase = (long)a.twt[t] * a.Cout * a.Cin + c0;
+        const int dy = tap_dy[t], dx = tap_dx[t];
+        const int toff = tap_x[t] + c0 + seg * EPV;
+        const long wbase = (long)tap_w[t] + c0;
 #pragma unroll
         for (int i = 0; i < NPA; ++i)
             ra[i] = a_ok[i] ? *(const uint4*)(wg + wbase + a_off[i]) : zero4;
@@ -157,45 +302,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
             *(uint4*)(sB + buf * B_BYTES + lds_off<BKB>(row, seg)) = rb[i];
         }
     };
-
-    f32x4_t acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    const int S = (a.Cin / BK) * a.ntaps;
     if (S > 0) {
         gload(0, 0);
         lstore(0);
     }
     __syncthreads();
     int c0 = 0, t = 0;
-    const int frow = lane & 15, fslot = lane >> 4;
     for (int s = 0; s < S; ++s) {
         int tn = t + 1, cn = c0;
         if (tn == a.ntaps) { tn = 0; cn += BK; }
         const bool more = (s + 1 < S);
         if (more) gload(cn, tn);
-        const char* pa = sA + (s & 1) * A_BYTES;
-        const char* pb = sB + (s & 1) * B_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            uint4 fa[MI], fb[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                fa[mi] = *(const uint4*)(pa + lds_off<BKB>(wm * WTM + mi * 16 + frow, kk * 4 + fslot));
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                fb[ni] = *(const uint4*)(pb + lds_off<BKB>(wn * WTN + ni * 16 + frow, kk * 4 + fslot));
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], fa[mi], fb[ni]);
-        }
+        compute(sA + (s & 1) * A_BYTES, sB + (s & 1) * B_BYTES);
         if (more) lstore((s + 1) & 1);
         __syncthreads();
         t = tn; c0 = cn;
+    }
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -301,12 +423,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
     }
 }
 
-template <typename T, int BM, int BKB>
-int launch_conv(const DykConvDesc* d, hipStream_t stream) {
+template <typename T, int BM, int BKB, bool DMA>
+int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     constexpr int BN = 128;
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * BKB + BN * (3 * sizeof(int) + 2 * sizeof(short));
+    constexpr size_t lds = (DMA ? 3 : 2) * (size_t)(BM + BN) * BKB + BN * (3 * sizeof(int) + 2 * sizeof(short)) + 1024 + 4 * 32 * sizeof(int);
     static bool attr_set = false;
-    auto kfn = conv_igemm_kernel<T, BM, BKB>;
+    auto kfn = conv_igemm_kernel<T, BM, BKB, DMA>;
     if (!attr_set) {
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -322,6 +444,21 @@ int launch_conv(const DykConvDesc* d, hipStream_t stream) {
     hipLaunchKernelGGL(kfn, dim3(tiles_n * tiles_m), dim3(256), lds, stream, args);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
+}
+
+// DYK_CONV_PIPE=reg selects the register-staged pipeline (kept for A/B measurements)
+inline bool use_dma() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DYK_CONV_PIPE");
+        v = (e && e[0] == 'r') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+template <typename T, int BM, int BKB>
+int launch_conv(const DykConvDesc* d, hipStream_t stream) {
+    return use_dma() ? launch_conv_impl<T, BM, BKB, true>(d, stream) : launch_conv_impl<T, BM, BKB, false>(d, stream);
 }
 
 template <typename T>
