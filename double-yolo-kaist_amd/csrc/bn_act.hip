@@ -17,10 +17,13 @@ __global__ void bn_finalize_kernel(DykBnFinalizeDesc d) {
     const double n = (double)d.count;
     const int slots = d.slots > 0 ? d.slots : 1;
     double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < slots; ++r) {
-        double* st = d.stats + (size_t)r * 2 * d.C;
+    for (int r = 0; r < slots; ++r) {            // all loads first (independent, pipelined) ...
+        const double* st = d.stats + (size_t)r * 2 * d.C;
         s1 += st[c]; s2 += st[d.C + c];
-        st[c] = 0.0; st[d.C + c] = 0.0;          // ready for the next step
+    }
+    for (int r = 0; r < slots; ++r) {            // ... then re-arm the accumulators for the next step
+        double* st = d.stats + (size_t)r * 2 * d.C;
+        st[c] = 0.0; st[d.C + c] = 0.0;
     }
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
@@ -68,18 +71,34 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwDesc d, int CVB) {
     const T* __restrict__ r = (const T*)d.b;
     T* __restrict__ o = (T*)d.out;
     const int act = d.act;
-    for (long p = (long)blockIdx.y * PY + ty; p < d.npix; p += (long)gridDim.y * PY) {
-        float x[EPV], y[EPV];
-        vec_unpack<T>(*(const uint4*)(a + p * d.lda + c), x);
+    constexpr int U = 4;                      // pixels in flight per thread (memory-level parallelism)
+    const long pstep = (long)gridDim.y * PY;
+    for (long p0 = (long)blockIdx.y * PY + ty; p0 < d.npix; p0 += pstep * U) {
+        uint4 vx[U], vr[U];
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) y[j] = act_fwd(act, x[j] * sc[j] + sh[j]);
-        if (r) {
-            float rr[EPV];
-            vec_unpack<T>(*(const uint4*)(r + p * d.ldb + c), rr);
-#pragma unroll
-            for (int j = 0; j < EPV; ++j) y[j] += rr[j];
+        for (int u = 0; u < U; ++u) {
+            const long p = p0 + u * pstep;
+            if (p < d.npix) {
+                vx[u] = *(const uint4*)(a + p * d.lda + c);
+                if (r) vr[u] = *(const uint4*)(r + p * d.ldb + c);
+            }
         }
-        *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(y);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long p = p0 + u * pstep;
+            if (p >= d.npix) break;
+            float x[EPV], y[EPV];
+            vec_unpack<T>(vx[u], x);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) y[j] = act_fwd(act, x[j] * sc[j] + sh[j]);
+            if (r) {
+                float rr[EPV];
+                vec_unpack<T>(vr[u], rr);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) y[j] += rr[j];
+            }
+            *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(y);
+        }
     }
 }
 
@@ -105,15 +124,28 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(DykEwDesc d, int
         }
         const T* __restrict__ dz = (const T*)d.a;
         const T* __restrict__ y = (const T*)d.b;
-        for (long p = (long)blockIdx.y * PY + ty; p < d.npix; p += (long)gridDim.y * PY) {
-            float g[EPV], yy[EPV];
-            vec_unpack<T>(*(const uint4*)(dz + p * d.lda + c), g);
-            vec_unpack<T>(*(const uint4*)(y + p * d.ldb + c), yy);
+        constexpr int U = 4;
+        const long pstep = (long)gridDim.y * PY;
+        const int act = d.act;
+        for (long p0 = (long)blockIdx.y * PY + ty; p0 < d.npix; p0 += pstep * U) {
+            uint4 vg[U], vy[U];
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) {
-                const float da = g[j] * act_bwd(d.act, yy[j] * sc[j] + sh[j]);
-                s1[j] += da;
-                s2[j] += da * ((yy[j] - mu[j]) * rs[j]);
+            for (int u = 0; u < U; ++u) {
+                const long p = p0 + u * pstep;
+                if (p < d.npix) { vg[u] = *(const uint4*)(dz + p * d.lda + c); vy[u] = *(const uint4*)(y + p * d.ldb + c); }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (p0 + u * pstep >= d.npix) break;
+                float g[EPV], yy[EPV];
+                vec_unpack<T>(vg[u], g);
+                vec_unpack<T>(vy[u], yy);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) {
+                    const float da = g[j] * act_bwd(act, yy[j] * sc[j] + sh[j]);
+                    s1[j] += da;
+                    s2[j] += da * ((yy[j] - mu[j]) * rs[j]);
+                }
             }
         }
     }
@@ -167,23 +199,40 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwDesc d, int 
     T* __restrict__ o = (T*)d.out;
     const int act = d.act;
     const bool accum = d.flags & DYK_EW_ACCUM;
-    for (long p = (long)blockIdx.y * PY + ty; p < d.npix; p += (long)gridDim.y * PY) {
-        float g[EPV], yy[EPV], r[EPV];
-        vec_unpack<T>(*(const uint4*)(dz + p * d.lda + c), g);
-        vec_unpack<T>(*(const uint4*)(y + p * d.ldb + c), yy);
+    constexpr int U = 4;
+    const long pstep = (long)gridDim.y * PY;
+    for (long p0 = (long)blockIdx.y * PY + ty; p0 < d.npix; p0 += pstep * U) {
+        uint4 vg[U], vy[U], vo[U];
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) {
-            const float da = g[j] * act_bwd(act, yy[j] * sc[j] + sh[j]);
-            const float xh = (yy[j] - mu[j]) * rs[j];
-            r[j] = sc[j] * (da - m1[j] - xh * m2[j]);      // sc = gamma * rstd
+        for (int u = 0; u < U; ++u) {
+            const long p = p0 + u * pstep;
+            if (p < d.npix) {
+                vg[u] = *(const uint4*)(dz + p * d.lda + c);
+                vy[u] = *(const uint4*)(y + p * d.ldb + c);
+                if (accum) vo[u] = *(const uint4*)(o + p * d.ldo + c);
+            }
         }
-        if (accum) {
-            float old[EPV];
-            vec_unpack<T>(*(const uint4*)(o + p * d.ldo + c), old);
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) r[j] += old[j];
+        for (int u = 0; u < U; ++u) {
+            const long p = p0 + u * pstep;
+            if (p >= d.npix) break;
+            float g[EPV], yy[EPV], r[EPV];
+            vec_unpack<T>(vg[u], g);
+            vec_unpack<T>(vy[u], yy);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                const float da = g[j] * act_bwd(act, yy[j] * sc[j] + sh[j]);
+                const float xh = (yy[j] - mu[j]) * rs[j];
+                r[j] = sc[j] * (da - m1[j] - xh * m2[j]);      // sc = gamma * rstd
+            }
+            if (accum) {
+                float old[EPV];
+                vec_unpack<T>(vo[u], old);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) r[j] += old[j];
+            }
+            *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(r);
         }
-        *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(r);
     }
 }
 
@@ -193,8 +242,8 @@ inline int ew_grid2d(int CV, long npix, int* gx, int* gy) {
     while (CVB < CV && CVB < 32) CVB <<= 1;
     const int PY = 256 / CVB;
     *gx = (CV + CVB - 1) / CVB;
-    long g = (npix + (long)PY * 4 - 1) / ((long)PY * 4);        // >= 4 pixels per thread
-    const long cap = 4096 / *gx > 0 ? 4096 / *gx : 1;
+    long g = (npix + (long)PY * 8 - 1) / ((long)PY * 8);        // >= 8 pixels per thread (2 unrolled iterations)
+    const long cap = 2048 / *gx > 0 ? 2048 / *gx : 1;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     *gy = (int)g;

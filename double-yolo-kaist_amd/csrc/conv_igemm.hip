@@ -74,8 +74,10 @@ __device__ inline unsigned lds_addr_of(const void* p) {
     return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(DYK_AS3 const char*)p);
 }
 
-template <typename T, int BM, int BKB, bool DMA>
+// PIPE: 0 = register-staged double buffer, 2 / 3 = LDS-DMA ring of that many stages
+template <typename T, int BM, int BKB, int PIPE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
+    constexpr bool DMA = PIPE != 0;
     const DykConvDesc& a = args.d;
     constexpr int BN = 128;
     constexpr int EPV = 16 / (int)sizeof(T);
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
     constexpr int MI = WTM / 16, NI = WTN / 16;
     constexpr int KK = BKB / 64;
     constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
-    constexpr int NSTAGE = DMA ? 3 : 2;
+    constexpr int NSTAGE = DMA ? PIPE : 2;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;                               // [NSTAGE][A_BYTES]
@@ -239,22 +241,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
             stage(buf, sc0, st);
             if (++st == a.ntaps) { st = 0; sc0 += BK; }
         };
-        if (S > 0) stage_next(0);
-        if (S > 1) stage_next(1);
-        if (S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int cur = 0, nxt = 2;
-        for (int s = 0; s < S; ++s) {
-            const bool more = (s + 2 < S);
-            if (more) stage_next(nxt);
-            compute(sA + cur * A_BYTES, sB + cur * B_BYTES);
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        if constexpr (PIPE == 3) {
+            if (S > 0) stage_next(0);
+            if (S > 1) stage_next(1);
+            if (S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            cur = (cur == 2) ? 0 : cur + 1;
-            nxt = (nxt == 2) ? 0 : nxt + 1;
+            int cur = 0, nxt = 2;
+            for (int s = 0; s < S; ++s) {
+                const bool more = (s + 2 < S);
+                if (more) stage_next(nxt);
+                compute(sA + cur * A_BYTES, sB + cur * B_BYTES);
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                cur = (cur == 2) ? 0 : cur + 1;
+                nxt = (nxt == 2) ? 0 : nxt + 1;
+            }
+        } else {
+            // 2-stage ring for short K loops (1x1 convs, small Cin): half the LDS, 2-3x the resident
+            // workgroups per CU -- latency is hidden across workgroups instead of inside one
+            if (S > 0) stage_next(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int s = 0; s < S; ++s) {
+                if (s + 1 < S) stage_next((s + 1) & 1);
+                compute(sA + (s & 1) * A_BYTES, sB + (s & 1) * B_BYTES);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
         }
     } else {
     // ---- register-staged pipeline (global -> VGPR -> LDS), double-buffered
@@ -423,12 +440,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
     }
 }
 
-template <typename T, int BM, int BKB, bool DMA>
+template <typename T, int BM, int BKB, int PIPE>
 int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     constexpr int BN = 128;
-    constexpr size_t lds = (DMA ? 3 : 2) * (size_t)(BM + BN) * BKB + BN * (3 * sizeof(int) + 2 * sizeof(short)) + 1024 + 4 * 32 * sizeof(int);
+    constexpr size_t lds = (PIPE ? PIPE : 2) * (size_t)(BM + BN) * BKB + BN * (3 * sizeof(int) + 2 * sizeof(short)) + 1024 + 4 * 32 * sizeof(int);
     static bool attr_set = false;
-    auto kfn = conv_igemm_kernel<T, BM, BKB, DMA>;
+    auto kfn = conv_igemm_kernel<T, BM, BKB, PIPE>;
     if (!attr_set) {
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -458,14 +475,18 @@ inline bool use_dma() {
 
 template <typename T, int BM, int BKB>
 int launch_conv(const DykConvDesc* d, hipStream_t stream) {
-    return use_dma() ? launch_conv_impl<T, BM, BKB, true>(d, stream) : launch_conv_impl<T, BM, BKB, false>(d, stream);
+    if (!use_dma()) return launch_conv_impl<T, BM, BKB, 0>(d, stream);
+    const int steps = (d->Cin * (int)sizeof(T) / BKB) * d->ntaps;
+    return steps > 4 ? launch_conv_impl<T, BM, BKB, 3>(d, stream) : launch_conv_impl<T, BM, BKB, 2>(d, stream);
 }
 
 template <typename T>
 int dispatch_conv(const DykConvDesc* d, hipStream_t stream) {
     const int row_bytes = d->Cin * (int)sizeof(T);
-    const bool k128 = (row_bytes % 128) == 0;
-    if (!k128 && (row_bytes % 64) != 0) return DYK_ERR_ARG;
+    if ((row_bytes % 64) != 0) return DYK_ERR_ARG;
+    // short K loops (<= 4 steps of 128 B) are latency/HBM bound: use 64-byte K steps and the 2-stage
+    // ring so that 4-6 workgroups fit a CU; long loops use 128-byte steps and the 3-stage ring
+    const bool k128 = (row_bytes % 128) == 0 && (row_bytes / 128) * d->ntaps > 4;
     const int bm = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
     if (k128) {
         if (bm == 128) return launch_conv<T, 128, 128>(d, stream);

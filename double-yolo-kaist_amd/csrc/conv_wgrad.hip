@@ -15,6 +15,7 @@
 //
 // Replaces autograd's convolution_backward (weight gradient) for nn.Conv2d at reference
 // models.py:34-42.
+#include <stdlib.h>
 #include "dyk_common.h"
 
 namespace {
@@ -41,20 +42,41 @@ template <typename T, int C> __device__ inline int wg_off(int row, int ch) {
     }
 }
 
-template <typename T, int BM, int BN>
+// one LDS-DMA wave instruction (see conv_igemm.hip: issued via inline asm so that hipcc does not
+// drain vmcnt(0) in front of every LDS read while the ring is in flight)
+__device__ uint4 dyk_wg_zero_page[8];
+__device__ inline void wg_glds16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+__device__ inline unsigned wg_lds_addr(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(LDS_AS const char*)p);
+}
+
+// logical channel stored at physical 16-byte slot `ps` of tile row `row` (inverse of wg_off's swizzle,
+// which is an XOR on the 32-byte (bf16) / 64-byte (f32) chunk index and therefore its own inverse)
+template <typename T, int C> __device__ inline int wg_logical_ch(int row, int ps) {
+    constexpr int EPV = 16 / (int)sizeof(T);
+    return (wg_off<T, C>(row, ps * EPV) - row * C * (int)sizeof(T)) / (int)sizeof(T);
+}
+
+template <typename T, int BM, int BN, bool DMA>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, const int splits, const int chunk) {
     constexpr int ROWS = WgTraits<T>::ROWS;
     constexpr int EPV = 16 / (int)sizeof(T);
     constexpr int VPR_A = BM / EPV, VPR_B = BN / EPV;          // 16-byte vectors per tile row
     constexpr int NV_A = ROWS * VPR_A, NV_B = ROWS * VPR_B;
-    constexpr int NPA = (NV_A + 255) / 256, NPB = (NV_B + 255) / 256;
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int MI = WTM / 16, NI = WTN / 16;
     constexpr int A_BYTES = ROWS * BM * (int)sizeof(T), B_BYTES = ROWS * BN * (int)sizeof(T);
+    constexpr int NSTAGE = DMA ? 3 : 2;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                    // [2][A_BYTES]  dy tile
-    char* sB = smem + 2 * A_BYTES;      // [2][B_BYTES]  x tile
+    char* sA = smem;                         // [NSTAGE][A_BYTES]  dy tile
+    char* sB = smem + NSTAGE * A_BYTES;      // [NSTAGE][B_BYTES]  x tile
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -73,62 +95,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
     const int p_end = min(Ntot, p_begin + chunk);
     if (p_begin >= p_end) return;
     const int tdy = a.tdy[tap], tdx = a.tdx[tap];
-
-    // ---- loader state: each thread owns NPA dy vectors and NPB x vectors per step
     const T* __restrict__ dyg = (const T*)a.dy;
     const T* __restrict__ xg = (const T*)a.x;
-    int a_row[NPA], a_ch[NPA];
-    int b_row[NPB], b_ch[NPB];
-    int b_img[NPB], b_yo[NPB], b_xo[NPB];      // decomposition of the pixel of row b_row at step 0
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) {
-        const int v = i * 256 + tid;
-        a_row[i] = v / VPR_A; a_ch[i] = (v % VPR_A) * EPV;
-    }
-#pragma unroll
-    for (int i = 0; i < NPB; ++i) {
-        const int v = i * 256 + tid;
-        b_row[i] = v / VPR_B; b_ch[i] = (v % VPR_B) * EPV;
-        const int n = p_begin + b_row[i];
-        const int b = n / HWo, r = n - b * HWo;
-        b_img[i] = b; b_yo[i] = r / a.Wo; b_xo[i] = r - b_yo[i] * a.Wo;
-    }
-    uint4 ra[NPA], rb[NPB];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-    auto gload = [&](int p0) {
-#pragma unroll
-        for (int i = 0; i < NPA; ++i) {
-            const int n = p0 + a_row[i];
-            const int c = m0 + a_ch[i];
-            const bool ok = (NV_A % 256 == 0 || i * 256 + tid < NV_A) && n < p_end && c < a.Cout;
-            ra[i] = ok ? *(const uint4*)(dyg + (long)n * a.lddy + c) : zero4;
-        }
-#pragma unroll
-        for (int i = 0; i < NPB; ++i) {
-            const int n = p0 + b_row[i];
-            const int c = n0 + b_ch[i];
-            const int yi = b_yo[i] * a.isy + tdy, xi = b_xo[i] * a.isx + tdx;
-            const bool ok = (NV_B % 256 == 0 || i * 256 + tid < NV_B) && n < p_end && c < a.Cin &&
-                            ((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi);
-            rb[i] = ok ? *(const uint4*)(xg + ((long)(b_img[i] * a.Hi + yi) * a.Wi + xi) * a.ldx + c) : zero4;
-            // advance the pixel decomposition by ROWS for the next step
-            int xo = b_xo[i] + ROWS, yo = b_yo[i], bb = b_img[i];
-            while (xo >= a.Wo) { xo -= a.Wo; ++yo; }
-            while (yo >= a.Ho) { yo -= a.Ho; ++bb; }
-            b_xo[i] = xo; b_yo[i] = yo; b_img[i] = bb;
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NPA; ++i)
-            if (NV_A % 256 == 0 || i * 256 + tid < NV_A)
-                *(uint4*)(sA + buf * A_BYTES + wg_off<T, BM>(a_row[i], a_ch[i])) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NPB; ++i)
-            if (NV_B % 256 == 0 || i * 256 + tid < NV_B)
-                *(uint4*)(sB + buf * B_BYTES + wg_off<T, BN>(b_row[i], b_ch[i])) = rb[i];
-    };
 
     f32x4_t acc[MI][NI];
 #pragma unroll
@@ -136,17 +104,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    const int S = (p_end - p_begin + ROWS - 1) / ROWS;
-    gload(p_begin);
-    lstore(0);
-    __syncthreads();
-    for (int s = 0; s < S; ++s) {
-        const bool more = (s + 1 < S);
-        if (more) gload(p_begin + (s + 1) * ROWS);
-        const char* pa = sA + (s & 1) * A_BYTES;
-        const char* pb = sB + (s & 1) * B_BYTES;
+    auto compute = [&](const char* pa, const char* pb) {
+        const int i16 = lane & 15, kq = lane >> 4;
         if constexpr (sizeof(T) == 2) {
-            const int i16 = lane & 15, kq = lane >> 4;
 #pragma unroll
             for (int kk = 0; kk < ROWS / 32; ++kk) {
                 uint4 fa[MI], fb[NI];
@@ -175,7 +135,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
                             __builtin_bit_cast(bf16x8_t, fa[mi]), __builtin_bit_cast(bf16x8_t, fb[ni]), acc[mi][ni], 0, 0, 0);
             }
         } else {
-            const int i16 = lane & 15, kq = lane >> 4;
 #pragma unroll
             for (int kk = 0; kk < ROWS / 4; ++kk) {
                 float fa[MI], fb[NI];
@@ -193,8 +152,138 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
             }
         }
-        if (more) lstore((s + 1) & 1);
+    };
+
+    const int S = (p_end - p_begin + ROWS - 1) / ROWS;
+    if constexpr (DMA) {
+        // ---- 3-stage LDS-DMA ring; each wave instruction fills RPI consecutive pixel rows of a tile
+        constexpr int RPI_A = 64 / VPR_A, RPI_B = 64 / VPR_B;
+        constexpr int NI_A = A_BYTES / 1024, NI_B = B_BYTES / 1024;         // both multiples of 4
+        constexpr int NIA_W = NI_A / 4, NIB_W = NI_B / 4;
+        constexpr int NPW = NIA_W + NIB_W;
+        const int wv = __builtin_amdgcn_readfirstlane(wid);
+        const T* zero = (const T*)dyk_wg_zero_page;
+        int a_row[NIA_W], a_ch[NIA_W];
+#pragma unroll
+        for (int j = 0; j < NIA_W; ++j) {
+            a_row[j] = (j * 4 + wv) * RPI_A + lane / VPR_A;
+            a_ch[j] = wg_logical_ch<T, BM>(a_row[j], lane % VPR_A);
+        }
+        int b_row[NIB_W], b_ch[NIB_W], b_img[NIB_W], b_yo[NIB_W], b_xo[NIB_W];
+#pragma unroll
+        for (int j = 0; j < NIB_W; ++j) {
+            b_row[j] = (j * 4 + wv) * RPI_B + lane / VPR_B;
+            b_ch[j] = wg_logical_ch<T, BN>(b_row[j], lane % VPR_B);
+            const int n = p_begin + b_row[j];
+            const int b = n / HWo, r = n - b * HWo;
+            b_img[j] = b; b_yo[j] = r / a.Wo; b_xo[j] = r - b_yo[j] * a.Wo;
+        }
+        int sp0 = p_begin;                       // first pixel of the next step to stage
+        auto stage_next = [&](int buf) {
+            char* da = sA + buf * A_BYTES;
+            char* db = sB + buf * B_BYTES;
+#pragma unroll
+            for (int j = 0; j < NIA_W; ++j) {
+                const int n = sp0 + a_row[j];
+                const int c = m0 + a_ch[j];
+                const T* src = (n < p_end && c < a.Cout) ? dyg + (long)n * a.lddy + c : zero;
+                wg_glds16(src, wg_lds_addr(da + (j * 4 + wv) * 1024));
+            }
+#pragma unroll
+            for (int j = 0; j < NIB_W; ++j) {
+                const int n = sp0 + b_row[j];
+                const int c = n0 + b_ch[j];
+                const int yi = b_yo[j] * a.isy + tdy, xi = b_xo[j] * a.isx + tdx;
+                const bool ok = n < p_end && c < a.Cin && ((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi);
+                const T* src = ok ? xg + ((long)(b_img[j] * a.Hi + yi) * a.Wi + xi) * a.ldx + c : zero;
+                wg_glds16(src, wg_lds_addr(db + (j * 4 + wv) * 1024));
+                int xo = b_xo[j] + ROWS, yo = b_yo[j], bb = b_img[j];
+                while (xo >= a.Wo) { xo -= a.Wo; ++yo; }
+                while (yo >= a.Ho) { yo -= a.Ho; ++bb; }
+                b_xo[j] = xo; b_yo[j] = yo; b_img[j] = bb;
+            }
+            sp0 += ROWS;
+        };
+        stage_next(0);
+        if (S > 1) stage_next(1);
+        if (S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0, nxt = 2;
+        for (int s = 0; s < S; ++s) {
+            const bool more = (s + 2 < S);
+            if (more) stage_next(nxt);
+            compute(sA + cur * A_BYTES, sB + cur * B_BYTES);
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur = (cur == 2) ? 0 : cur + 1;
+            nxt = (nxt == 2) ? 0 : nxt + 1;
+        }
+    } else {
+        // ---- register-staged double buffer
+        constexpr int NPA = (NV_A + 255) / 256, NPB = (NV_B + 255) / 256;
+        int a_row[NPA], a_ch[NPA];
+        int b_row[NPB], b_ch[NPB];
+        int b_img[NPB], b_yo[NPB], b_xo[NPB];
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int v = i * 256 + tid;
+            a_row[i] = v / VPR_A; a_ch[i] = (v % VPR_A) * EPV;
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int v = i * 256 + tid;
+            b_row[i] = v / VPR_B; b_ch[i] = (v % VPR_B) * EPV;
+            const int n = p_begin + b_row[i];
+            const int b = n / HWo, r = n - b * HWo;
+            b_img[i] = b; b_yo[i] = r / a.Wo; b_xo[i] = r - b_yo[i] * a.Wo;
+        }
+        uint4 ra[NPA], rb[NPB];
+        const uint4 zero4 = make_uint4(0, 0, 0, 0);
+        auto gload = [&](int p0) {
+#pragma unroll
+            for (int i = 0; i < NPA; ++i) {
+                const int n = p0 + a_row[i];
+                const int c = m0 + a_ch[i];
+                const bool ok = (NV_A % 256 == 0 || i * 256 + tid < NV_A) && n < p_end && c < a.Cout;
+                ra[i] = ok ? *(const uint4*)(dyg + (long)n * a.lddy + c) : zero4;
+            }
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) {
+                const int n = p0 + b_row[i];
+                const int c = n0 + b_ch[i];
+                const int yi = b_yo[i] * a.isy + tdy, xi = b_xo[i] * a.isx + tdx;
+                const bool ok = (NV_B % 256 == 0 || i * 256 + tid < NV_B) && n < p_end && c < a.Cin &&
+                                ((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi);
+                rb[i] = ok ? *(const uint4*)(xg + ((long)(b_img[i] * a.Hi + yi) * a.Wi + xi) * a.ldx + c) : zero4;
+                int xo = b_xo[i] + ROWS, yo = b_yo[i], bb = b_img[i];
+                while (xo >= a.Wo) { xo -= a.Wo; ++yo; }
+                while (yo >= a.Ho) { yo -= a.Ho; ++bb; }
+                b_xo[i] = xo; b_yo[i] = yo; b_img[i] = bb;
+            }
+        };
+        auto lstore = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < NPA; ++i)
+                if (NV_A % 256 == 0 || i * 256 + tid < NV_A)
+                    *(uint4*)(sA + buf * A_BYTES + wg_off<T, BM>(a_row[i], a_ch[i])) = ra[i];
+#pragma unroll
+            for (int i = 0; i < NPB; ++i)
+                if (NV_B % 256 == 0 || i * 256 + tid < NV_B)
+                    *(uint4*)(sB + buf * B_BYTES + wg_off<T, BN>(b_row[i], b_ch[i])) = rb[i];
+        };
+        gload(p_begin);
+        lstore(0);
         __syncthreads();
+        for (int s = 0; s < S; ++s) {
+            const bool more = (s + 1 < S);
+            if (more) gload(p_begin + (s + 1) * ROWS);
+            compute(sA + (s & 1) * A_BYTES, sB + (s & 1) * B_BYTES);
+            if (more) lstore((s + 1) & 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: acc[r] = D[co = (lane>>4)*4 + r][ci = lane&15]
@@ -215,12 +304,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
     }
 }
 
-template <typename T, int BM, int BN>
-int launch_wgrad(const DykWgradDesc* d, hipStream_t stream) {
+inline bool wg_use_dma() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DYK_CONV_PIPE");
+        v = (e && e[0] == 'r') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+template <typename T, int BM, int BN, bool DMA>
+int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream) {
     constexpr int ROWS = WgTraits<T>::ROWS;
-    constexpr size_t lds = 2 * (size_t)ROWS * (BM + BN) * sizeof(T);
+    constexpr size_t lds = (DMA ? 3 : 2) * (size_t)ROWS * (BM + BN) * sizeof(T);
     static bool attr_set = false;
-    auto kfn = conv_wgrad_kernel<T, BM, BN>;
+    auto kfn = conv_wgrad_kernel<T, BM, BN, DMA>;
     if (!attr_set) {
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -240,6 +338,11 @@ int launch_wgrad(const DykWgradDesc* d, hipStream_t stream) {
     hipLaunchKernelGGL(kfn, dim3(tiles * splits), dim3(256), lds, stream, *d, splits, chunk);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
+}
+
+template <typename T, int BM, int BN>
+int launch_wgrad(const DykWgradDesc* d, hipStream_t stream) {
+    return wg_use_dma() ? launch_wgrad_impl<T, BM, BN, true>(d, stream) : launch_wgrad_impl<T, BM, BN, false>(d, stream);
 }
 
 template <typename T, int BM>
