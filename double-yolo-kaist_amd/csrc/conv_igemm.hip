@@ -477,7 +477,12 @@ template <typename T, int BM, int BKB>
 int launch_conv(const DykConvDesc* d, hipStream_t stream) {
     if (!use_dma()) return launch_conv_impl<T, BM, BKB, 0>(d, stream);
     const int steps = (d->Cin * (int)sizeof(T) / BKB) * d->ntaps;
-    return steps > 4 ? launch_conv_impl<T, BM, BKB, 3>(d, stream) : launch_conv_impl<T, BM, BKB, 2>(d, stream);
+    static int force_pipe = -1;
+    if (force_pipe < 0) { const char* e = getenv("DYK_CONV_FORCE_PIPE"); force_pipe = e ? atoi(e) : 0; }
+    int pipe = force_pipe ? force_pipe : 2;      // 2-stage ring: 2-4 resident workgroups per CU beat a deeper ring
+    if ((d->tune >> 8) == 2 || (d->tune >> 8) == 3) pipe = d->tune >> 8;
+    (void)steps;
+    return pipe == 3 ? launch_conv_impl<T, BM, BKB, 3>(d, stream) : launch_conv_impl<T, BM, BKB, 2>(d, stream);
 }
 
 template <typename T>
@@ -486,7 +491,14 @@ int dispatch_conv(const DykConvDesc* d, hipStream_t stream) {
     if ((row_bytes % 64) != 0) return DYK_ERR_ARG;
     // short K loops (<= 4 steps of 128 B) are latency/HBM bound: use 64-byte K steps and the 2-stage
     // ring so that 4-6 workgroups fit a CU; long loops use 128-byte steps and the 3-stage ring
-    const bool k128 = (row_bytes % 128) == 0 && (row_bytes / 128) * d->ntaps > 4;
+    static int force_bkb = -1;
+    if (force_bkb < 0) { const char* e = getenv("DYK_CONV_FORCE_BKB"); force_bkb = e ? atoi(e) : 0; }
+    bool k128 = (row_bytes % 128) == 0 && (row_bytes / 128) * d->ntaps > 4;
+    if (row_bytes % 128 == 0 && (row_bytes / 128) * d->ntaps > 4) k128 = d->Cin >= 512;   // measured: see DESIGN.md
+    if (force_bkb == 64) k128 = false;
+    if (force_bkb == 128 && (row_bytes % 128) == 0) k128 = true;
+    if ((d->tune & 0xff) == 64) k128 = false;
+    if ((d->tune & 0xff) == 128 && (row_bytes % 128) == 0) k128 = true;
     const int bm = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
     if (k128) {
         if (bm == 128) return launch_conv<T, 128, 128>(d, stream);

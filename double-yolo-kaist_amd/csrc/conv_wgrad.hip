@@ -63,7 +63,8 @@ template <typename T, int C> __device__ inline int wg_logical_ch(int row, int ps
     return (wg_off<T, C>(row, ps * EPV) - row * C * (int)sizeof(T)) / (int)sizeof(T);
 }
 
-template <typename T, int BM, int BN, bool DMA>
+// PIPE: 0 = register-staged double buffer, 2 / 3 = LDS-DMA ring stages
+template <typename T, int BM, int BN, int PIPE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, const int splits, const int chunk) {
     constexpr int ROWS = WgTraits<T>::ROWS;
     constexpr int EPV = 16 / (int)sizeof(T);
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int MI = WTM / 16, NI = WTN / 16;
     constexpr int A_BYTES = ROWS * BM * (int)sizeof(T), B_BYTES = ROWS * BN * (int)sizeof(T);
-    constexpr int NSTAGE = DMA ? 3 : 2;
+    constexpr bool DMA = PIPE != 0;
+    constexpr int NSTAGE = DMA ? PIPE : 2;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;                         // [NSTAGE][A_BYTES]  dy tile
@@ -204,22 +206,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
             }
             sp0 += ROWS;
         };
-        stage_next(0);
-        if (S > 1) stage_next(1);
-        if (S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int cur = 0, nxt = 2;
-        for (int s = 0; s < S; ++s) {
-            const bool more = (s + 2 < S);
-            if (more) stage_next(nxt);
-            compute(sA + cur * A_BYTES, sB + cur * B_BYTES);
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        if constexpr (PIPE == 3) {
+            stage_next(0);
+            if (S > 1) stage_next(1);
+            if (S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            cur = (cur == 2) ? 0 : cur + 1;
-            nxt = (nxt == 2) ? 0 : nxt + 1;
+            int cur = 0, nxt = 2;
+            for (int s = 0; s < S; ++s) {
+                const bool more = (s + 2 < S);
+                if (more) stage_next(nxt);
+                compute(sA + cur * A_BYTES, sB + cur * B_BYTES);
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                cur = (cur == 2) ? 0 : cur + 1;
+                nxt = (nxt == 2) ? 0 : nxt + 1;
+            }
+        } else {
+            stage_next(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int s = 0; s < S; ++s) {
+                if (s + 1 < S) stage_next((s + 1) & 1);
+                compute(sA + (s & 1) * A_BYTES, sB + (s & 1) * B_BYTES);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
         }
     } else {
         // ---- register-staged double buffer
@@ -313,12 +328,12 @@ inline bool wg_use_dma() {
     return v == 1;
 }
 
-template <typename T, int BM, int BN, bool DMA>
+template <typename T, int BM, int BN, int PIPE>
 int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream) {
     constexpr int ROWS = WgTraits<T>::ROWS;
-    constexpr size_t lds = (DMA ? 3 : 2) * (size_t)ROWS * (BM + BN) * sizeof(T);
+    constexpr size_t lds = (PIPE ? PIPE : 2) * (size_t)ROWS * (BM + BN) * sizeof(T);
     static bool attr_set = false;
-    auto kfn = conv_wgrad_kernel<T, BM, BN, DMA>;
+    auto kfn = conv_wgrad_kernel<T, BM, BN, PIPE>;
     if (!attr_set) {
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -328,8 +343,8 @@ int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream) {
     const int ksteps = dyk_div_up(Ntot, ROWS);
     int splits = d->splits;
     if (splits <= 0) {
-        splits = dyk_div_up(1536, tiles);            // ~6 blocks per CU
-        const int max_splits = ksteps / 4 > 0 ? ksteps / 4 : 1;   // at least 4 K steps per block
+        splits = dyk_div_up(768, tiles);             // ~3 workgroups per CU
+        const int max_splits = ksteps / 8 > 0 ? ksteps / 8 : 1;   // at least 8 K steps per workgroup (amortise the atomics)
         if (splits > max_splits) splits = max_splits;
     }
     if (splits > ksteps) splits = ksteps;
@@ -342,7 +357,8 @@ int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream) {
 
 template <typename T, int BM, int BN>
 int launch_wgrad(const DykWgradDesc* d, hipStream_t stream) {
-    return wg_use_dma() ? launch_wgrad_impl<T, BM, BN, true>(d, stream) : launch_wgrad_impl<T, BM, BN, false>(d, stream);
+    if (!wg_use_dma()) return launch_wgrad_impl<T, BM, BN, 0>(d, stream);
+    return d->tune == 3 ? launch_wgrad_impl<T, BM, BN, 3>(d, stream) : launch_wgrad_impl<T, BM, BN, 2>(d, stream);
 }
 
 template <typename T, int BM>

@@ -43,7 +43,7 @@ class DykConvDesc(ctypes.Structure):
         ("isy", _i32), ("isx", _i32), ("osy", _i32), ("osx", _i32), ("ooy", _i32), ("oox", _i32),
         ("ntaps", _i32),
         ("tdy", _i8 * MAX_TAPS), ("tdx", _i8 * MAX_TAPS), ("twt", _i8 * MAX_TAPS), ("_pad", _i8),
-        ("act", _i32), ("flags", _i32), ("stats_slots", _i32),
+        ("act", _i32), ("flags", _i32), ("stats_slots", _i32), ("tune", _i32),
     ]
 
 
@@ -54,7 +54,7 @@ class DykWgradDesc(ctypes.Structure):
         ("B", _i32), ("Hi", _i32), ("Wi", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32), ("Cout", _i32),
         ("isy", _i32), ("isx", _i32), ("ntaps", _i32),
         ("tdy", _i8 * MAX_TAPS), ("tdx", _i8 * MAX_TAPS), ("twt", _i8 * MAX_TAPS), ("_pad", _i8),
-        ("splits", _i32), ("lddw", _i32),
+        ("splits", _i32), ("lddw", _i32), ("tune", _i32),
     ]
 
 

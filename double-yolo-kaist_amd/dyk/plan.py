@@ -645,6 +645,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device):
     for fn in pending:
         fn()
     plan.finalize()
+    if os.environ.get("DYK_AUTOTUNE", "1") != "0":
+        autotune(plan, getattr(model, "_dyk_tune_cache", None))
     plan.info = info
     plan.grads = grads if training else {}
     plan.outs = outs
@@ -652,3 +654,60 @@ def compile_plan(model, store, B, H, W, dtype, training, device):
     plan.dtype = dtype
     plan.training = training
     return plan
+
+
+# ======================================================================================
+_CONV_CANDIDATES = [64 | (2 << 8), 64 | (3 << 8), 128 | (2 << 8), 128 | (3 << 8)]
+_WGRAD_CANDIDATES = [2, 3]
+
+
+def _time_launch(fn, desc, stream, reps=3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    L.check(fn(ctypes.byref(desc), stream), "autotune launch")          # warm-up (also loads the code object)
+    e0.record()
+    for _ in range(reps):
+        fn(ctypes.byref(desc), stream)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def autotune(plan, cache=None):
+    """Measure, don't guess: for every distinct convolution / weight-gradient problem of the plan, time
+    the tile configurations the kernels offer (K-step bytes x LDS ring depth) on the real buffers and
+    keep the fastest.  One-off cost at plan compilation (~0.2 s for the 46 problems of the target cfg)."""
+    lib = L.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    cache = cache if cache is not None else {}
+    groups = {}
+    for (op, d) in plan.fwd + plan.bwd:
+        if op == L.OP_CONV:
+            key = ("c", d.dtype, d.B, d.Cin, d.Cout, d.Hg, d.Wg, d.ntaps, d.isy, d.osy, d.flags & (L.EPI_STATS | L.EPI_OUT_F32))
+        elif op == L.OP_WGRAD:
+            key = ("w", d.dtype, d.B, d.Cin, d.Cout, d.Ho, d.Wo, d.ntaps, d.isy)
+        else:
+            continue
+        groups.setdefault(key, []).append(d)
+    for key, descs in groups.items():
+        best = cache.get(key)
+        if best is None:
+            d = descs[0]
+            if key[0] == "c":
+                es = 2 if d.dtype == L.DYK_BF16 else 4
+                cands = [c for c in _CONV_CANDIDATES if (c & 0xff) == 64 or (d.Cin * es) % 128 == 0]
+                fn = lib.dyk_conv_igemm
+            else:
+                cands, fn = _WGRAD_CANDIDATES, lib.dyk_conv_wgrad
+            times = []
+            for c in cands:
+                d.tune = c
+                times.append(_time_launch(fn, d, stream))
+            best = cands[times.index(min(times))]
+            cache[key] = best
+        for d in descs:
+            d.tune = best
+    plan.tuned = dict(cache)
+    # the trial launches polluted the statistics accumulators / scratch: reset
+    plan.arenas["ws"].tensor.zero_()
+    plan.arenas["grad"].tensor.zero_()
+    torch.cuda.synchronize()

@@ -102,6 +102,8 @@ typedef struct DykConvDesc {
     int32_t act;                    /* DYK_ACT_* applied after the affine */
     int32_t flags;                  /* DYK_EPI_* */
     int32_t stats_slots;            /* number of stats replicas (>= 1; 0 is read as 1) */
+    int32_t tune;                   /* 0 = built-in heuristic; else (K-step bytes: 64|128) | (LDS ring stages 2|3) << 8,
+                                       as chosen by the plan compiler's per-shape measurement */
 } DykConvDesc;
 
 int dyk_conv_igemm(const DykConvDesc* desc, void* stream);
@@ -129,6 +131,7 @@ typedef struct DykWgradDesc {
     int8_t _pad;
     int32_t splits;                 /* K splits; <= 0 selects automatically */
     int32_t lddw;                   /* row stride of dw in floats; <= 0 means Cin */
+    int32_t tune;                   /* 0 = default; else LDS ring stages (2 | 3) */
 } DykWgradDesc;
 
 int dyk_conv_wgrad(const DykWgradDesc* desc, void* stream);
