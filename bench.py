@@ -167,7 +167,16 @@ def main():
     if reducer is not None:
         opt.grad_scale = 1.0 / world
 
+    # first-epoch linear learning-rate warm-up of the reference harness (kaist_train_eval_utils.py:28-35,
+    # distributed_utils.py warmup_lr_scheduler: factor 1/1000 -> 1 over 1000 iterations).  On uniform-noise
+    # images a cold start at lr0 drives box sizes to 0 within a few steps, where the CIoU term atan(w/h) has
+    # a 0*inf gradient in the reference's own math (and here) -- the warm-up is what the reference trains with.
+    it = [0]
+
     def step():
+        alpha = min(it[0] / 1000.0, 1.0)
+        opt.param_groups[0]["lr"] = hyp["lr0"] * (0.001 * (1 - alpha) + alpha)
+        it[0] += 1
         v = v8.float() / 255.0                       # kaist_train_eval_utils.py:54-55
         l = l8.float() / 255.0
         pred = model(v, l)

@@ -25,6 +25,9 @@ struct ConvArgs {
     DykConvDesc d;
 };
 
+// bytes of the tables at the start of the workgroup's LDS (see kernel)
+constexpr int TABLE_BYTES = 128 * (3 * 4 + 2 * 2) + 1024 + 4 * 32 * 4 + 2 * 128 * 4;
+
 // set by the launcher when y / ldy allow 8/16-byte vector stores
 constexpr int EPI_INTERNAL_VEC = 1 << 30;
 
@@ -95,10 +98,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
     constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
     constexpr int NSTAGE = DMA ? PIPE : 2;
 
+    // LDS: [pixel / tap tables | dummy-DMA sink | stats scratch] then the operand ring, which the
+    // epilogue re-uses as the output staging tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                               // [NSTAGE][A_BYTES]
-    char* sB = smem + NSTAGE * A_BYTES;            // [NSTAGE][B_BYTES]
-    int* t_in = (int*)(smem + NSTAGE * (A_BYTES + B_BYTES));   // [BN] input base offset
+    int* t_in = (int*)smem;                   // [BN] input base offset
     int* t_out = t_in + BN;                   // [BN] output offset or -1
     int* t_res = t_out + BN;                  // [BN] residual offset
     short* t_y = (short*)(t_res + BN);        // [BN] input row of tap (0,0)
@@ -108,6 +111,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
     int* tap_w = tap_x + 32;                  // [32] weight element offset of a tap: twt*Cout*Cin
     int* tap_dy = tap_w + 32;                 // [32]
     int* tap_dx = tap_dy + 32;                // [32]
+    float* s_stat = (float*)(tap_dx + 32);    // [2][BM] per-workgroup channel sums (STATS epilogue)
+    char* sA = smem + TABLE_BYTES;                 // [NSTAGE][A_BYTES]
+    char* sB = sA + NSTAGE * A_BYTES;              // [NSTAGE][B_BYTES]
+    char* sC = sA;                                 // epilogue staging tile (overlays the ring)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -154,7 +161,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
 
     const T* __restrict__ xg = (const T*)a.x;
     const T* __restrict__ wg = (const T*)a.w;
-    const int S = (a.Cin / BK) * a.ntaps;
+    // bits 16.. of `tune` are ablation switches for kernel analysis (tools/gpu_probe.py ablate): never set by the plan
+    const bool abl_nostore = (a.tune >> 16) & 1, abl_noloop = (a.tune >> 17) & 1;
+    const int S = abl_noloop ? 0 : (a.Cin / BK) * a.ntaps;
     const int frow = lane & 15, fslot = lane >> 4;
 
     auto compute = [&](const char* pa, const char* pb) {
@@ -338,12 +347,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
     }
 
     // ------------------------------------------------------------------ epilogue
+    // (both pipelines leave the loop behind a workgroup barrier: the ring is free to be overwritten)
     const int flags = a.flags;
     const int mlane = (lane >> 4) * 4;
     if (flags & DYK_EPI_STATS) {
-        // per-channel sum / sum of squares of the raw accumulators over this wave's
-        // WTN pixels: reduce over ni in-lane, over the 16 pixel lanes by xor-shuffle,
-        // then one fp64 atomic per channel per wave.
+        // per-channel sum / sum of squares of the raw accumulators: in-lane over ni, xor-shuffle over the
+        // 16 pixel lanes, LDS atomics across the waves of the workgroup, then ONE fp64 atomic per channel
+        // and workgroup into a replica of the statistics buffer.
+        for (int i = tid; i < 2 * BM; i += 256) s_stat[i] = 0.f;
+        __syncthreads();
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -359,12 +371,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
                     s1 += __shfl_xor(s1, o, 64);
                     s2 += __shfl_xor(s2, o, 64);
                 }
-                const int m = m0 + wm * WTM + mi * 16 + mlane + r;
-                if ((lane & 15) == 0 && m < a.Cout) {
-                    double* st = a.stats + (size_t)(blockIdx.x % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
-                    atomicAdd(st + m, (double)s1);
-                    atomicAdd(st + a.Cout + m, (double)s2);
+                if ((lane & 15) == 0) {
+                    const int ml = wm * WTM + mi * 16 + mlane + r;
+                    atomicAdd(s_stat + ml, s1);
+                    atomicAdd(s_stat + BM + ml, s2);
                 }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BM) {
+            const int ml = tid % BM, which = tid / BM;
+            if (m0 + ml < a.Cout) {
+                double* st = a.stats + (size_t)(blockIdx.x % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
+                atomicAdd(st + which * a.Cout + m0 + ml, (double)s_stat[tid]);
             }
         }
     }
@@ -372,6 +391,103 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
     const bool has_res = flags & DYK_EPI_RESIDUAL;
     const bool accum = flags & DYK_EPI_ACCUM;
     const bool out_f32 = (flags & DYK_EPI_OUT_F32) || sizeof(T) == 4;
+
+    if (flags & EPI_INTERNAL_VEC) {
+        // ---- staged, coalesced store: accumulators -> LDS tile [pixel][channel] -> 16-byte global stores
+        // in which 16 consecutive lanes cover one contiguous channel row of a pixel (the per-lane 8-byte
+        // scatter of the MFMA layout wrote 32-byte fragments and cost 2-3x the store time).
+        const int eso = out_f32 ? 4 : 2;                  // output element size
+        const int rstride = BM * eso + 16;                // padded row stride (bytes)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int ml = wm * WTM + mi * 16 + mlane;
+            const int m = m0 + ml;
+            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+            if (affine) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < a.Cout) {
+                        if (a.scale) sc[r] = a.scale[m + r];
+                        if (a.shift) sh[r] = a.shift[m + r];
+                    }
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int nl = wn * WTN + ni * 16 + (lane & 15);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float u = acc[mi][ni][r];
+                    if (affine) u = u * sc[r] + sh[r];
+                    v[r] = act_fwd(a.act, u);
+                }
+                char* dst = sC + nl * rstride + ml * eso;
+                if (out_f32) {
+                    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *(uint2*)dst = pk;
+                }
+            }
+        }
+        __syncthreads();
+        const int epv_o = 16 / eso;                       // output elements per 16-byte chunk
+        const int cpr = BM / epv_o;                       // chunks per tile row
+        const int nchunk = BN * cpr;
+        for (int q = tid; q < nchunk; q += 256) {
+            const int row = q / cpr, cc = q - row * cpr;
+            const int po = t_out[row];
+            const int mc = m0 + cc * epv_o;
+            if (po < 0 || mc >= a.Cout) continue;
+            if (abl_nostore && t_out[0] != -12345) continue;
+            uint4 val = *(const uint4*)(sC + row * rstride + cc * 16);
+            const bool whole = (mc + epv_o <= a.Cout);
+            if (out_f32) {
+                float* yp = (float*)a.y + (long)po + mc;
+                float f[4] = {__uint_as_float(val.x), __uint_as_float(val.y), __uint_as_float(val.z), __uint_as_float(val.w)};
+                if (has_res) {
+                    const T* rp = (const T*)a.res + (long)t_res[row] + mc;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (mc + j < a.Cout) f[j] += ElemTraits<T>::to_f32(rp[j]);
+                }
+                if (accum) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (mc + j < a.Cout) f[j] += yp[j];
+                }
+                if (whole) *(float4*)yp = make_float4(f[0], f[1], f[2], f[3]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (mc + j < a.Cout) yp[j] = f[j];
+                }
+            } else {
+                bf16_t* yp = (bf16_t*)a.y + (long)po + mc;
+                if (has_res || accum || !whole) {
+                    float f[8];
+                    vec_unpack<bf16_t>(val, f);
+                    if (has_res) {
+                        const bf16_t* rp = (const bf16_t*)a.res + (long)t_res[row] + mc;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (mc + j < a.Cout) f[j] += bf16_to_f32(rp[j]);
+                    }
+                    if (accum) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (mc + j < a.Cout) f[j] += bf16_to_f32(yp[j]);
+                    }
+                    if (whole) *(uint4*)yp = vec_pack<bf16_t>(f);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (mc + j < a.Cout) yp[j] = f32_to_bf16(f[j]);
+                    }
+                } else {
+                    *(uint4*)yp = val;
+                }
+            }
+        }
+        return;
+    }
+    // ---- fallback: per-lane stores straight from the MFMA layout (unaligned / odd-stride outputs)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + wm * WTM + mi * 16 + mlane;
@@ -385,7 +501,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
                     if (a.shift) sh[r] = a.shift[m + r];
                 }
         }
-        const bool full = (m + 3 < a.Cout) && (flags & EPI_INTERNAL_VEC);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int nl = wn * WTN + ni * 16 + (lane & 15);
@@ -406,35 +521,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
             }
             if (out_f32) {
                 float* yp = (float*)a.y + (long)po + m;
-                if (accum) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (m + r < a.Cout) v[r] += yp[r];
-                }
-                if (full) {
-                    *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (m + r < a.Cout) yp[r] = v[r];
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < a.Cout) yp[r] = accum ? yp[r] + v[r] : v[r];
             } else {
                 bf16_t* yp = (bf16_t*)a.y + (long)po + m;
-                if (accum) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (m + r < a.Cout) v[r] += bf16_to_f32(yp[r]);
-                }
-                if (full) {
-                    uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    *(uint2*)yp = pk;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (m + r < a.Cout) yp[r] = f32_to_bf16(v[r]);
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < a.Cout) yp[r] = f32_to_bf16(accum ? bf16_to_f32(yp[r]) + v[r] : v[r]);
             }
         }
     }
@@ -443,11 +537,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
 template <typename T, int BM, int BKB, int PIPE>
 int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     constexpr int BN = 128;
-    constexpr size_t lds = (PIPE ? PIPE : 2) * (size_t)(BM + BN) * BKB + BN * (3 * sizeof(int) + 2 * sizeof(short)) + 1024 + 4 * 32 * sizeof(int);
+    constexpr size_t ring = (PIPE ? PIPE : 2) * (size_t)(BM + BN) * BKB;
+    const bool of32 = (d->flags & DYK_EPI_OUT_F32) || sizeof(T) == 4;
+    const size_t stage_c = (size_t)BN * (BM * (of32 ? 4 : 2) + 16);
+    const size_t lds = TABLE_BYTES + (ring > stage_c ? ring : stage_c);
     static bool attr_set = false;
     auto kfn = conv_igemm_kernel<T, BM, BKB, PIPE>;
     if (!attr_set) {
-        DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        constexpr size_t lds_max = TABLE_BYTES + (ring > (size_t)BN * (BM * 4 + 16) ? ring : (size_t)BN * (BM * 4 + 16));
+        DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_set = true;
     }
     const long Ntot = (long)d->B * d->Hg * d->Wg;
@@ -455,8 +553,14 @@ int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     const int tiles_m = dyk_div_up(d->Cout, BM);
     ConvArgs args;
     args.d = *d;
-    const size_t vec_bytes = ((d->flags & DYK_EPI_OUT_F32) || sizeof(T) == 4) ? 16 : 8;
-    if ((d->ldy % 4) == 0 && ((uintptr_t)d->y % vec_bytes) == 0) args.d.flags |= EPI_INTERNAL_VEC;
+    // the staged epilogue needs 16-byte aligned pixel rows of the output (and residual)
+    const int eso = of32 ? 4 : 2;
+    bool vec = ((size_t)d->ldy * eso) % 16 == 0 && ((uintptr_t)d->y % 16) == 0;
+    if ((d->flags & DYK_EPI_RESIDUAL) && (((size_t)d->ldr * sizeof(T)) % 16 != 0 || ((uintptr_t)d->res % 16) != 0)) vec = false;
+    static int force_scatter = -1;
+    if (force_scatter < 0) { const char* e = getenv("DYK_CONV_EPI"); force_scatter = (e && e[0] == 's') ? 1 : 0; }
+    if (force_scatter) vec = false;
+    if (vec) args.d.flags |= EPI_INTERNAL_VEC;
     else args.d.flags &= ~EPI_INTERNAL_VEC;
     hipLaunchKernelGGL(kfn, dim3(tiles_n * tiles_m), dim3(256), lds, stream, args);
     DYK_LAUNCH_CHECK();

@@ -88,6 +88,37 @@ if "convbench" in what:
             print(rows[-1], flush=True)
     res["convbench"] = rows
 
+if "ablate" in what:
+    import ctypes as C
+    from dyk import lib as L
+    rows = []
+    for (ci, co, H, W, k) in [(128, 128, 64, 80, 1), (64, 64, 256, 320, 1), (256, 256, 32, 40, 1), (128, 128, 64, 80, 3)]:
+        B, dt = 16, torch.bfloat16
+        x = torch.randn(B, H, W, ci, device="cuda").to(dt)
+        w = torch.randn(co, ci, k, k, device="cuda") * 0.05
+        wp = ops.pack_weight(w, dt)
+        out = torch.empty(B, H, W, co, device="cuda", dtype=dt)
+        stats = torch.zeros(64 * co, dtype=torch.float64, device="cuda")
+        for name, tune, st in [("default", 0, None), ("stats", 0, stats), ("nostore", 1 << 16, None), ("noloop", 1 << 17, None),
+                               ("noloop+nostore", 3 << 16, None), ("bkb128", 128 | (2 << 8), None), ("bkb64p3", 64 | (3 << 8), None)]:
+            d = ops.make_conv_desc(x, wp, out, Hi=H, Wi=W, Cin=ci, Cout=co, Hg=H, Wg=W, Ho=H, Wo=W, taps=ops.fwd_taps(k, k // 2), stats=st)
+            d.tune = tune
+            d.stats_slots = 32 if st is not None else 0
+            fn = L.load().dyk_conv_igemm
+            for _ in range(3):
+                fn(C.byref(d), None)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn(C.byref(d), None)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            by = (x.numel() + out.numel()) * 2
+            rows.append((ci, co, H, k, name, round(ms * 1e3, 1), round(by / ms / 1e6)))
+            print(rows[-1], flush=True)
+    res["ablate"] = rows
+
 with open(os.path.join(OUT, "probe.json"), "w") as f:
     json.dump(res, f, indent=1)
 print("wrote probe.json")
