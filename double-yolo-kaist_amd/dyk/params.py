@@ -164,6 +164,20 @@ class ParamStore:
     def version_key(self):
         return (sum(e.param._version for e in self.entries), self._dirty)
 
+    def alloc_compute(self, dtype):
+        """allocate (without filling) the compute-dtype staging buffers; used by dry plan compilation"""
+        st = {"stems": {}, "heads_t": {}, "version": None}
+        st["Wc"] = self.P if dtype == torch.float32 else torch.empty(self.total, dtype=dtype, device=self.device)
+        st["Wt"] = torch.zeros(self.total, dtype=dtype, device=self.device)
+        for e in self.entries:
+            if e.kind == "stem_w":
+                co, ci, kh, kw = e.shape
+                st["stems"][e.name] = torch.zeros((co, _round_up(ci * kh * kw, 32)), dtype=dtype, device=self.device)
+            elif e.kind == "conv_w" and e.shape[0] % 32:
+                co, ci, kh, kw = e.shape
+                st["heads_t"][e.name] = torch.zeros((ci, _round_up(co, 32)), dtype=dtype, device=self.device)
+        return st
+
     def compute_weights(self, dtype, force=False, skip_cast=False):
         """Return dict(Wc=<tensor same offsets as P>, Wt=<transposed per tap>, stems={name: tensor})
         for the compute dtype, refreshed iff the master buffer changed since the last call."""

