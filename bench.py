@@ -95,20 +95,20 @@ def profile_plan(plan, stream, dump=None):
     return res
 
 
-def cpu_baseline(cfg_name, steps=1):
+def cpu_baseline(cfg_name, steps=6):
     """oracle (CPU restatement of the reference's train step: forward + loss + backward) on B=2, 512x640"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from build_utils.parse_config import sections_from_json
     from oracle.model import OracleNet
     from oracle import loss as oloss
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 32)      # beyond ~32 threads the many small CPU convs only oversubscribe
     torch.set_num_threads(threads)
     net = OracleNet(sections_from_json(os.path.join(PKG, "config", "netdefs", cfg_name + ".json")), "config/%s.cfg" % cfg_name)
     sd = net.synth_state(0)
     for k, v in sd.items():
         if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
             v.requires_grad_(True)
-    B = 2
+    B = 1
     v, l, t = synth_batch(B, 512, 640, 0, "cpu")
     hyp = load_hyp()
     av = net.anchor_vecs()

@@ -11,20 +11,22 @@
 
 namespace {
 
-__global__ void bn_finalize_kernel(DykBnFinalizeDesc d) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// 32 lanes per channel: lane r sums replicas r, r+32, ... , a 5-step xor-shuffle folds them, lane 0 finalises
+__global__ __launch_bounds__(256) void bn_finalize_kernel(DykBnFinalizeDesc d) {
+    const int sub = threadIdx.x & 31;
+    const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (c >= d.C) return;
     const double n = (double)d.count;
     const int slots = d.slots > 0 ? d.slots : 1;
     double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < slots; ++r) {            // all loads first (independent, pipelined) ...
-        const double* st = d.stats + (size_t)r * 2 * d.C;
-        s1 += st[c]; s2 += st[d.C + c];
-    }
-    for (int r = 0; r < slots; ++r) {            // ... then re-arm the accumulators for the next step
+    for (int r = sub; r < slots; r += 32) {
         double* st = d.stats + (size_t)r * 2 * d.C;
-        st[c] = 0.0; st[d.C + c] = 0.0;
+        s1 += st[c]; s2 += st[d.C + c];
+        st[c] = 0.0; st[d.C + c] = 0.0;          // re-arm the accumulators for the next step
     }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (sub != 0) return;
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -169,11 +171,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(DykEwDesc d, int
     }
 }
 
-__global__ void bn_bwd_params_kernel(double* red, float* dgamma, float* dbeta, int C, int slots) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_bwd_params_kernel(double* red, float* dgamma, float* dbeta, int C, int slots) {
+    const int sub = threadIdx.x & 31;
+    const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (c >= C) return;
-    double s1 = red[c], s2 = red[C + c];
-    for (int r = 1; r < slots; ++r) { s1 += red[(size_t)r * 2 * C + c]; s2 += red[(size_t)r * 2 * C + C + c]; }
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = sub; r < slots; r += 32) { s1 += red[(size_t)r * 2 * C + c]; s2 += red[(size_t)r * 2 * C + C + c]; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (sub != 0) return;
     red[c] = s1; red[C + c] = s2;            // replica 0 now holds the totals (read by the apply kernel)
     if (dbeta) dbeta[c] += (float)s1;
     if (dgamma) dgamma[c] += (float)s2;
@@ -263,7 +269,7 @@ inline int ew_check(const DykEwDesc* d, bool need_b) {
 
 extern "C" int dyk_bn_finalize(const DykBnFinalizeDesc* d, void* stream) {
     if (!d || !d->stats || !d->scale || !d->shift || d->C <= 0 || d->count <= 0) return DYK_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 127) / 128), dim3(128), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 7) / 8), dim3(256), 0, (hipStream_t)stream, *d);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -316,7 +322,7 @@ extern "C" int dyk_bn_act_bwd_reduce(const DykEwDesc* d, void* stream) {
 
 extern "C" int dyk_bn_bwd_params(double* red, float* dgamma, float* dbeta, int32_t C, int32_t slots, void* stream) {
     if (!red || C <= 0) return DYK_ERR_ARG;
-    hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, red, dgamma, dbeta, C,
+    hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, red, dgamma, dbeta, C,
                        slots > 0 ? slots : 1);
     DYK_LAUNCH_CHECK();
     return DYK_OK;

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void se_pool_kernel(DykEwDesc d, float* __rest
 }
 
 // one block per image: h = relu(W1 pooled + b1); s = hardsigmoid(W2 h + b2)   (layers.py:185-189)
-__global__ __launch_bounds__(256) void se_fc_fwd_kernel(DykSeFcDesc d) {
+__global__ __launch_bounds__(1024) void se_fc_fwd_kernel(DykSeFcDesc d) {
     extern __shared__ float sm[];           // pooled[C] | h[Cs]
     float* pooled = sm;
     float* h = sm + d.C;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void se_fc_fwd_kernel(DykSeFcDesc d) {
 
 // backward of the two FCs for one image per block; parameter gradients via fp32 atomics.
 // in: dscale[b][c] = sum_hw dz*x ; out: dpooled[b][c] (gradient w.r.t. the pooled mean)
-__global__ __launch_bounds__(256) void se_fc_bwd_kernel(DykSeFcDesc d) {
+__global__ __launch_bounds__(1024) void se_fc_bwd_kernel(DykSeFcDesc d) {
     extern __shared__ float sm[];           // pooled[C] | h[Cs] | t1[Cs] | dt2[C] | dt1[Cs]
     float* pooled = sm;
     float* h = pooled + d.C;
@@ -344,12 +344,15 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(DykSeFcDesc d) {
         const float g = dt2[c] * h[j];
         if (g != 0.f) unsafeAtomicAdd(d.dw2 + i, g);
     }
-    for (int j = threadIdx.x; j < d.Cs; j += blockDim.x) {
+    for (int j = w; j < d.Cs; j += nw) {             // dh[j] = sum_c W2[c][j] dt2[c]: one wave per j
         float acc = 0.f;
-        for (int c = 0; c < d.C; ++c) acc += d.w2[(long)c * d.Cs + j] * dt2[c];
-        const float g = t1[j] > 0.f ? acc : 0.f;
-        dt1[j] = g;
-        if (g != 0.f) unsafeAtomicAdd(d.db1 + j, g);
+        for (int c = lane; c < d.C; c += 64) acc += d.w2[(long)c * d.Cs + j] * dt2[c];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float g = t1[j] > 0.f ? acc : 0.f;
+            dt1[j] = g;
+            if (g != 0.f) unsafeAtomicAdd(d.db1 + j, g);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < d.C * d.Cs; i += blockDim.x) {
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(DykSeFcDesc d) {
         const float g = dt1[j] * pooled[c];
         if (g != 0.f) unsafeAtomicAdd(d.dw1 + i, g);
     }
-    for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+    for (int c = threadIdx.x; c < d.C; c += blockDim.x) {      // coalesced over c, short loop over Cs
         float acc = 0.f;
         for (int j = 0; j < d.Cs; ++j) acc += d.w1[(long)j * d.C + c] * dt1[j];
         d.dpooled[(long)b * d.C + c] = acc;
@@ -585,7 +588,7 @@ extern "C" int dyk_se_fc_fwd(const DykSeFcDesc* d, void* stream) {
     if (!d || !d->pooled || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->scale || d->B <= 0 || d->C <= 0 || d->Cs <= 0)
         return DYK_ERR_ARG;
     const size_t lds = (size_t)(d->C + d->Cs) * sizeof(float);
-    hipLaunchKernelGGL(se_fc_fwd_kernel, dim3(d->B), dim3(256), lds, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(se_fc_fwd_kernel, dim3(d->B), dim3(1024), lds, (hipStream_t)stream, *d);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -595,7 +598,7 @@ extern "C" int dyk_se_fc_bwd(const DykSeFcDesc* d, void* stream) {
         !d->dw2 || !d->db2 || d->B <= 0 || d->C <= 0 || d->Cs <= 0)
         return DYK_ERR_ARG;
     const size_t lds = (size_t)(2 * d->C + 3 * d->Cs) * sizeof(float);
-    hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(d->B), dim3(256), lds, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(d->B), dim3(1024), lds, (hipStream_t)stream, *d);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
