@@ -9,9 +9,12 @@ Names, constructor signatures and state_dict keys follow the reference (layers.p
 checkpoints and user code interchange.
 """
 import math
+import sys  # noqa: F401  (re-exported through `from build_utils.layers import *`, as in the reference)
 
+import numpy as np  # noqa: F401
 import torch
 import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401
 
 
 def make_divisible(v, divisor):

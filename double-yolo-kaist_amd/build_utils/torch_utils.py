@@ -9,12 +9,19 @@ def init_seeds(seed=0):
     torch.manual_seed(seed)
 
 
-def select_device(device="", apex=False, batch_size=None):
-    """'cpu' or a cuda index string -> torch.device (reference torch_utils.py:23-50: single GPU)."""
-    cpu_request = str(device).lower() == "cpu"
-    if cpu_request or not torch.cuda.is_available():
-        return torch.device("cpu")
-    return torch.device("cuda:0")
+def select_device(device="cuda:0"):
+    """device string -> torch.device, single GPU or CPU (reference torch_utils.py:35-50)"""
+    cpu_request = device.lower() == "cpu"
+    if device and not cpu_request:
+        assert torch.cuda.is_available(), "CUDA unavailable, invalid device %s requested" % device
+    device = torch.device(device)
+    if not cpu_request and torch.cuda.is_available():
+        di = 0 if device.index is None else device.index
+        dp = torch.cuda.get_device_properties(di)
+        print("Using torch %s CUDA:%d (%s, %dMB)" % (torch.__version__, di, dp.name, dp.total_memory / 1024 ** 2))
+    else:
+        print("Using torch %s CPU" % torch.__version__)
+    return device
 
 
 def time_synchronized():

@@ -10,8 +10,10 @@ import torch
 import torch.nn as nn
 
 from build_utils import torch_utils
+from build_utils.layers import *  # noqa: F401,F403  (callers do `from models import *`, reference models.py:1-4)
 from build_utils.layers import (ConvBlock, DepthwiseSeparableConv2d, FeatureConcat, Inception, SqueezeExcitation,
                                 WeightedFeatureFusion, make_activation)
+from build_utils.parse_config import *  # noqa: F401,F403
 from build_utils.parse_config import parse_model_cfg
 from build_utils.utils import get_yolo_layers
 
