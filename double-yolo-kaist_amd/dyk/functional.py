@@ -1,0 +1,154 @@
+"""Stand-alone forward of the operator classes in build_utils/layers.py and models.YOLOLayer on torch
+NCHW float32 CUDA tensors (the reference's `module(x)` / `module(x, outputs)` surface).  Each call converts to the
+channels-last compute layout, runs the same HIP kernels the compiled plan uses, and converts back.  This is the
+module-level compatibility surface (no autograd); `models.YOLO.forward` never goes through here.
+"""
+import ctypes
+
+import torch
+
+from . import lib as L
+from . import ops
+from .lib import check, load
+
+
+def _dtype():
+    return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+
+
+def _ru(n, a):
+    return (n + a - 1) // a * a
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _nhwc(x, cpad=None):
+    ops._require_cuda(x)
+    return ops.to_nhwc(x.float().contiguous(), _dtype(), cpad=cpad)
+
+
+def concat(tensors):
+    """FeatureConcat.forward for several inputs (reference layers.py:44)"""
+    dt = _dtype()
+    B, _, H, W = tensors[0].shape
+    cs = [t.shape[1] for t in tensors]
+    buf = torch.zeros((B, H, W, sum(cs)), dtype=dt, device=tensors[0].device)
+    c0 = 0
+    for t, c in zip(tensors, cs):
+        ops._require_cuda(t)
+        ops.to_nhwc(t.float().contiguous(), dt, out=buf[..., c0:c0 + c])
+        c0 += c
+    return ops.to_nchw(buf)
+
+
+def weighted_fusion(x, others, w, n):
+    """WeightedFeatureFusion.forward (reference layers.py:63-85), equal channel counts"""
+    xd = _nhwc(x)
+    weff = None
+    if w is not None:
+        weff = torch.zeros(n, device=x.device)
+        check(load().dyk_wfuse_weights(w.detach().float().contiguous().data_ptr(), weff.data_ptr(), n, _stream()))
+    out = xd
+    for i, a in enumerate(others):
+        if a.shape[1] != x.shape[1]:
+            raise NotImplementedError("WeightedFeatureFusion with mismatched channel counts")
+        ad = _nhwc(a)
+        nxt = torch.empty_like(xd)
+        d = ops.ew_desc(a=out, b=ad, out=nxt, p0=weff[0:1] if (weff is not None and i == 0) else None,
+                        p1=weff[i + 1:i + 2] if weff is not None else None)
+        ops.call("dyk_axpby", d)
+        out = nxt
+    return ops.to_nchw(out)
+
+
+def squeeze_excitation(x, w1, b1, w2, b2):
+    """SqueezeExcitation.forward (reference layers.py:184-190)"""
+    xd = _nhwc(x)
+    B, H, W, C = xd.shape
+    Cs = w1.shape[0]
+    pooled = torch.zeros(B, C, device=x.device)
+    scale = torch.zeros(B, C, device=x.device)
+    ops.call("dyk_se_pool", ops.ew_desc(a=xd, B=B, H=H, W=W, alpha=1.0 / (H * W)), pooled)
+    prm = [t.detach().float().contiguous() for t in (w1, b1, w2, b2)]
+    fd = L.DykSeFcDesc()
+    fd.pooled, fd.scale = pooled.data_ptr(), scale.data_ptr()
+    fd.w1, fd.b1, fd.w2, fd.b2 = (t.data_ptr() for t in prm)
+    fd.B, fd.C, fd.Cs = B, C, Cs
+    ops.call("dyk_se_fc_fwd", fd)
+    z = torch.empty_like(xd)
+    ops.call("dyk_se_scale", ops.ew_desc(a=xd, out=z, p0=scale, B=B, H=H, W=W))
+    return ops.to_nchw(z)
+
+
+def conv_bn_act(x, conv, bn, act, training):
+    """nn.Sequential(Conv2d[, BatchNorm2d][, activation]) forward (reference models.py:28-64)."""
+    if conv.groups != 1:
+        raise NotImplementedError("grouped / depthwise convolution is not built yet")
+    dt = _dtype()
+    k, s, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    cin, cout = conv.in_channels, conv.out_channels
+    cpad = _ru(cin, 32)
+    xd = _nhwc(x, cpad=cpad)
+    wp = ops.pack_weight(conv.weight.detach().float().contiguous(), dt, cin_pad=cpad)
+    dev = x.device
+    if bn is None:
+        bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+        y = ops.conv2d_fwd(xd, wp, k, s, pad, cout, act=act, shift=bias)
+        return ops.to_nchw(y)
+    gamma, beta = bn.weight.detach().float().contiguous(), bn.bias.detach().float().contiguous()
+    if not training:
+        scale, shift = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+        check(load().dyk_bn_fold(gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                 float(bn.eps), scale.data_ptr(), shift.data_ptr(), cout, _stream()))
+        return ops.to_nchw(ops.conv2d_fwd(xd, wp, k, s, pad, cout, act=act, scale=scale, shift=shift))
+    stats = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
+    y = ops.conv2d_fwd(xd, wp, k, s, pad, cout, stats=stats)
+    n = y.shape[0] * y.shape[1] * y.shape[2]
+    scale, shift, _, _ = ops.bn_finalize(stats, n, gamma, beta, bn.running_mean, bn.running_var,
+                                         momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps)
+    bn.num_batches_tracked += 1
+    z = torch.empty_like(y)
+    ops.call("dyk_bn_act_fwd", ops.ew_desc(a=y, out=z, act=act, p0=scale, p1=shift))
+    return ops.to_nchw(z)
+
+
+def maxpool(x, k):
+    xd = _nhwc(x)
+    B, H, W, C = xd.shape
+    z = torch.empty_like(xd)
+    ops.call("dyk_maxpool_fwd", ops.ew_desc(a=xd, out=z, B=B, H=H, W=W, k=k), None)
+    return ops.to_nchw(z)
+
+
+def upsample2x(x):
+    xd = _nhwc(x)
+    B, H, W, C = xd.shape
+    z = torch.empty((B, 2 * H, 2 * W, C), dtype=xd.dtype, device=xd.device)
+    ops.call("dyk_upsample2x_fwd", ops.ew_desc(a=xd, out=z, B=B, H=H, W=W))
+    return ops.to_nchw(z)
+
+
+def yolo_layer(p, layer):
+    """YOLOLayer.forward (reference models.py:218-258): p [B, na*no, ny, nx] -> training: [B,na,ny,nx,no];
+    eval: (decoded [B, na*ny*nx, no], raw)"""
+    ops._require_cuda(p)
+    B, _, ny, nx = p.shape
+    na, no = layer.na, layer.no
+    y = torch.zeros((B, ny, nx, 32 if na * no <= 32 else _ru(na * no, 4)), dtype=torch.float32, device=p.device)
+    ld = y.shape[3]
+    ops.to_nhwc(p.float().contiguous(), torch.float32, out=y[..., :na * no])
+    out = torch.empty((B, na, ny, nx, no), dtype=torch.float32, device=p.device)
+    check(load().dyk_head_permute_fwd(y.data_ptr(), out.data_ptr(), B, ny, nx, na, no, ld, _stream()))
+    if layer.training:
+        return out
+    io = torch.empty((B, na * ny * nx, no), dtype=torch.float32, device=p.device)
+    d = L.DykDecodeDesc()
+    d.p, d.io = out.data_ptr(), io.data_ptr()
+    d.B, d.na, d.ny, d.nx, d.no = B, na, ny, nx, no
+    d.rows_total, d.row_offset, d.v4, d.stride = na * ny * nx, 0, 1 if layer.bf_type == "yolov4" else 0, float(layer.stride)
+    for i, v in enumerate(layer.anchor_vec.detach().float().cpu().reshape(-1).tolist()):
+        d.anchor_vec[i] = v
+    ops.call("dyk_yolo_decode", d)
+    return io, out

@@ -1,0 +1,99 @@
+"""Stand-alone calls of the operator surface (build_utils.layers classes, models.YOLOLayer, ConvBlock) on CUDA
+NCHW tensors against the torch CPU modules the reference instantiates (layers.py:32-234, models.py:28-64,158-258)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, tol=2e-5):
+    err = (got.cpu() - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+def test_routing_ops():
+    from build_utils.layers import FeatureConcat, WeightedFeatureFusion
+    g = torch.Generator().manual_seed(1)
+    outs = [torch.randn(2, c, 6, 8, generator=g) for c in (32, 64, 32)]
+    cu = [o.cuda() for o in outs]
+    assert FeatureConcat([1]).forward(None, cu) is cu[1]                       # single source: alias, no copy
+    _close(FeatureConcat([0, 2, 1])(None, cu), torch.cat([outs[0], outs[2], outs[1]], 1))
+    x = torch.randn(2, 32, 6, 8, generator=g)
+    _close(WeightedFeatureFusion([0])(x.cuda(), cu), x + outs[0])
+    wf = WeightedFeatureFusion([2], weight=True)
+    with torch.no_grad():
+        wf.w.copy_(torch.tensor([0.4, -0.9]))
+    w = torch.sigmoid(wf.w.detach()) * (2 / 2)
+    _close(wf.cuda()(x.cuda(), cu), x * w[0] + outs[2] * w[1])
+
+
+def test_squeeze_excitation_and_make_divisible():
+    from build_utils.layers import SqueezeExcitation, make_divisible
+    assert make_divisible(256 // 4, 8) == 64 and make_divisible(72 // 4, 8) == 24
+    torch.manual_seed(2)
+    se = SqueezeExcitation(64, 4)
+    x = torch.randn(2, 64, 6, 8)
+    s = F.hardsigmoid(se.fc2(F.relu(se.fc1(F.adaptive_avg_pool2d(x, 1)))))
+    ref = (s * x).detach()
+    _close(se.cuda()(x.cuda()), ref)
+
+
+@pytest.mark.parametrize("act", ["mish", "leaky", "linear"])
+def test_conv_block_eval_and_train(act):
+    from build_utils.layers import ConvBlock, make_activation
+    torch.manual_seed(3)
+    blk = ConvBlock()
+    blk.add_module("Conv2d", nn.Conv2d(3, 32, 3, 1, 1, bias=False))          # Cin = 3: padded to 32 internally
+    blk.add_module("BatchNorm2d", nn.BatchNorm2d(32))
+    a = make_activation(act)
+    if a is not None:
+        blk.add_module("activation", a)
+        blk.act_name = act
+    with torch.no_grad():
+        blk.BatchNorm2d.running_mean.normal_(0, 0.2)
+        blk.BatchNorm2d.running_var.uniform_(0.5, 1.5)
+        blk.BatchNorm2d.weight.uniform_(0.5, 1.5)
+        blk.BatchNorm2d.bias.normal_(0, 0.2)
+    ref_blk = nn.Sequential(nn.Conv2d(3, 32, 3, 1, 1, bias=False), nn.BatchNorm2d(32), *( [make_activation(act)] if a is not None else []))
+    ref_blk[0].load_state_dict(blk.Conv2d.state_dict())
+    ref_blk[1].load_state_dict(blk.BatchNorm2d.state_dict())
+    x = torch.randn(2, 3, 16, 20)
+    ref_blk.eval()
+    ref = ref_blk(x).detach()
+    blk = blk.cuda().eval()
+    _close(blk(x.cuda()), ref, 5e-5)
+    ref_blk.train()
+    ref_t = ref_blk(x).detach()
+    blk.train()
+    _close(blk(x.cuda()), ref_t, 5e-5)
+    _close(blk.BatchNorm2d.running_mean, ref_blk[1].running_mean, 1e-5)
+    _close(blk.BatchNorm2d.running_var, ref_blk[1].running_var, 1e-5)
+    assert int(blk.BatchNorm2d.num_batches_tracked) == 1
+
+
+def test_yolo_layer_standalone():
+    import numpy as np
+    from models import YOLOLayer
+    for bf in ("yolov3", "yolov4"):
+        lay = YOLOLayer(np.array([[16., 32.], [18., 42.], [22., 44.]]), 1, (128, 160), 8, bf)
+        p = torch.randn(2, 18, 16, 20)
+        lay.train()
+        out = lay.cuda()(p.cuda())
+        ref = p.view(2, 3, 6, 16, 20).permute(0, 1, 3, 4, 2).contiguous()
+        assert torch.equal(out.cpu(), ref)
+        lay.eval()
+        io, raw = lay(p.cuda())
+        yv, xv = torch.meshgrid(torch.arange(16), torch.arange(20), indexing="ij")
+        grid = torch.stack((xv, yv), 2).view(1, 1, 16, 20, 2).float()
+        awh = (torch.tensor([[16., 32.], [18., 42.], [22., 44.]]) / 8).view(1, 3, 1, 1, 2)
+        if bf == "yolov4":
+            s = ref.sigmoid()
+            want = torch.cat(((s[..., :2] * 2 - 0.5 + grid) * 8, ((s[..., 2:4] * 2) ** 2 * awh) * 8, s[..., 4:]), -1)
+        else:
+            want = torch.cat(((ref[..., :2].sigmoid() + grid) * 8, (ref[..., 2:4].exp() * awh) * 8, ref[..., 4:].sigmoid()), -1)
+        assert io.shape == (2, 3 * 16 * 20, 6)
+        err = ((io.cpu() - want.view(2, -1, 6)).abs() / want.view(2, -1, 6).abs().clamp(min=1)).max().item()
+        assert err < 2e-6
+        assert torch.equal(raw.cpu(), ref)
