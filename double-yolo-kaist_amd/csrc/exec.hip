@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void transpose_taps_kernel(const float* __rest
     local -= t * tr * tc;
     const int r0 = (local / tc) * 32, c0 = (local % tc) * 32;
     const float* s = src + e.src_off + (long)t * e.rows * e.cols;
-    T* d = dst + e.dst_off + (long)t * e.rows * e.cols;
+    const int dld = e.dst_ld > 0 ? e.dst_ld : e.rows;
+    T* d = dst + e.dst_off + (long)t * dld * e.cols;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int j = ty; j < 32; j += 8) {
         const int r = r0 + j, c = c0 + tx;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void transpose_taps_kernel(const float* __rest
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int c = c0 + j, r = r0 + tx;
-        if (c < e.cols && r < e.rows) d[(long)c * e.rows + r] = ElemTraits<T>::from_f32(tile[tx][j]);
+        if (c < e.cols && r < dld) d[(long)c * dld + r] = ElemTraits<T>::from_f32(tile[tx][j]);
     }
 }
 
@@ -201,6 +202,11 @@ extern "C" int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream,
                          ? DYK_OK : DYK_ERR_HIP;
                 break;
             case DYK_OP_YOLO_DECODE: rc = dyk_yolo_decode((const DykDecodeDesc*)dp, stream); break;
+            case DYK_OP_DW_FWD: rc = dyk_dwconv_fwd((const DykDwDesc*)dp, stream); break;
+            case DYK_OP_DW_DGRAD: rc = dyk_dwconv_dgrad((const DykDwDesc*)dp, stream); break;
+            case DYK_OP_DW_WGRAD: rc = dyk_dwconv_wgrad((const DykDwDesc*)dp, stream); break;
+            case DYK_OP_CAST_PAD_ROWS:
+                rc = dyk_cast_pad_rows((const float*)m->p[0], m->p[1], m->i[0], m->i[1], m->i[2], m->i[3], stream); break;
             default: rc = DYK_ERR_UNSUPPORTED; break;
             }
         }

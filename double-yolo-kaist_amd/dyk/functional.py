@@ -83,35 +83,49 @@ def squeeze_excitation(x, w1, b1, w2, b2):
 
 
 def conv_bn_act(x, conv, bn, act, training):
-    """nn.Sequential(Conv2d[, BatchNorm2d][, activation]) forward (reference models.py:28-64)."""
-    if conv.groups != 1:
-        raise NotImplementedError("grouped / depthwise convolution is not built yet")
+    """nn.Sequential(Conv2d[, BatchNorm2d][, activation]) forward (reference models.py:28-64); dense or depthwise."""
     dt = _dtype()
     k, s, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     cin, cout = conv.in_channels, conv.out_channels
+    depthwise = conv.groups > 1
+    if depthwise and not (conv.groups == cin == cout):
+        raise NotImplementedError("grouped convolution that is not depthwise")
     cpad = _ru(cin, 32)
     xd = _nhwc(x, cpad=cpad)
-    wp = ops.pack_weight(conv.weight.detach().float().contiguous(), dt, cin_pad=cpad)
     dev = x.device
+    if depthwise:
+        if bn is None:
+            raise NotImplementedError("depthwise convolution without BatchNorm2d")
+        wt = conv.weight.detach().float().reshape(cout, k * k).t().contiguous()
+
+        def run_conv(stats=None, **epi):
+            return ops.dwconv_fwd(xd, wt, k, s, pad, stats=stats, stats_slots=1, C=cout)
+    else:
+        wp = ops.pack_weight(conv.weight.detach().float().contiguous(), dt, cin_pad=cpad)
+
+        def run_conv(stats=None, **epi):
+            return ops.conv2d_fwd(xd, wp, k, s, pad, cout, stats=stats, **epi)
     if bn is None:
         bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
-        y = ops.conv2d_fwd(xd, wp, k, s, pad, cout, act=act, shift=bias)
-        return ops.to_nchw(y)
+        return ops.to_nchw(run_conv(act=act, shift=bias))
     gamma, beta = bn.weight.detach().float().contiguous(), bn.bias.detach().float().contiguous()
     if not training:
         scale, shift = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
         check(load().dyk_bn_fold(gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                  float(bn.eps), scale.data_ptr(), shift.data_ptr(), cout, _stream()))
-        return ops.to_nchw(ops.conv2d_fwd(xd, wp, k, s, pad, cout, act=act, scale=scale, shift=shift))
-    stats = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
-    y = ops.conv2d_fwd(xd, wp, k, s, pad, cout, stats=stats)
-    n = y.shape[0] * y.shape[1] * y.shape[2]
-    scale, shift, _, _ = ops.bn_finalize(stats, n, gamma, beta, bn.running_mean, bn.running_var,
-                                         momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps)
-    bn.num_batches_tracked += 1
+        if not depthwise:
+            return ops.to_nchw(run_conv(act=act, scale=scale, shift=shift))
+        y = run_conv()
+    else:
+        stats = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
+        y = run_conv(stats=stats)
+        n = y.shape[0] * y.shape[1] * y.shape[2]
+        scale, shift, _, _ = ops.bn_finalize(stats, n, gamma, beta, bn.running_mean, bn.running_var,
+                                             momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps)
+        bn.num_batches_tracked += 1
     z = torch.empty_like(y)
-    ops.call("dyk_bn_act_fwd", ops.ew_desc(a=y, out=z, act=act, p0=scale, p1=shift))
-    return ops.to_nchw(z)
+    ops.call("dyk_bn_act_fwd", ops.ew_desc(a=y, out=z, act=act, p0=scale, p1=shift, C=cout))
+    return ops.to_nchw(z, C=cout)
 
 
 def maxpool(x, k):

@@ -20,7 +20,8 @@ MAX_TAPS = 25
 (OP_CONV, OP_WGRAD, OP_BN_FINALIZE, OP_BN_ACT_FWD, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_AXPBY, OP_DOT,
  OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_SE_POOL, OP_SE_FC_FWD, OP_SE_FC_BWD,
  OP_SE_SCALE, OP_BN_BWD_PARAMS, OP_BN_FOLD, OP_WFUSE_WEIGHTS, OP_WFUSE_BWD_PARAMS, OP_HEAD_PERMUTE_FWD,
- OP_HEAD_PERMUTE_BWD, OP_PATCH_GATHER, OP_MEMSET, OP_YOLO_DECODE, OP_DW_CONV) = range(1, 27)
+ OP_HEAD_PERMUTE_BWD, OP_PATCH_GATHER, OP_MEMSET, OP_YOLO_DECODE, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD,
+ OP_CAST_PAD_ROWS) = range(1, 30)
 
 
 class DykLibraryError(RuntimeError):
@@ -86,7 +87,14 @@ class DykSeFcDesc(ctypes.Structure):
 
 class DykTransposeEntry(ctypes.Structure):
     _fields_ = [("src_off", _i64), ("dst_off", _i64), ("taps", _i32), ("rows", _i32), ("cols", _i32),
-                ("tile_begin", _i32)]
+                ("tile_begin", _i32), ("dst_ld", _i32), ("_pad", _i32)]
+
+
+class DykDwDesc(ctypes.Structure):
+    _fields_ = [("x", _vp), ("y", _vp), ("w", _vp), ("dw", _vp), ("stats", _vp),
+                ("dtype", _i32), ("ldx", _i32), ("ldy", _i32),
+                ("B", _i32), ("Hi", _i32), ("Wi", _i32), ("Ho", _i32), ("Wo", _i32), ("C", _i32),
+                ("k", _i32), ("stride", _i32), ("pad", _i32), ("flags", _i32), ("stats_slots", _i32)]
 
 
 class DykMiscDesc(ctypes.Structure):
@@ -164,6 +172,9 @@ SIGNATURES = {
     "dyk_cast_f32": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "dyk_cast_pad_rows": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "dyk_transpose_taps": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "dyk_dwconv_fwd": (_i32, [_P(DykDwDesc), _vp]),
+    "dyk_dwconv_dgrad": (_i32, [_P(DykDwDesc), _vp]),
+    "dyk_dwconv_wgrad": (_i32, [_P(DykDwDesc), _vp]),
     "dyk_run_commands": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
     "dyk_yolo_decode": (_i32, [_P(DykDecodeDesc), _vp]),
     "dyk_build_targets": (_i32, [_P(DykTargetsDesc), _vp]),

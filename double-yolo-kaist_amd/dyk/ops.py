@@ -213,6 +213,57 @@ def conv2d_wgrad(x, dy, k, stride, pad, *, dw=None, splits=0, Cin=None, Cout=Non
     return dw
 
 
+# --------------------------------------------------------------------------- depthwise convolution
+def _dw_desc(x, y, w_taps, k, stride, pad, C):
+    from .lib import DykDwDesc
+    d = DykDwDesc()
+    d.x, d.y = x.data_ptr(), y.data_ptr()
+    d.w = w_taps.data_ptr() if w_taps is not None else None
+    d.dtype = dtype_code(x.dtype)
+    d.ldx, d.ldy = nhwc_ld(x), nhwc_ld(y)
+    d.B, d.Hi, d.Wi = x.shape[0], x.shape[1], x.shape[2]
+    d.Ho, d.Wo, d.C = y.shape[1], y.shape[2], C
+    d.k, d.stride, d.pad = k, stride, pad
+    return d
+
+
+def dwconv_fwd(x, w_taps, k, stride, pad, *, stats=None, stats_slots=1, C=None):
+    """depthwise conv; x channels-last [B,H,W,ld>=C], w_taps fp32 [k*k][C]"""
+    _require_cuda(x, w_taps)
+    B, Hi, Wi, Cx = x.shape
+    C = C or Cx
+    Ho, Wo = conv_out_size(Hi, k, stride, pad), conv_out_size(Wi, k, stride, pad)
+    y = torch.zeros((B, Ho, Wo, Cx), dtype=x.dtype, device=x.device)
+    d = _dw_desc(x, y, w_taps, k, stride, pad, C)
+    if stats is not None:
+        d.stats, d.stats_slots = stats.data_ptr(), stats_slots
+    check(load().dyk_dwconv_fwd(ctypes.byref(d), _stream()), "dyk_dwconv_fwd")
+    return y
+
+
+def dwconv_dgrad(dy, w_taps, k, stride, pad, Hi, Wi, *, out=None, accumulate=False, C=None):
+    _require_cuda(dy, w_taps)
+    B, Ho, Wo, Cy = dy.shape
+    C = C or Cy
+    if out is None:
+        out = torch.zeros((B, Hi, Wi, Cy), dtype=dy.dtype, device=dy.device)
+    d = _dw_desc(out, dy, w_taps, k, stride, pad, C)
+    d.flags = 1 if accumulate else 0
+    check(load().dyk_dwconv_dgrad(ctypes.byref(d), _stream()), "dyk_dwconv_dgrad")
+    return out
+
+
+def dwconv_wgrad(x, dy, k, stride, pad, *, dw=None, C=None):
+    _require_cuda(x, dy)
+    C = C or x.shape[3]
+    if dw is None:
+        dw = torch.zeros((k * k, C), dtype=torch.float32, device=x.device)
+    d = _dw_desc(x, dy, None, k, stride, pad, C)
+    d.dw = dw.data_ptr()
+    check(load().dyk_dwconv_wgrad(ctypes.byref(d), _stream()), "dyk_dwconv_wgrad")
+    return dw
+
+
 # --------------------------------------------------------------------------- elementwise family
 def ew_desc(a=None, b=None, out=None, *, C=None, npix=None, act="linear", flags=0, alpha=1.0, beta=1.0,
             p0=None, p1=None, p2=None, p3=None, red=None, aux=None, B=0, H=0, W=0, k=0):

@@ -46,6 +46,11 @@ class ParamStore:
                         co, ci, kh, kw = p.shape
                         if getattr(sub, "_dyk_stem", False):
                             e.kind, e.storage_shape, e.perm = "stem_w", (co, kh, kw, ci), (0, 3, 1, 2)
+                        elif sub.groups > 1:
+                            if not (sub.groups == sub.in_channels == sub.out_channels):
+                                raise NotImplementedError("grouped convolution that is not depthwise (%s)" % e.name)
+                            # depthwise: [k*k][C], read as fp32 by the depthwise kernels
+                            e.kind, e.storage_shape, e.perm = "dw_w", (kh, kw, co, ci), (2, 3, 0, 1)
                         else:
                             e.kind, e.storage_shape, e.perm = "conv_w", (kh, kw, co, ci), (2, 3, 0, 1)
                     else:
@@ -66,6 +71,7 @@ class ParamStore:
         self.device = None
         self._compute = {}      # dtype -> dict(Wc, Wt, stems, version)
         self._ttable = None
+        self._pad_layout = None
         self._dirty = 0
 
     # ------------------------------------------------------------------ adoption
@@ -141,21 +147,45 @@ class ParamStore:
         raise KeyError(attr)
 
     # ------------------------------------------------------------------ compute-dtype staging
+    def _layout_padded(self):
+        """Offsets (elements) of the zero-padded weight packs that channel counts off the GEMM K step need:
+        fwd  [t][Cout][ru32(Cin)]  for Cin  % 32 != 0   (forward conv reads K = padded input channels)
+        bwd  [t][Cin][ru32(Cout)]  for Cout % 32 != 0   (data-gradient conv reads K = padded output channels)"""
+        if getattr(self, "_pad_layout", None) is None:
+            fwd, bwd, fo, bo = {}, {}, 0, 0
+            for e in self.entries:
+                if e.kind != "conv_w":
+                    continue
+                co, ci, kh, kw = e.shape
+                if ci % 32:
+                    fwd[e.name] = fo
+                    fo += _round_up(kh * kw * co * _round_up(ci, 32), ALIGN)
+                if co % 32:
+                    bwd[e.name] = bo
+                    bo += _round_up(kh * kw * ci * _round_up(co, 32), ALIGN)
+            self._pad_layout = (fwd, max(fo, ALIGN), bwd, max(bo, ALIGN))
+        return self._pad_layout
+
     def _transpose_table(self):
         if self._ttable is None:
-            ents = [e for e in self.entries if e.kind == "conv_w" and e.shape[0] % 32 == 0]
-            arr = (L.DykTransposeEntry * max(len(ents), 1))()
-            tiles = 0
-            for i, e in enumerate(ents):
-                co, ci, kh, kw = e.shape
-                arr[i].src_off = e.offset
-                arr[i].dst_off = e.offset
-                arr[i].taps, arr[i].rows, arr[i].cols = kh * kw, co, ci
-                arr[i].tile_begin = tiles
-                tiles += kh * kw * ((co + 31) // 32) * ((ci + 31) // 32)
-            raw = bytes(arr)
-            t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
-            self._ttable = (t, len(ents), tiles)
+            _, _, bwd_off, _ = self._layout_padded()
+            tabs = []
+            for padded in (False, True):
+                ents = [e for e in self.entries if e.kind == "conv_w" and bool(e.shape[0] % 32) == padded]
+                arr = (L.DykTransposeEntry * max(len(ents), 1))()
+                tiles = 0
+                for i, e in enumerate(ents):
+                    co, ci, kh, kw = e.shape
+                    arr[i].src_off = e.offset
+                    arr[i].dst_off = bwd_off[e.name] if padded else e.offset
+                    arr[i].taps, arr[i].rows, arr[i].cols = kh * kw, co, ci
+                    arr[i].dst_ld = _round_up(co, 32) if padded else 0
+                    arr[i].tile_begin = tiles
+                    tiles += kh * kw * ((co + 31) // 32) * ((ci + 31) // 32)
+                raw = bytes(arr)
+                t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+                tabs.append((t, len(ents), tiles))
+            self._ttable = tabs
         return self._ttable
 
     def mark_dirty(self):
@@ -166,16 +196,21 @@ class ParamStore:
 
     def alloc_compute(self, dtype):
         """allocate (without filling) the compute-dtype staging buffers; used by dry plan compilation"""
-        st = {"stems": {}, "heads_t": {}, "version": None}
+        st = self._alloc(dtype)
+        st["version"] = None
+        return st
+
+    def _alloc(self, dtype):
+        fwd_off, fwd_n, bwd_off, bwd_n = self._layout_padded()
+        st = {"stems": {}, "fwd_pad_off": fwd_off, "bwd_pad_off": bwd_off}
         st["Wc"] = self.P if dtype == torch.float32 else torch.empty(self.total, dtype=dtype, device=self.device)
         st["Wt"] = torch.zeros(self.total, dtype=dtype, device=self.device)
+        st["Wc_pad"] = torch.zeros(fwd_n, dtype=dtype, device=self.device)
+        st["Wt_pad"] = torch.zeros(bwd_n, dtype=dtype, device=self.device)
         for e in self.entries:
             if e.kind == "stem_w":
                 co, ci, kh, kw = e.shape
                 st["stems"][e.name] = torch.zeros((co, _round_up(ci * kh * kw, 32)), dtype=dtype, device=self.device)
-            elif e.kind == "conv_w" and e.shape[0] % 32:
-                co, ci, kh, kw = e.shape
-                st["heads_t"][e.name] = torch.zeros((ci, _round_up(co, 32)), dtype=dtype, device=self.device)
         return st
 
     def compute_weights(self, dtype, force=False, skip_cast=False):
@@ -192,35 +227,25 @@ class ParamStore:
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         code = L.DYK_BF16 if dtype == torch.bfloat16 else L.DYK_F32
         if st is None:
-            st = {"stems": {}, "heads_t": {}}
-            st["Wc"] = self.P if dtype == torch.float32 else torch.empty(self.total, dtype=dtype, device=self.device)
-            st["Wt"] = torch.zeros(self.total, dtype=dtype, device=self.device)
-            for e in self.entries:
-                if e.kind == "stem_w":
-                    co, ci, kh, kw = e.shape
-                    st["stems"][e.name] = torch.zeros((co, _round_up(ci * kh * kw, 32)), dtype=dtype, device=self.device)
-                elif e.kind == "conv_w" and e.shape[0] % 32:
-                    # detection heads (Cout = na*(5+nc)): the data-gradient GEMM needs K padded to 32
-                    co, ci, kh, kw = e.shape
-                    assert kh == 1 and kw == 1, "Cout %% 32 != 0 is only supported for 1x1 convs (%s)" % e.name
-                    st["heads_t"][e.name] = torch.zeros((ci, _round_up(co, 32)), dtype=dtype, device=self.device)
+            st = self._alloc(dtype)
             self._compute[dtype] = st
         if dtype != torch.float32 and not skip_cast:
             check(lib.dyk_cast_f32(self.P.data_ptr(), st["Wc"].data_ptr(), self.total, code, stream), "dyk_cast_f32")
-        tab, n, tiles = self._transpose_table()
-        if n:
-            check(lib.dyk_transpose_taps(self.P.data_ptr(), st["Wt"].data_ptr(), tab.data_ptr(), n, tiles, code, stream),
-                  "dyk_transpose_taps")
+        for (tab, n, tiles), dst in zip(self._transpose_table(), (st["Wt"], st["Wt_pad"])):
+            if n:
+                check(lib.dyk_transpose_taps(self.P.data_ptr(), dst.data_ptr(), tab.data_ptr(), n, tiles, code, stream),
+                      "dyk_transpose_taps")
+        esz = 2 if dtype == torch.bfloat16 else 4
+        for name, off in st["fwd_pad_off"].items():
+            e = self.by_name[name]
+            co, ci, kh, kw = e.shape
+            check(lib.dyk_cast_pad_rows(self.P.data_ptr() + 4 * e.offset, st["Wc_pad"].data_ptr() + esz * off,
+                                        kh * kw * co, ci, _round_up(ci, 32), code, stream), "dyk_cast_pad_rows")
         for e in self.entries:
             if e.kind == "stem_w":
                 co, ci, kh, kw = e.shape
                 t = st["stems"][e.name]
                 check(lib.dyk_cast_pad_rows(self.P.data_ptr() + 4 * e.offset, t.data_ptr(), co, ci * kh * kw, t.shape[1],
                                             code, stream), "dyk_cast_pad_rows")
-        for name, t in st["heads_t"].items():
-            e = self.by_name[name]
-            co, ci, kh, kw = e.shape
-            check(lib.dyk_pack_conv_weight(self.P.data_ptr() + 4 * e.offset, t.data_ptr(), co, ci, 1, 1, t.shape[1], ci, 1,
-                                           code, stream), "dyk_pack_conv_weight")
         st["version"] = ver
         return st

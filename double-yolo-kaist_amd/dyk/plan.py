@@ -126,7 +126,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     v4 = "yolov4" in model.cfg
 
     def new_act(Bn, Hn, Wn, C, ld=None, esize=None):
-        ld = ld or C
+        ld = ld or _ru(C, 32)        # rows padded (with zeros that no kernel ever overwrites) to the GEMM K step
         esize = esize or es
         return TRef("act", act_arena.alloc(Bn * Hn * Wn * ld * esize), Bn, Hn, Wn, C, ld, esize)
 
@@ -172,19 +172,26 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     head_idx = 0
     na_no = []
 
-    def conv_forward(i, m, mod, x_in, stem_src):
-        """emit forward commands of a [convolutional] section; returns (out TRef, info dict)"""
-        conv = mod[0]
-        bn = bool(m["batch_normalize"])
-        k = m["size"]
-        stride = m["stride"]
-        pad = k // 2 if m["pad"] else 0
-        cout = m["filters"]
-        act = L.ACT_CODES.get(m["activation"], 0)
-        pre = "module_list.%d." % i
+    def conv_forward(i, x_in, stem_src, wname, bnpre, bnm, bias_name, k, stride, pad, cout, act, groups=1):
+        """emit forward commands of Conv2d [+ BatchNorm2d] [+ activation]; returns (out TRef, info dict).
+        wname / bnpre / bias_name are parameter-store names (bnpre None = no BatchNorm)."""
+        bn = bnpre is not None
+        dw = groups > 1
         rec = {"kind": "conv", "bn": bn, "k": k, "stride": stride, "pad": pad, "cout": cout, "act": act, "i": i,
-               "stem": stem_src is not None}
-        if stem_src is not None:
+               "stem": stem_src is not None, "wname": wname, "bnpre": bnpre, "bias_name": bias_name, "dw": dw}
+        if dw:
+            if stem_src is not None or groups != x_in.C or cout != x_in.C:
+                raise NotImplementedError("grouped convolution that is not depthwise (layer %d)" % i)
+            Hi, Wi = x_in.H, x_in.W
+            Ho, Wo = conv_out_size(Hi, k, stride, pad), conv_out_size(Wi, k, stride, pad)
+            d = L.DykDwDesc()
+            plan._keep.append(d)
+            d.dtype, d.w = code, store.p_ptr(wname)
+            d.B, d.Hi, d.Wi, d.Ho, d.Wo, d.C = B, Hi, Wi, Ho, Wo, cout
+            d.k, d.stride, d.pad = k, stride, pad
+            d.ldx = x_in.ld
+            conv_op = L.OP_DW_FWD
+        elif stem_src is not None:
             # Cin=3 stem: gather k*k*3 patches (zero padded to 32) and run a 1x1 MFMA conv on them
             Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
             patches = new_act(B, Ho, Wo, 32)
@@ -195,45 +202,53 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             plan.dyn_in.append((g, stem_src))
             plan.fwd.append((L.OP_PATCH_GATHER, g))
             x_in = patches
-            wfwd_ptr = cw["stems"][pre + "Conv2d.weight"].data_ptr()
+            wfwd_ptr = cw["stems"][wname].data_ptr()
             taps, cin_k, cisy = [(0, 0, 0)], 32, 1
             rec["wgrad"] = dict(x=patches, Cin=k * k * 3, lddw=k * k * 3, taps=[(0, 0, 0)], isy=1, Hi=Ho, Wi=Wo)
             Hi, Wi = Ho, Wo
         else:
             Hi, Wi = x_in.H, x_in.W
             Ho, Wo = conv_out_size(Hi, k, stride, pad), conv_out_size(Wi, k, stride, pad)
-            e = store.by_name[pre + "Conv2d.weight"]
-            wfwd_ptr = cw["Wc"].data_ptr() + e.offset * es
-            taps, cin_k, cisy = fwd_taps(k, pad), x_in.C, stride
-            assert x_in.C % 32 == 0, "conv input channels must be a multiple of 32 (layer %d)" % i
+            e = store.by_name[wname]
+            cin_k = _ru(x_in.C, 32)
+            if x_in.ld < cin_k:
+                raise NotImplementedError("conv input rows narrower than the padded K (layer %d)" % i)
+            if cin_k != x_in.C:
+                wfwd_ptr = cw["Wc_pad"].data_ptr() + cw["fwd_pad_off"][wname] * es
+            else:
+                wfwd_ptr = cw["Wc"].data_ptr() + e.offset * es
+            taps, cisy = fwd_taps(k, pad), stride
             rec["wgrad"] = dict(x=x_in, Cin=x_in.C, lddw=0, taps=taps, isy=stride, Hi=Hi, Wi=Wi)
         rec["x"] = x_in
-        d = L.DykConvDesc()
-        plan._keep.append(d)
-        d.dtype = code
-        d.w = wfwd_ptr
-        d.B, d.Hi, d.Wi, d.Cin, d.Cout = B, Hi, Wi, cin_k, cout
-        d.Hg, d.Wg, d.Ho, d.Wo = Ho, Wo, Ho, Wo
-        d.isy = d.isx = cisy
-        d.osy = d.osx = 1
-        d.ntaps = len(taps)
-        for q, (ty, tx, wt) in enumerate(taps):
-            d.tdy[q], d.tdx[q], d.twt[q] = ty, tx, wt
-        d.ldx = x_in.ld
+        if not dw:
+            d = L.DykConvDesc()
+            plan._keep.append(d)
+            d.dtype = code
+            d.w = wfwd_ptr
+            d.B, d.Hi, d.Wi, d.Cin, d.Cout = B, Hi, Wi, cin_k, cout
+            d.Hg, d.Wg, d.Ho, d.Wo = Ho, Wo, Ho, Wo
+            d.isy = d.isx = cisy
+            d.osy = d.osx = 1
+            d.ntaps = len(taps)
+            for q, (ty, tx, wt) in enumerate(taps):
+                d.tdy[q], d.tdx[q], d.twt[q] = ty, tx, wt
+            d.ldx = x_in.ld
+            conv_op = L.OP_CONV
         if bn:
-            bnm = mod[1]
             if training:
                 y_raw = new_act(B, Ho, Wo, cout)
                 z = new_act(B, Ho, Wo, cout)
                 stats = new_ws(STAT_SLOTS * 2 * cout * 8)
                 vecs = new_ws(4 * cout * 4)          # scale | shift | mean | rstd
-                d.ldy, d.act, d.flags, d.stats_slots = y_raw.ld, 0, L.EPI_STATS, STAT_SLOTS
+                d.ldy, d.stats_slots = y_raw.ld, STAT_SLOTS
+                if not dw:
+                    d.act, d.flags = 0, L.EPI_STATS
                 later(lambda d=d, x_in=x_in, y_raw=y_raw, stats=stats: (
                     setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", ws.ptr(stats))))
-                plan.fwd.append((L.OP_CONV, d))
+                plan.fwd.append((conv_op, d))
                 f = L.DykBnFinalizeDesc()
                 plan._keep.append(f)
-                f.gamma, f.beta = store.p_ptr(pre + "BatchNorm2d.weight"), store.p_ptr(pre + "BatchNorm2d.bias")
+                f.gamma, f.beta = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
                 f.running_mean, f.running_var = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
                 f.C, f.count, f.momentum, f.eps, f.slots = cout, B * Ho * Wo, BN_MOMENTUM, BN_EPS, STAT_SLOTS
                 later(lambda f=f, stats=stats, vecs=vecs: (
@@ -246,15 +261,25 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 plan.fwd.append((L.OP_BN_ACT_FWD, a))
                 rec.update(y_raw=y_raw, z=z, vecs=vecs, bn_act_desc=a)
                 return z, rec
-            # eval: fold running statistics into the conv epilogue
+            # eval: running statistics folded into an affine (conv epilogue for the MFMA conv, one more
+            # streaming pass for the depthwise conv)
             z = new_act(B, Ho, Wo, cout)
             vecs = new_ws(2 * cout * 4)
             fo = misc()
-            fo.p[0], fo.p[1] = store.p_ptr(pre + "BatchNorm2d.weight"), store.p_ptr(pre + "BatchNorm2d.bias")
+            fo.p[0], fo.p[1] = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
             fo.p[2], fo.p[3] = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
             fo.i[0], fo.f[0] = cout, BN_EPS
             later(lambda fo=fo, vecs=vecs: (fo.p.__setitem__(4, ws.ptr(vecs)), fo.p.__setitem__(5, ws.ptr(vecs + 4 * cout))))
             plan.fwd.append((L.OP_BN_FOLD, fo))
+            if dw:
+                d.ldy = z.ld
+                later(lambda d=d, x_in=x_in, z=z: (setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(z))))
+                plan.fwd.append((conv_op, d))
+                a = ew_desc(a=z, out=z, act=act)
+                later(lambda a=a, vecs=vecs: (setattr(a, "p0", ws.ptr(vecs)), setattr(a, "p1", ws.ptr(vecs + 4 * cout))))
+                plan.fwd.append((L.OP_BN_ACT_FWD, a))
+                rec.update(z=z)
+                return z, rec
             d.ldy, d.act, d.flags = z.ld, act, L.EPI_AFFINE
             later(lambda d=d, x_in=x_in, z=z, vecs=vecs: (
                 setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)),
@@ -262,6 +287,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             plan.fwd.append((L.OP_CONV, d))
             rec.update(z=z)
             return z, rec
+        if dw:
+            raise NotImplementedError("depthwise conv without batch_normalize (layer %d)" % i)
         # no BN: bias epilogue; detection heads go to fp32 rows of HEAD_LD channels
         is_head = (i + 1 < len(defs) and defs[i + 1]["type"] == "yolo")
         if is_head:
@@ -272,7 +299,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             z = new_act(B, Ho, Wo, cout)
             d.flags = L.EPI_AFFINE
         d.ldy, d.act = z.ld, act
-        d.shift = store.p_ptr(pre + "Conv2d.bias")
+        d.shift = store.p_ptr(bias_name)
         later(lambda d=d, x_in=x_in, z=z: (setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(z))))
         plan.fwd.append((L.OP_CONV, d))
         rec.update(z=z, is_head=is_head)
@@ -285,14 +312,33 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         mod = mods[i]
         rec = {"kind": t, "i": i}
         if t == "convolutional":
-            if m.get("groups", 1) != 1:
-                raise NotImplementedError("grouped / depthwise [convolutional] (layer %d) is not built yet" % i)
             stem = None
             if i == 0:
                 stem = "x"
             elif second is not None and i == second:
                 stem = "y"
-            cur, rec = conv_forward(i, m, mod, cur, stem)
+            pre = "module_list.%d." % i
+            k = m["size"]
+            if "stride" not in m:
+                raise NotImplementedError("anisotropic stride_y/stride_x (layer %d)" % i)
+            bn = bool(m["batch_normalize"])
+            cur, rec = conv_forward(i, cur, stem, pre + "Conv2d.weight", (pre + "BatchNorm2d.") if bn else None,
+                                    mod[1] if bn else None, pre + "Conv2d.bias", k, m["stride"],
+                                    k // 2 if m["pad"] else 0, m["filters"], L.ACT_CODES.get(m["activation"], 0),
+                                    groups=m.get("groups", 1))
+        elif t == "depthwiseconvolutional":
+            # DepthwiseSeparableConv2d (layers.py:218-231): depthwise k x k (padding fixed at 1) + BN + ReLU6,
+            # then pointwise 1x1 + BN + ReLU6
+            pre = "module_list.%d.conv." % i
+            ks = m.get("size", 3)
+            if "stride" not in m:
+                raise NotImplementedError("anisotropic stride_y/stride_x (layer %d)" % i)
+            relu6 = L.ACT_CODES["relu6"]
+            mid, rec_dw = conv_forward(i, cur, None, pre + "0.weight", pre + "1.", mod.conv[1], None, ks, m["stride"], 1,
+                                       cur.C, relu6, groups=cur.C)
+            cur, rec_pw = conv_forward(i, mid, None, pre + "3.weight", pre + "4.", mod.conv[4], None, 1, 1, 0,
+                                       m["filters"], relu6)
+            rec = {"kind": "dwsep", "i": i, "parts": [rec_dw, rec_pw]}
         elif t == "route":
             layers = mod.layers
             if len(layers) == 1:
@@ -447,15 +493,35 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             red_offs.append((off, nbytes))
             return off
 
-        def emit_conv_backward(rec, dy, i):
-            """dy: gradient w.r.t. the conv's raw output (dtype), channels padded to 32 for heads"""
-            pre = "module_list.%d." % i
-            k, stride, pad, cout = rec["k"], rec["stride"], rec["pad"], rec["cout"]
+        def emit_conv_backward(rec, dy):
+            """dy: gradient w.r.t. the conv's raw output (dtype), rows zero padded to a multiple of 32 channels"""
+            k, stride, pad, cout, wname = rec["k"], rec["stride"], rec["pad"], rec["cout"], rec["wname"]
+            x_in = rec["x"]
+            if rec["dw"]:
+                wd = L.DykDwDesc()
+                plan._keep.append(wd)
+                wd.dtype, wd.w, wd.dw = code, store.p_ptr(wname), store.g_ptr(wname)
+                wd.B, wd.Hi, wd.Wi, wd.Ho, wd.Wo, wd.C = B, x_in.H, x_in.W, dy.H, dy.W, cout
+                wd.k, wd.stride, wd.pad = k, stride, pad
+                wd.ldx, wd.ldy = x_in.ld, dy.ld
+                later(lambda wd=wd, x=x_in, dy=dy: (setattr(wd, "x", ptr_of(x)), setattr(wd, "y", ptr_of(dy))))
+                plan.bwd.append((L.OP_DW_WGRAD, wd))
+                gx = gref(x_in)
+                gd = L.DykDwDesc()
+                plan._keep.append(gd)
+                gd.dtype, gd.w = code, store.p_ptr(wname)
+                gd.B, gd.Hi, gd.Wi, gd.Ho, gd.Wo, gd.C = B, x_in.H, x_in.W, dy.H, dy.W, cout
+                gd.k, gd.stride, gd.pad = k, stride, pad
+                gd.ldx, gd.ldy = gx.ld, dy.ld
+                gd.flags = acc_flag(x_in)
+                later(lambda gd=gd, gx=gx, dy=dy: (setattr(gd, "x", ptr_of(gx)), setattr(gd, "y", ptr_of(dy))))
+                plan.bwd.append((L.OP_DW_DGRAD, gd))
+                return
             wg = rec["wgrad"]
             wd = L.DykWgradDesc()
             plan._keep.append(wd)
             wd.dtype = code
-            wd.dw = store.g_ptr(pre + "Conv2d.weight")
+            wd.dw = store.g_ptr(wname)
             wd.ldx, wd.lddy = wg["x"].ld, dy.ld
             wd.B, wd.Hi, wd.Wi, wd.Cin = B, wg["Hi"], wg["Wi"], wg["Cin"]
             wd.Ho, wd.Wo, wd.Cout = dy.H, dy.W, cout
@@ -468,17 +534,20 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             plan.bwd.append((L.OP_WGRAD, wd))
             if rec["stem"]:
                 return
-            x_in = rec["x"]
             gx = gref(x_in)
             first = x_in.tid not in ginit
-            e = store.by_name[pre + "Conv2d.weight"]
+            e = store.by_name[wname]
             kpad = _ru(cout, 32)
+            if dy.ld < kpad:
+                raise NotImplementedError("gradient rows narrower than the padded K (layer %d)" % rec["i"])
             if kpad != cout:
-                wt_ptr = cw["heads_t"][pre + "Conv2d.weight"].data_ptr()
+                wt_ptr = cw["Wt_pad"].data_ptr() + cw["bwd_pad_off"][wname] * es
             else:
                 wt_ptr = cw["Wt"].data_ptr() + e.offset * es
             classes = dgrad_classes(k, pad, stride, x_in.H, x_in.W)
             for (py, px, Hg, Wg, taps) in classes:
+                if not taps and not first:
+                    continue                      # nothing to accumulate for this parity class
                 d = L.DykConvDesc()
                 plan._keep.append(d)
                 d.dtype = code
@@ -497,6 +566,39 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 plan.bwd.append((L.OP_CONV, d))
             ginit.add(x_in.tid)
 
+        def conv_layer_backward(rec):
+            """BatchNorm+activation backward (train-mode statistics) followed by the conv gradients"""
+            z = rec["z"]
+            if z.tid not in ginit:
+                return                           # no gradient reaches this layer
+            dz = gref(z)
+            if rec["bn"]:
+                cout, vecs, bnpre = rec["cout"], rec["vecs"], rec["bnpre"]
+                red = new_red(STAT_SLOTS * 2 * cout * 8)
+                r = ew_desc(a=dz, b=rec["y_raw"], act=rec["act"])
+                r.slots = STAT_SLOTS
+                later(lambda r=r, vecs=vecs, red=red, cout=cout: (
+                    setattr(r, "p0", ws.ptr(vecs)), setattr(r, "p1", ws.ptr(vecs + 4 * cout)),
+                    setattr(r, "p2", ws.ptr(vecs + 8 * cout)), setattr(r, "p3", ws.ptr(vecs + 12 * cout)),
+                    setattr(r, "red", ws.ptr(red))))
+                plan.bwd.append((L.OP_BN_BWD_REDUCE, r))
+                pm = misc()
+                pm.p[1], pm.p[2] = store.g_ptr(bnpre + "weight"), store.g_ptr(bnpre + "bias")
+                pm.i[0], pm.i[1] = cout, STAT_SLOTS
+                later(lambda pm=pm, red=red: pm.p.__setitem__(0, ws.ptr(red)))
+                plan.bwd.append((L.OP_BN_BWD_PARAMS, pm))
+                dyr = dz
+                if os.environ.get("DYK_DEBUG_PLAN"):      # keep dz intact for per-layer gradient dumps
+                    dyr = TRef("grad", grad_arena.alloc(dz.npix * dz.ld * es), dz.B, dz.H, dz.W, dz.C, dz.ld, es)
+                ap = ew_desc(a=dz, b=rec["y_raw"], out=dyr, act=rec["act"])     # in place: dz -> dy_raw
+                later(lambda ap=ap, vecs=vecs, red=red, cout=cout: (
+                    setattr(ap, "p0", ws.ptr(vecs)), setattr(ap, "p1", ws.ptr(vecs + 4 * cout)),
+                    setattr(ap, "p2", ws.ptr(vecs + 8 * cout)), setattr(ap, "p3", ws.ptr(vecs + 12 * cout)),
+                    setattr(ap, "red", ws.ptr(red))))
+                plan.bwd.append((L.OP_BN_BWD_APPLY, ap))
+                dz = dyr
+            emit_conv_backward(rec, dz)
+
         memset_desc = misc()
         plan.bwd.append((L.OP_MEMSET, memset_desc))          # slot 0: clears the fp64 reduction scratch
         plan.bwd_marks = []                                  # (number of commands emitted, layer index) in backward order
@@ -510,44 +612,17 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 y_in = rec["y"]
                 gy = gref(y_in, ld=HEAD_LD)          # dtype rows of 32 channels, zero padded
                 hd = misc()
-                hd.p[2] = store.g_ptr("module_list.%d.Conv2d.bias" % (i - 1))
+                hd.p[2] = store.g_ptr(info[i - 1]["bias_name"])
                 hd.i[0], hd.i[1], hd.i[2], hd.i[3], hd.i[4], hd.i[5], hd.i[6] = B, rec["ny"], rec["nx"], rec["na"], rec["no"], HEAD_LD, code
                 later(lambda hd=hd, gy=gy: hd.p.__setitem__(1, ptr_of(gy)))
                 plan.dyn_dp.append((hd, rec["head"]))
                 plan.bwd.append((L.OP_HEAD_PERMUTE_BWD, hd))
                 ginit.add(y_in.tid)
             elif t == "conv":
-                z = rec["z"]
-                if z.tid not in ginit:
-                    continue                         # no gradient reaches this layer
-                dz = gref(z)
-                if rec["bn"]:
-                    cout, vecs = rec["cout"], rec["vecs"]
-                    red = new_red(STAT_SLOTS * 2 * cout * 8)
-                    r = ew_desc(a=dz, b=rec["y_raw"], act=rec["act"])
-                    r.slots = STAT_SLOTS
-                    later(lambda r=r, vecs=vecs, red=red, cout=cout: (
-                        setattr(r, "p0", ws.ptr(vecs)), setattr(r, "p1", ws.ptr(vecs + 4 * cout)),
-                        setattr(r, "p2", ws.ptr(vecs + 8 * cout)), setattr(r, "p3", ws.ptr(vecs + 12 * cout)),
-                        setattr(r, "red", ws.ptr(red))))
-                    plan.bwd.append((L.OP_BN_BWD_REDUCE, r))
-                    pm = misc()
-                    pre = "module_list.%d." % i
-                    pm.p[1], pm.p[2] = store.g_ptr(pre + "BatchNorm2d.weight"), store.g_ptr(pre + "BatchNorm2d.bias")
-                    pm.i[0], pm.i[1] = cout, STAT_SLOTS
-                    later(lambda pm=pm, red=red: pm.p.__setitem__(0, ws.ptr(red)))
-                    plan.bwd.append((L.OP_BN_BWD_PARAMS, pm))
-                    dyr = dz
-                    if os.environ.get("DYK_DEBUG_PLAN"):      # keep dz intact for per-layer gradient dumps
-                        dyr = TRef("grad", grad_arena.alloc(dz.npix * dz.ld * es), dz.B, dz.H, dz.W, dz.C, dz.ld, es)
-                    ap = ew_desc(a=dz, b=rec["y_raw"], out=dyr, act=rec["act"])     # in place: dz -> dy_raw
-                    later(lambda ap=ap, vecs=vecs, red=red, cout=cout: (
-                        setattr(ap, "p0", ws.ptr(vecs)), setattr(ap, "p1", ws.ptr(vecs + 4 * cout)),
-                        setattr(ap, "p2", ws.ptr(vecs + 8 * cout)), setattr(ap, "p3", ws.ptr(vecs + 12 * cout)),
-                        setattr(ap, "red", ws.ptr(red))))
-                    plan.bwd.append((L.OP_BN_BWD_APPLY, ap))
-                    dz = dyr
-                emit_conv_backward(rec, dz, i)
+                conv_layer_backward(rec)
+            elif t == "dwsep":
+                for sub in reversed(rec["parts"]):
+                    conv_layer_backward(sub)
             elif t == "route":
                 out = rec["out"]
                 if out.tid not in ginit:

@@ -283,18 +283,48 @@ int dyk_nhwc_to_nchw(const void* in, float* out, int32_t B, int32_t C, int32_t H
                      int32_t ldi, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Depthwise convolution (nn.Conv2d(groups=C), reference models.py:41 for `groups=` sections and
+ * layers.py:223-224 for DepthwiseSeparableConv2d), square kernel k, zero padding `pad`, stride 1 or 2.
+ * w is the fp32 master weight in tap-major order [k*k][C] (the parameter store layout).
+ *   dyk_dwconv_fwd   : y[b,yo,xo,c] = sum_t x[b, yo*s+kh-pad, xo*s+kw-pad, c] * w[t][c]
+ *                      stats (optional): replicated fp64 [slots][2][C] sum / sum of squares of y
+ *   dyk_dwconv_dgrad : x := gradient wrt the conv input [B,Hi,Wi,C] (written, or accumulated with
+ *                      DYK_EW_ACCUM), y := gradient wrt the conv output [B,Ho,Wo,C] (read)
+ *   dyk_dwconv_wgrad : dw[t][c] += sum_p y[p][c] * x[src(p,t)][c]     (y = output gradient)
+ * In the two gradient entry points the roles follow the tensor, not the data direction:
+ * x/ldx/Hi/Wi always describe the conv-input-shaped tensor, y/ldy/Ho/Wo the conv-output-shaped one.
+ * ---------------------------------------------------------------------------------- */
+typedef struct DykDwDesc {
+    void* x;
+    void* y;
+    const float* w;
+    float* dw;
+    double* stats;
+    int32_t dtype, ldx, ldy;
+    int32_t B, Hi, Wi, Ho, Wo, C;
+    int32_t k, stride, pad;
+    int32_t flags, stats_slots;
+} DykDwDesc;
+int dyk_dwconv_fwd(const DykDwDesc* desc, void* stream);
+int dyk_dwconv_dgrad(const DykDwDesc* desc, void* stream);
+int dyk_dwconv_wgrad(const DykDwDesc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Parameter staging.  Master parameters and gradients are fp32, conv weights stored
  * tap-major [kh*kw][Cout][Cin] (DESIGN.md "parameter store").
  *   dyk_cast_f32       : dst[i] = (dtype) src[i]                      (whole flat buffer, one launch)
  *   dyk_cast_pad_rows  : dst[r][c] = src[r][c] (c < C), 0 (C <= c < Cpad)   (stem weights, K padded)
  *   dyk_transpose_taps : for each entry e of a device table: dst_e[t][ci][co] = src_e[t][co][ci]
- *                        (weights for the data-gradient GEMM), one launch for all layers.
+ *                        (weights for the data-gradient GEMM), one launch for all layers; dst rows may be
+ *                        padded to dst_ld (channel counts that are not a multiple of the GEMM K step).
  * ---------------------------------------------------------------------------------- */
 typedef struct DykTransposeEntry {
     int64_t src_off;      /* element offset into src (fp32) */
     int64_t dst_off;      /* element offset into dst (dtype) */
     int32_t taps, rows, cols;   /* src is [taps][rows][cols] */
     int32_t tile_begin;   /* first 32x32 tile index of this entry (exclusive prefix sum) */
+    int32_t dst_ld;       /* row length of dst (>= rows, <= rows rounded up to 32; 0 = rows); the tail is zero-filled */
+    int32_t _pad;
 } DykTransposeEntry;
 int dyk_cast_f32(const float* src, void* dst, int64_t n, int32_t dtype, void* stream);
 int dyk_cast_pad_rows(const float* src, void* dst, int32_t R, int32_t C, int32_t Cpad, int32_t dtype, void* stream);
@@ -341,7 +371,10 @@ enum {
     DYK_OP_PATCH_GATHER = 23,   /* Misc: p0=in p1=out i0=B i1=Cin i2=H i3=W i4=k i5=stride i6=pad i7=ld i8=dtype f0=mul */
     DYK_OP_MEMSET = 24,         /* Misc: p0=ptr n=bytes i0=value */
     DYK_OP_YOLO_DECODE = 25,    /* DykDecodeDesc */
-    DYK_OP_DW_CONV = 26,        /* reserved: depthwise conv */
+    DYK_OP_DW_FWD = 26,         /* DykDwDesc -> dyk_dwconv_fwd */
+    DYK_OP_DW_DGRAD = 27,       /* DykDwDesc -> dyk_dwconv_dgrad */
+    DYK_OP_DW_WGRAD = 28,       /* DykDwDesc -> dyk_dwconv_wgrad */
+    DYK_OP_CAST_PAD_ROWS = 29,  /* Misc: p0=src p1=dst i0=R i1=C i2=Cpad i3=dtype */
     DYK_OP_COUNT_
 };
 

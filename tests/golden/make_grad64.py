@@ -2,7 +2,7 @@
 the target cfg, evaluated by oracle.model in fp64 and in fp32, sampled at 64 fixed positions per parameter
 tensor plus the tensor norms.  Lets the GPU test bound the HIP path's gradient error by torch-fp32's own
 error against the fp64 truth without re-running a 10-minute fp64 CPU pass on the GPU box.
-    python tests/golden/make_grad64.py"""
+    python tests/golden/make_grad64.py [cfg name ...]      (default: the target cfg and the MobileNetV3 one)"""
 import os
 import sys
 
@@ -12,7 +12,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "double-yolo-kaist_amd"), os.path.join(ROOT, "tests")]
-from helpers import C3, oracle_net  # noqa: E402
+from helpers import C3, C5, oracle_net  # noqa: E402
 
 K = 64
 
@@ -22,9 +22,9 @@ def sample_index(numel, name):
     return g.randint(0, numel, size=K)
 
 
-def main():
+def main(name):
     torch.set_num_threads(8)
-    net = oracle_net(C3)
+    net = oracle_net(name)
     g = torch.Generator().manual_seed(1234)
     x = torch.rand(2, 3, 128, 160, generator=g)
     y = torch.rand(2, 3, 128, 160, generator=g)
@@ -49,9 +49,10 @@ def main():
             out["err32_norm"] = np.array([float((sd[k].grad.double() - g64_full[k]).norm()) for k in names])
         else:
             g64_full = {k: sd[k].grad.double().clone() for k in names}
-    np.savez_compressed(os.path.join(HERE, "grad64_%s.npz" % C3), names=np.array(names), **out)
+    np.savez_compressed(os.path.join(HERE, "grad64_%s.npz" % name), names=np.array(names), **out)
     print("written", len(names))
 
 
 if __name__ == "__main__":
-    main()
+    for cfg_name in (sys.argv[1:] or [C3, C5]):
+        main(cfg_name)

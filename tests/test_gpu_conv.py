@@ -156,3 +156,65 @@ def test_conv_wgrad_head_padded_ld():
     dw = ops.conv2d_wgrad(xd, buf[..., :Cout], 1, 1, 0)
     err = (dw.view(Cout, Cin).cpu() - dw_ref.view(Cout, Cin)).abs().max().item()
     assert err <= 1e-4 * max(1.0, dw_ref.abs().max().item())
+
+
+DW_CASES = [
+    # (B, C, H, W, k, stride, pad)
+    (2, 64, 16, 20, 3, 1, 1),
+    (2, 72, 17, 23, 3, 1, 1),       # C not a multiple of 32 (rows padded to 96), ragged extent
+    (1, 120, 12, 12, 5, 1, 2),      # 25 taps
+    (2, 16, 32, 40, 3, 2, 1),       # DepthwiseSeparableConv2d stride 2
+    (2, 200, 9, 11, 3, 2, 1),       # odd size stride 2
+    (1, 960, 4, 5, 5, 1, 2),
+    (1, 40, 10, 10, 5, 1, 1),       # DepthwiseSeparableConv2d keeps padding 1 for any kernel size (layers.py:223)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", DW_CASES)
+def test_depthwise_conv_fwd_dgrad_wgrad(case, dtype):
+    """dyk_dwconv_{fwd,dgrad,wgrad} against torch CPU conv2d(groups=C) and its autograd"""
+    from dyk import ops
+    B, C, H, W, k, s, pad = case
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g) / k
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y_ref = F.conv2d(x, w, stride=s, padding=pad, groups=C)
+    dy = torch.randn(y_ref.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    y_ref.backward(dy)
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+    cpad = (C + 31) // 32 * 32
+    xd = ops.to_nhwc(x.detach().cuda(), dtype, cpad=cpad)
+    wt = w.detach().reshape(C, k * k).t().contiguous().cuda()          # tap-major [k*k][C] fp32
+    slots = 4
+    stats = torch.zeros(slots, 2, C, dtype=torch.float64, device="cuda")
+    y = ops.dwconv_fwd(xd, wt, k, s, pad, stats=stats, stats_slots=slots, C=C)
+    y_nchw = ops.to_nchw(y, C=C).cpu()
+    err = (y_nchw - y_ref.detach()).abs().max().item()
+    assert err <= tol * max(1.0, y_ref.abs().max().item()), "fwd max err %g" % err
+    assert float(y[..., C:].abs().max()) == 0.0 if cpad > C else True
+    # statistics are taken from the fp32 accumulators (before rounding to the storage dtype)
+    st = stats.sum(0).cpu()
+    yr = y_ref.detach().double()
+    n = B * y_ref.shape[2] * y_ref.shape[3]
+    assert torch.allclose(st[0], yr.sum((0, 2, 3)), rtol=1e-4, atol=1e-3 * n ** 0.5)
+    assert torch.allclose(st[1], (yr * yr).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+    dyd = ops.to_nhwc(dy.cuda(), dtype, cpad=cpad)
+    dx = ops.dwconv_dgrad(dyd, wt, k, s, pad, H, W, C=C)
+    err = (ops.to_nchw(dx, C=C).cpu() - x.grad).abs().max().item()
+    assert err <= tol * max(1.0, x.grad.abs().max().item()), "dgrad max err %g" % err
+    ops.dwconv_dgrad(dyd, wt, k, s, pad, H, W, C=C, out=dx, accumulate=True)
+    err = (ops.to_nchw(dx, C=C).cpu() - 2 * x.grad).abs().max().item()
+    assert err <= 2.5 * tol * max(1.0, x.grad.abs().max().item()), "dgrad accumulate max err %g" % err
+
+    dw = ops.dwconv_wgrad(xd, dyd, k, s, pad, C=C)
+    dw_ref = w.grad.reshape(C, k * k).t()
+    err = (dw.cpu() - dw_ref).abs().max().item()
+    assert err <= 1e-4 * max(1.0, dw_ref.abs().max().item()), "wgrad max err %g" % err

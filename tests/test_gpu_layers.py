@@ -97,3 +97,32 @@ def test_yolo_layer_standalone():
         err = ((io.cpu() - want.view(2, -1, 6)).abs() / want.view(2, -1, 6).abs().clamp(min=1)).max().item()
         assert err < 2e-6
         assert torch.equal(raw.cpu(), ref)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_depthwise_separable_block(stride):
+    """DepthwiseSeparableConv2d (reference layers.py:218-231), eval and train, C = 40 (rows padded to 64)"""
+    from build_utils.layers import DepthwiseSeparableConv2d
+    torch.manual_seed(5)
+    blk = DepthwiseSeparableConv2d(40, 72, 3, stride)
+    with torch.no_grad():
+        for j in (1, 4):
+            blk.conv[j].running_mean.normal_(0, 0.2)
+            blk.conv[j].running_var.uniform_(0.5, 1.5)
+            blk.conv[j].weight.uniform_(0.5, 1.5)
+            blk.conv[j].bias.normal_(0, 0.2)
+    ref_blk = nn.Sequential(nn.Conv2d(40, 40, 3, stride, 1, groups=40, bias=False), nn.BatchNorm2d(40), nn.ReLU6(),
+                            nn.Conv2d(40, 72, 1, 1, 0, bias=False), nn.BatchNorm2d(72), nn.ReLU6())
+    ref_blk.load_state_dict(blk.conv.state_dict())
+    x = torch.randn(2, 40, 16, 20)
+    ref_blk.eval()
+    ref = ref_blk(x).detach()
+    blk = blk.cuda().eval()
+    _close(blk(x.cuda()), ref, 5e-5)
+    ref_blk.train()
+    ref_t = ref_blk(x).detach()
+    blk.train()
+    _close(blk(x.cuda()), ref_t, 5e-5)
+    for j in (1, 4):
+        _close(blk.conv[j].running_mean, ref_blk[j].running_mean, 1e-5)
+        _close(blk.conv[j].running_var, ref_blk[j].running_var, 1e-5)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import C1, C2, C3, CFGS, GOLDEN, oracle_net
+from helpers import C1, C2, C3, C5, CFGS, GOLDEN, MNV2, oracle_net
 
 
 def _model(name):
@@ -119,14 +119,78 @@ def test_plan_compiles_consistently(name, training):
             assert a.ptr() <= d.y < a.ptr() + a.size
 
 
-def test_unsupported_sections_fail_loudly():
+def test_unsupported_sections_fail_loudly(tmp_path):
+    """cfg features outside the built path (here: a stride-2 [maxpool]) raise instead of computing something else"""
     from dyk.params import ParamStore
     from dyk.plan import compile_plan
-    m = _model("kaist_dyolov4_mobilenetv3_fshare_global_cse3")
+    from models import YOLO
+    cfg = tmp_path / "tiny_kaist.cfg"
+    cfg.write_text("""[net]
+channels=3
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[maxpool]
+size=2
+stride=2
+
+[convolutional]
+size=1
+stride=1
+pad=1
+filters=18
+activation=linear
+
+[yolo]
+mask = 0,1,2
+anchors = 10,13, 16,30, 33,23
+classes=1
+num=3
+""")
+    m = YOLO(str(cfg))
     st = ParamStore(m)
     st.adopt(torch.device("cpu"))
     with pytest.raises(NotImplementedError):
         compile_plan(m, st, 1, 64, 64, torch.bfloat16, False, torch.device("cpu"), dry=True)
+
+
+@pytest.mark.parametrize("name", [C5, MNV2])
+def test_mobilenet_plans_use_depthwise_and_padded_channel_rows(name):
+    """MobileNet cfgs: grouped [convolutional] and [depthwiseconvolutional] sections go to the depthwise kernels,
+    channel counts off the GEMM K step (16, 24, 40, 72, ...) live in rows padded to 32 with padded weight packs."""
+    from dyk import lib as L
+    from dyk.params import ParamStore
+    from dyk.plan import compile_plan
+    m = _model(name)
+    st = ParamStore(m)
+    st.adopt(torch.device("cpu"))
+    n_dw = sum(1 for d in m.module_defs if d["type"] == "convolutional" and d.get("groups", 1) > 1)
+    n_sep = sum(1 for d in m.module_defs if d["type"] == "depthwiseconvolutional")
+    n_dense = sum(1 for d in m.module_defs if d["type"] == "convolutional" and d.get("groups", 1) == 1)
+    assert n_dw > 0 and n_sep > 0
+    assert sum(1 for e in st.entries if e.kind == "dw_w") == n_dw + n_sep
+    fwd_off, fwd_n, bwd_off, bwd_n = st._layout_padded()
+    for e in st.entries:
+        if e.kind == "conv_w":
+            assert (e.name in fwd_off) == bool(e.shape[1] % 32) and (e.name in bwd_off) == bool(e.shape[0] % 32)
+    plan = compile_plan(m, st, 2, 64, 96, torch.bfloat16, True, torch.device("cpu"), dry=True)
+    ops = [op for op, _ in plan.fwd]
+    bops = [op for op, _ in plan.bwd]
+    assert ops.count(L.OP_DW_FWD) == n_dw + n_sep
+    assert ops.count(L.OP_CONV) == n_dense + n_sep
+    assert bops.count(L.OP_DW_WGRAD) == bops.count(L.OP_DW_DGRAD) == n_dw + n_sep
+    assert bops.count(L.OP_WGRAD) == n_dense + n_sep
+    for op, d in plan.fwd + plan.bwd:
+        if op == L.OP_CONV:
+            assert d.Cin % 32 == 0 and d.ldx >= d.Cin and d.ldy % 8 == 0
+        if op in (L.OP_DW_FWD, L.OP_DW_DGRAD, L.OP_DW_WGRAD):
+            assert d.ldx % 32 == 0 and d.ldy % 32 == 0 and d.C % 8 == 0
 
 
 def test_darknet_weights_roundtrip(tmp_path):
