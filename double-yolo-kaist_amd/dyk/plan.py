@@ -722,7 +722,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         fn()
     plan.finalize()
     if not dry and os.environ.get("DYK_AUTOTUNE", "1") != "0":
-        autotune(plan, getattr(model, "_dyk_tune_cache", None))
+        autotune(plan, _TUNE_CACHE)
     plan.info = info
     plan.grads = grads if training else {}
     plan.outs = outs
@@ -733,6 +733,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
 
 
 # ======================================================================================
+_TUNE_CACHE = {}     # process-wide: the same problem always runs the same tile configuration (bit-reproducible
+                     # results across plans / model instances within a process)
 _CONV_CANDIDATES = [64 | (2 << 8), 64 | (3 << 8), 128 | (2 << 8), 128 | (3 << 8)]
 _WGRAD_CANDIDATES = [2, 3]
 
