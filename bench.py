@@ -55,11 +55,12 @@ def conv_flops(plan):
     """algorithmic conv flops of one forward pass of the plan: 2*B*Ho*Wo*Cout*Cin*k*k per [convolutional]"""
     total = 0.0
     for rec in plan.info:
-        if rec.get("kind") != "conv":
-            continue
-        z = rec["z"]
-        cin = 3 if rec["stem"] else rec["x"].C
-        total += 2.0 * z.B * z.H * z.W * rec["cout"] * cin * rec["k"] * rec["k"]
+        for r in (rec["parts"] if rec.get("kind") == "dwsep" else [rec]):
+            if r.get("kind") != "conv":
+                continue
+            z = r["z"]
+            cin = 3 if r["stem"] else (1 if r["dw"] else r["x"].C)
+            total += 2.0 * z.B * z.H * z.W * r["cout"] * cin * r["k"] * r["k"]
     return total
 
 

@@ -17,6 +17,7 @@
 // that follow it at :46-62 when run with the AFFINE epilogue), and autograd's
 // convolution_backward (input gradient) for the same layers.
 #include <stdlib.h>
+#include <type_traits>
 #include "dyk_common.h"
 
 namespace {
@@ -79,7 +80,7 @@ __device__ inline unsigned lds_addr_of(const void* p) {
 
 // PIPE: 0 = register-staged double buffer, 2 / 3 = LDS-DMA ring of that many stages
 template <typename T, int BM, int BKB, int PIPE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_kernel(const ConvArgs args) {
     constexpr bool DMA = PIPE != 0;
     const DykConvDesc& a = args.d;
     constexpr int BN = 128;
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
+    if ((a.tune >> 18) & 1) return;            // ablation: empty kernel
 
     const int tiles_m = (a.Cout + BM - 1) / BM;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
         tap_w[q] = a.twt[q] * a.Cout * a.Cin;
     }
     __syncthreads();
+    if ((a.tune >> 19) & 1) return;            // ablation: tables only
 
     f32x4_t acc[MI][NI];
 #pragma unroll
@@ -348,10 +351,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
 
     // ------------------------------------------------------------------ epilogue
     // (both pipelines leave the loop behind a workgroup barrier: the ring is free to be overwritten)
+    if ((a.tune >> 20) & 1) {                  // ablation: no epilogue (keep the accumulators alive)
+        float sum = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) sum += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+        if (sum == 123.456f) ((float*)a.y)[0] = sum;
+        return;
+    }
     const int flags = a.flags;
     const int mlane = (lane >> 4) * 4;
     if (flags & DYK_EPI_STATS) {
-        // per-channel sum / sum of squares of the raw accumulators: in-lane over ni, xor-shuffle over the
+        // per-channel sum / sum of squares of the raw accumulators: in-lane over ni, DPP row rotate-adds over the
         // 16 pixel lanes, LDS atomics across the waves of the workgroup, then ONE fp64 atomic per channel
         // and workgroup into a replica of the statistics buffer.
         for (int i = tid; i < 2 * BM; i += 256) s_stat[i] = 0.f;
@@ -366,11 +378,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
                     const float v = acc[mi][ni][r];
                     s1 += v; s2 += v * v;
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1 += __shfl_xor(s1, o, 64);
-                    s2 += __shfl_xor(s2, o, 64);
-                }
+                s1 = row16_sum(s1);
+                s2 = row16_sum(s2);
                 if ((lane & 15) == 0) {
                     const int ml = wm * WTM + mi * 16 + mlane + r;
                     atomicAdd(s_stat + ml, s1);
@@ -396,94 +405,133 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs args) {
         // ---- staged, coalesced store: accumulators -> LDS tile [pixel][channel] -> 16-byte global stores
         // in which 16 consecutive lanes cover one contiguous channel row of a pixel (the per-lane 8-byte
         // scatter of the MFMA layout wrote 32-byte fragments and cost 2-3x the store time).
-        const int eso = out_f32 ? 4 : 2;                  // output element size
-        const int rstride = BM * eso + 16;                // padded row stride (bytes)
+        // The code is instantiated per (output type, activation) and selected by ONE switch: with the
+        // activation switch inside the 64-value unrolled loop the epilogue was 20k instructions of
+        // branches and cost 9 us per launch (tools/gpu_probe.py ablate).
+        auto staged = [&](auto of32_tag, auto act_tag, auto affine_tag) {
+            constexpr bool OF32 = decltype(of32_tag)::value;
+            constexpr int ACT = decltype(act_tag)::value;
+            constexpr bool AFF = decltype(affine_tag)::value;
+            constexpr int eso = OF32 ? 4 : 2;                     // output element size
+            constexpr int rstride = BM * eso + 16;                // padded row stride (bytes)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int ml = wm * WTM + mi * 16 + mlane;
-            const int m = m0 + ml;
-            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-            if (affine) {
+            for (int mi = 0; mi < MI; ++mi) {
+                const int ml = wm * WTM + mi * 16 + mlane;
+                const int m = m0 + ml;
+                float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (AFF) {
+                    if (m + 3 < a.Cout) {
+                        if (a.scale) { const float4 t = *(const float4*)(a.scale + m); sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; }
+                        if (a.shift) { const float4 t = *(const float4*)(a.shift + m); sh[0] = t.x; sh[1] = t.y; sh[2] = t.z; sh[3] = t.w; }
+                    } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (m + r < a.Cout) {
-                        if (a.scale) sc[r] = a.scale[m + r];
-                        if (a.shift) sh[r] = a.shift[m + r];
+                        for (int r = 0; r < 4; ++r)
+                            if (m + r < a.Cout) {
+                                if (a.scale) sc[r] = a.scale[m + r];
+                                if (a.shift) sh[r] = a.shift[m + r];
+                            }
                     }
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int nl = wn * WTN + ni * 16 + (lane & 15);
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float u = acc[mi][ni][r];
+                        if constexpr (AFF) u = u * sc[r] + sh[r];
+                        v[r] = act_fwd_c<ACT>(u, a.act);
+                    }
+                    char* dst = sC + nl * rstride + ml * eso;
+                    if constexpr (OF32) {
+                        *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        uint2 pk;
+                        pk.x = f32x2_to_bf16x2(v[0], v[1]);
+                        pk.y = f32x2_to_bf16x2(v[2], v[3]);
+                        *(uint2*)dst = pk;
+                    }
+                }
             }
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int nl = wn * WTN + ni * 16 + (lane & 15);
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float u = acc[mi][ni][r];
-                    if (affine) u = u * sc[r] + sh[r];
-                    v[r] = act_fwd(a.act, u);
-                }
-                char* dst = sC + nl * rstride + ml * eso;
-                if (out_f32) {
-                    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    *(uint2*)dst = pk;
-                }
-            }
-        }
-        __syncthreads();
-        const int epv_o = 16 / eso;                       // output elements per 16-byte chunk
-        const int cpr = BM / epv_o;                       // chunks per tile row
-        const int nchunk = BN * cpr;
-        for (int q = tid; q < nchunk; q += 256) {
-            const int row = q / cpr, cc = q - row * cpr;
-            const int po = t_out[row];
-            const int mc = m0 + cc * epv_o;
-            if (po < 0 || mc >= a.Cout) continue;
-            if (abl_nostore && t_out[0] != -12345) continue;
-            uint4 val = *(const uint4*)(sC + row * rstride + cc * 16);
-            const bool whole = (mc + epv_o <= a.Cout);
-            if (out_f32) {
-                float* yp = (float*)a.y + (long)po + mc;
-                float f[4] = {__uint_as_float(val.x), __uint_as_float(val.y), __uint_as_float(val.z), __uint_as_float(val.w)};
-                if (has_res) {
-                    const T* rp = (const T*)a.res + (long)t_res[row] + mc;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (mc + j < a.Cout) f[j] += ElemTraits<T>::to_f32(rp[j]);
-                }
-                if (accum) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (mc + j < a.Cout) f[j] += yp[j];
-                }
-                if (whole) *(float4*)yp = make_float4(f[0], f[1], f[2], f[3]);
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (mc + j < a.Cout) yp[j] = f[j];
-                }
-            } else {
-                bf16_t* yp = (bf16_t*)a.y + (long)po + mc;
-                if (has_res || accum || !whole) {
-                    float f[8];
-                    vec_unpack<bf16_t>(val, f);
+            __syncthreads();
+            constexpr int epv_o = 16 / eso;                       // output elements per 16-byte chunk
+            constexpr int cpr = BM / epv_o;                       // chunks per tile row
+            constexpr int nchunk = BN * cpr;
+            for (int q = tid; q < nchunk; q += 256) {
+                const int row = q / cpr, cc = q % cpr;
+                const int po = t_out[row];
+                const int mc = m0 + cc * epv_o;
+                if (po < 0 || mc >= a.Cout) continue;
+                if (abl_nostore && t_out[0] != -12345) continue;
+                uint4 val = *(const uint4*)(sC + row * rstride + cc * 16);
+                const bool whole = (mc + epv_o <= a.Cout);
+                if constexpr (OF32) {
+                    float* yp = (float*)a.y + (long)po + mc;
+                    float f[4] = {__uint_as_float(val.x), __uint_as_float(val.y), __uint_as_float(val.z), __uint_as_float(val.w)};
                     if (has_res) {
-                        const bf16_t* rp = (const bf16_t*)a.res + (long)t_res[row] + mc;
+                        const T* rp = (const T*)a.res + (long)t_res[row] + mc;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) if (mc + j < a.Cout) f[j] += bf16_to_f32(rp[j]);
+                        for (int j = 0; j < 4; ++j) if (mc + j < a.Cout) f[j] += ElemTraits<T>::to_f32(rp[j]);
                     }
                     if (accum) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) if (mc + j < a.Cout) f[j] += bf16_to_f32(yp[j]);
+                        for (int j = 0; j < 4; ++j) if (mc + j < a.Cout) f[j] += yp[j];
                     }
-                    if (whole) *(uint4*)yp = vec_pack<bf16_t>(f);
+                    if (whole) *(float4*)yp = make_float4(f[0], f[1], f[2], f[3]);
                     else {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) if (mc + j < a.Cout) yp[j] = f32_to_bf16(f[j]);
+                        for (int j = 0; j < 4; ++j) if (mc + j < a.Cout) yp[j] = f[j];
                     }
                 } else {
-                    *(uint4*)yp = val;
+                    bf16_t* yp = (bf16_t*)a.y + (long)po + mc;
+                    if (whole && !has_res && !accum) {
+                        *(uint4*)yp = val;
+                    } else if (whole) {
+                        float f[8];
+                        vec_unpack<bf16_t>(val, f);
+                        if (has_res) {
+                            float g[8];
+                            vec_unpack<bf16_t>(*(const uint4*)((const bf16_t*)a.res + (long)t_res[row] + mc), g);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) f[j] += g[j];
+                        }
+                        if (accum) {
+                            float g[8];
+                            vec_unpack<bf16_t>(*(const uint4*)yp, g);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) f[j] += g[j];
+                        }
+                        *(uint4*)yp = vec_pack<bf16_t>(f);
+                    } else {
+                        float f[8];
+                        vec_unpack<bf16_t>(val, f);
+                        for (int j = 0; j < 8; ++j) {
+                            if (mc + j >= a.Cout) break;
+                            float u = f[j];
+                            if (has_res) u += bf16_to_f32(((const bf16_t*)a.res + (long)t_res[row] + mc)[j]);
+                            if (accum) u += bf16_to_f32(yp[j]);
+                            yp[j] = f32_to_bf16(u);
+                        }
+                    }
                 }
             }
+        };
+        using std::integral_constant;
+        using std::true_type;
+        using std::false_type;
+        if (out_f32) {
+            // heads (bias, linear) and the fp32 dtype: runtime activation, few launches
+            if (!affine && a.act == 0) staged(true_type{}, integral_constant<int, 0>{}, false_type{});
+            else if (a.act == 0) staged(true_type{}, integral_constant<int, 0>{}, true_type{});
+            else staged(true_type{}, integral_constant<int, -1>{}, true_type{});
+            return;
+        }
+        if (!affine && a.act == 0) { staged(false_type{}, integral_constant<int, 0>{}, false_type{}); return; }
+        switch (a.act) {
+        case DYK_ACT_LINEAR: staged(false_type{}, integral_constant<int, DYK_ACT_LINEAR>{}, true_type{}); break;
+        case DYK_ACT_LEAKY: staged(false_type{}, integral_constant<int, DYK_ACT_LEAKY>{}, true_type{}); break;
+        case DYK_ACT_MISH: staged(false_type{}, integral_constant<int, DYK_ACT_MISH>{}, true_type{}); break;
+        default: staged(false_type{}, integral_constant<int, -1>{}, true_type{}); break;
         }
         return;
     }

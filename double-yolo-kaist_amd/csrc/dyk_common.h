@@ -33,8 +33,18 @@ __device__ __host__ inline float bf16_to_f32(bf16_t v) {
     c.u = ((uint32_t)v) << 16;
     return c.f;
 }
-// round-to-nearest-even, NaN preserved (same rule as torch.bfloat16 casts)
+// round-to-nearest-even, NaN preserved (same rule as torch.bfloat16 casts); on the device this is the
+// gfx950 hardware conversion v_cvt_pk_bf16_f32 (no integer-rounding sequence, no NaN branch)
+typedef __attribute__((ext_vector_type(2))) __bf16 dyk_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float dyk_f32x2_t;
+__device__ inline uint32_t f32x2_to_bf16x2(float lo, float hi) {
+    const dyk_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, dyk_bf16x2_t));
+}
 __device__ __host__ inline bf16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (bf16_t)(f32x2_to_bf16x2(f, 0.f) & 0xffffu);
+#endif
     union { uint32_t u; float f; } c;
     c.f = f;
     uint32_t u = c.u;
@@ -73,8 +83,7 @@ template <typename T> __device__ inline uint4 vec_pack(const float* in);
 template <> __device__ inline uint4 vec_pack<bf16_t>(const float* in) {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        w[i] = (uint32_t)f32_to_bf16(in[2 * i]) | ((uint32_t)f32_to_bf16(in[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = f32x2_to_bf16x2(in[2 * i], in[2 * i + 1]);
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 template <> __device__ inline uint4 vec_pack<float>(const float* in) {
@@ -103,6 +112,12 @@ __device__ inline float act_fwd(int act, float x) {
     default: return x;
     }
 }
+// compile-time activation (hoists the switch out of unrolled epilogues)
+template <int ACT> __device__ inline float act_fwd_c(float x, int runtime_act = 0) {
+    if constexpr (ACT == DYK_ACT_LINEAR) return x;
+    else if constexpr (ACT < 0) return act_fwd(runtime_act, x);      // ACT = -1: runtime switch
+    else return act_fwd(ACT, x);
+}
 __device__ inline float act_bwd(int act, float x) {
     switch (act) {
     case DYK_ACT_LEAKY: return x > 0.f ? 1.f : 0.1f;
@@ -126,6 +141,15 @@ __device__ inline float act_bwd(int act, float x) {
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum over the 16 lanes of a DPP row (lanes 16k..16k+15); every lane of the row receives the total.
+// Four v_add_f32 with row_ror DPP modifiers -- no LDS crossbar traffic (ds_bpermute) as __shfl_xor would emit.
+__device__ inline float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, true));
     return v;
 }
 __device__ inline double wave_sum_d(double v) {

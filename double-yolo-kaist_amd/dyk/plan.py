@@ -238,9 +238,12 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             if training:
                 y_raw = new_act(B, Ho, Wo, cout)
                 z = new_act(B, Ho, Wo, cout)
-                stats = new_ws(STAT_SLOTS * 2 * cout * 8)
+                # replicas of the fp64 statistics accumulators: keep the atomics per address at a few dozen
+                tiles = (B * Ho * Wo + 127) // 128
+                slots = STAT_SLOTS if tiles <= 1024 else min(256, 1 << max(5, (tiles // 32 - 1).bit_length()))
+                stats = new_ws(slots * 2 * cout * 8)
                 vecs = new_ws(4 * cout * 4)          # scale | shift | mean | rstd
-                d.ldy, d.stats_slots = y_raw.ld, STAT_SLOTS
+                d.ldy, d.stats_slots = y_raw.ld, slots
                 if not dw:
                     d.act, d.flags = 0, L.EPI_STATS
                 later(lambda d=d, x_in=x_in, y_raw=y_raw, stats=stats: (
@@ -250,7 +253,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 plan._keep.append(f)
                 f.gamma, f.beta = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
                 f.running_mean, f.running_var = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
-                f.C, f.count, f.momentum, f.eps, f.slots = cout, B * Ho * Wo, BN_MOMENTUM, BN_EPS, STAT_SLOTS
+                f.C, f.count, f.momentum, f.eps, f.slots = cout, B * Ho * Wo, BN_MOMENTUM, BN_EPS, slots
                 later(lambda f=f, stats=stats, vecs=vecs: (
                     setattr(f, "stats", ws.ptr(stats)), setattr(f, "scale", ws.ptr(vecs)),
                     setattr(f, "shift", ws.ptr(vecs + 4 * cout)), setattr(f, "save_mean", ws.ptr(vecs + 8 * cout)),

@@ -100,7 +100,8 @@ if "ablate" in what:
         out = torch.empty(B, H, W, co, device="cuda", dtype=dt)
         stats = torch.zeros(64 * co, dtype=torch.float64, device="cuda")
         for name, tune, st in [("default", 0, None), ("stats", 0, stats), ("nostore", 1 << 16, None), ("noloop", 1 << 17, None),
-                               ("noloop+nostore", 3 << 16, None), ("bkb128", 128 | (2 << 8), None), ("bkb64p3", 64 | (3 << 8), None)]:
+                               ("noloop+nostore", 3 << 16, None), ("bkb128", 128 | (2 << 8), None), ("bkb64p3", 64 | (3 << 8), None),
+                               ("empty", 1 << 18, None), ("tables", 1 << 19, None), ("noepi", 1 << 20, None), ("noloop+noepi", (1 << 20) | (1 << 17), None)]:
             d = ops.make_conv_desc(x, wp, out, Hi=H, Wi=W, Cin=ci, Cout=co, Hg=H, Wg=W, Ho=H, Wo=W, taps=ops.fwd_taps(k, k // 2), stats=st)
             d.tune = tune
             d.stats_slots = 32 if st is not None else 0
