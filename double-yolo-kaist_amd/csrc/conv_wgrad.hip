@@ -64,8 +64,13 @@ template <typename T, int C> __device__ inline int wg_logical_ch(int row, int ps
 }
 
 // PIPE: 0 = register-staged double buffer, 2 / 3 = LDS-DMA ring stages
-template <typename T, int BM, int BN, int PIPE>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, const int splits, const int chunk) {
+// KG:   K-groups per workgroup.  The fp32 atomics of the epilogue run at ~1 element/clk/L2 channel, so their
+//       count (= workgroups x tile area) bounds the kernel; with KG = 2 a 512-thread workgroup holds two 4-wave
+//       groups that walk the two halves of its pixel range with private LDS rings, group 1 hands its
+//       accumulators to group 0 through LDS and only group 0 issues atomics: half the workgroups (and atomics)
+//       at the same number of waves per CU.
+template <typename T, int BM, int BN, int PIPE, int KG>
+__global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc a, const int splits, const int chunk) {
     constexpr int ROWS = WgTraits<T>::ROWS;
     constexpr int EPV = 16 / (int)sizeof(T);
     constexpr int VPR_A = BM / EPV, VPR_B = BN / EPV;          // 16-byte vectors per tile row
@@ -77,10 +82,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
     constexpr int NSTAGE = DMA ? PIPE : 2;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                         // [NSTAGE][A_BYTES]  dy tile
-    char* sB = smem + NSTAGE * A_BYTES;      // [NSTAGE][B_BYTES]  x tile
+    const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+    char* sA = smem + grp * (NSTAGE * (A_BYTES + B_BYTES));     // [NSTAGE][A_BYTES]  dy tile (per K-group)
+    char* sB = sA + NSTAGE * A_BYTES;                           // [NSTAGE][B_BYTES]  x tile
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
 
     const int tiles_m = (a.Cout + BM - 1) / BM;
@@ -93,9 +99,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
     const int m0 = tm * BM, n0 = tn * BN;
     const int HWo = a.Ho * a.Wo;
     const int Ntot = a.B * HWo;
-    const int p_begin = sp * chunk;
-    const int p_end = min(Ntot, p_begin + chunk);
-    if (p_begin >= p_end) return;
+    // the workgroup owns pixels [sp*chunk, +chunk); K-group g the g-th slice of chunk/KG pixels (a multiple of ROWS)
+    const int gchunk = chunk / KG;
+    const int p_begin = sp * chunk + grp * gchunk;
+    const int p_end = min(Ntot, p_begin + gchunk);
+    if (KG == 1 && p_begin >= p_end) return;
     const int tdy = a.tdy[tap], tdx = a.tdx[tap];
     const T* __restrict__ dyg = (const T*)a.dy;
     const T* __restrict__ xg = (const T*)a.x;
@@ -156,7 +164,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
         }
     };
 
-    const int S = (p_end - p_begin + ROWS - 1) / ROWS;
+    // bits 16.. of `tune`: ablation switches for kernel analysis (tools/gpu_probe.py wgablate), never set by the plan
+    const bool abl_noatomic = (a.tune >> 16) & 1, abl_noloop = (a.tune >> 17) & 1;
+    const int S = abl_noloop ? 0 : (KG > 1 ? gchunk / ROWS : (p_end - p_begin + ROWS - 1) / ROWS);   // uniform over the K-groups
     if constexpr (DMA) {
         // ---- 3-stage LDS-DMA ring; each wave instruction fills RPI consecutive pixel rows of a tile
         constexpr int RPI_A = 64 / VPR_A, RPI_B = 64 / VPR_B;
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
             sp0 += ROWS;
         };
         if constexpr (PIPE == 3) {
-            stage_next(0);
+            if (S > 0) stage_next(0);
             if (S > 1) stage_next(1);
             if (S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
                 nxt = (nxt == 2) ? 0 : nxt + 1;
             }
         } else {
-            stage_next(0);
+            if (S > 0) stage_next(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             for (int s = 0; s < S; ++s) {
@@ -289,8 +299,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
                 if (NV_B % 256 == 0 || i * 256 + tid < NV_B)
                     *(uint4*)(sB + buf * B_BYTES + wg_off<T, BN>(b_row[i], b_ch[i])) = rb[i];
         };
-        gload(p_begin);
-        lstore(0);
+        if (S > 0) { gload(p_begin); lstore(0); }
         __syncthreads();
         for (int s = 0; s < S; ++s) {
             const bool more = (s + 1 < S);
@@ -301,9 +310,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const DykWgradDesc a, c
         }
     }
 
+    if constexpr (KG > 1) {
+        // fold the K-groups: group g > 0 parks its accumulators in LDS (lane-linear float4, conflict free), group 0 adds
+        float4* park = (float4*)smem;            // overlays the rings (all waves are behind the loop's last barrier)
+        for (int g = 1; g < KG; ++g) {
+            if (grp == g) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        park[((mi * NI + ni) * 4 + wid) * 64 + lane] = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const float4 v = park[((mi * NI + ni) * 4 + wid) * 64 + lane];
+                        acc[mi][ni][0] += v.x; acc[mi][ni][1] += v.y; acc[mi][ni][2] += v.z; acc[mi][ni][3] += v.w;
+                    }
+            }
+            if (g + 1 < KG) __syncthreads();
+        }
+        if (grp != 0) return;
+    }
     // ---- epilogue: acc[r] = D[co = (lane>>4)*4 + r][ci = lane&15]
     const int lddw = a.lddw > 0 ? a.lddw : a.Cin;
     float* dw = a.dw + (long)a.twt[tap] * a.Cout * lddw;
+    if (abl_noatomic) {
+        float sum = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) sum += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+        if (sum == 123.456f) dw[0] = sum;
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -328,12 +371,15 @@ inline bool wg_use_dma() {
     return v == 1;
 }
 
-template <typename T, int BM, int BN, int PIPE>
+template <typename T, int BM, int BN, int PIPE, int KG>
 int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream) {
     constexpr int ROWS = WgTraits<T>::ROWS;
-    constexpr size_t lds = (PIPE ? PIPE : 2) * (size_t)ROWS * (BM + BN) * sizeof(T);
+    constexpr size_t ring = KG * (PIPE ? PIPE : 2) * (size_t)ROWS * (BM + BN) * sizeof(T);
+    constexpr size_t park = KG > 1 ? (size_t)BM * BN * 4 : 0;
+    constexpr size_t lds = ring > park ? ring : park;
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto kfn = conv_wgrad_kernel<T, BM, BN, PIPE>;
+    auto kfn = conv_wgrad_kernel<T, BM, BN, PIPE, KG>;
     if (!attr_set) {
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -343,22 +389,28 @@ int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream) {
     const int ksteps = dyk_div_up(Ntot, ROWS);
     int splits = d->splits;
     if (splits <= 0) {
-        splits = dyk_div_up(768, tiles);             // ~3 workgroups per CU
-        const int max_splits = ksteps / 8 > 0 ? ksteps / 8 : 1;   // at least 8 K steps per workgroup (amortise the atomics)
+        // 4-wave workgroups: ~3 per CU; K-grouped (8-wave) workgroups occupy a CU alone (LDS) unless the tile is small
+        const int target = KG > 1 ? (lds > 80 * 1024 ? 256 : 512) : 768;
+        splits = dyk_div_up(target, tiles);
+        const int max_splits = ksteps / (8 * KG) > 0 ? ksteps / (8 * KG) : 1;   // at least 8 K steps per K-group (amortise the atomics)
         if (splits > max_splits) splits = max_splits;
     }
-    if (splits > ksteps) splits = ksteps;
-    const int chunk = dyk_div_up(ksteps, splits) * ROWS;
+    if (splits * KG > ksteps) splits = ksteps / KG > 0 ? ksteps / KG : 1;
+    const int chunk = dyk_div_up(ksteps, splits * KG) * ROWS * KG;      // pixels per workgroup: KG slices of whole K steps
     splits = dyk_div_up(Ntot, chunk);
-    hipLaunchKernelGGL(kfn, dim3(tiles * splits), dim3(256), lds, stream, *d, splits, chunk);
+    hipLaunchKernelGGL(kfn, dim3(tiles * splits), dim3(256 * KG), lds, stream, *d, splits, chunk);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
 
 template <typename T, int BM, int BN>
 int launch_wgrad(const DykWgradDesc* d, hipStream_t stream) {
-    if (!wg_use_dma()) return launch_wgrad_impl<T, BM, BN, 0>(d, stream);
-    return d->tune == 3 ? launch_wgrad_impl<T, BM, BN, 3>(d, stream) : launch_wgrad_impl<T, BM, BN, 2>(d, stream);
+    if (!wg_use_dma()) return launch_wgrad_impl<T, BM, BN, 0, 1>(d, stream);
+    // tune: low byte = LDS ring stages (2 | 3), bits 8..15 = K-groups per workgroup (1 | 2)
+    const int kg = (d->tune >> 8) & 0xff;
+    if ((d->tune & 0xff) == 3) return launch_wgrad_impl<T, BM, BN, 3, 1>(d, stream);
+    if (kg == 2) return launch_wgrad_impl<T, BM, BN, 2, 2>(d, stream);
+    return launch_wgrad_impl<T, BM, BN, 2, 1>(d, stream);
 }
 
 template <typename T, int BM>

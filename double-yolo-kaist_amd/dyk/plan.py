@@ -739,7 +739,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
 _TUNE_CACHE = {}     # process-wide: the same problem always runs the same tile configuration (bit-reproducible
                      # results across plans / model instances within a process)
 _CONV_CANDIDATES = [64 | (2 << 8), 64 | (3 << 8), 128 | (2 << 8), 128 | (3 << 8)]
-_WGRAD_CANDIDATES = [2, 3]
+_WGRAD_CANDIDATES = [2, 3, 2 | (2 << 8)]      # LDS ring stages | K-groups per workgroup << 8
 
 
 def _time_launch(fn, desc, stream, reps=3):

@@ -120,6 +120,47 @@ if "ablate" in what:
             print(rows[-1], flush=True)
     res["ablate"] = rows
 
+if "wgablate" in what:
+    import ctypes as C
+    from dyk import lib as L
+    rows = []
+    for (ci, co, H, W, k) in [(128, 128, 64, 80, 3), (256, 256, 32, 40, 3), (128, 128, 64, 80, 1), (512, 512, 16, 20, 3), (64, 64, 256, 320, 1)]:
+        B, dt = 16, torch.bfloat16
+        x = torch.randn(B, H, W, ci, device="cuda").to(dt)
+        dy = torch.randn(B, H, W, co, device="cuda").to(dt)
+        dw = torch.zeros(k * k, co, ci, device="cuda")
+        for name, tune, splits in [("default", 0, 0), ("pipe3", 3, 0), ("kg2", 2 | (2 << 8), 0), ("kg2s.5", 2 | (2 << 8), -2), ("kg2s2", 2 | (2 << 8), -3), ("noatomic", 1 << 16, 0), ("noloop", 1 << 17, 0),
+                                   ("noloop+noatomic", 3 << 16, 0), ("splits16", 0, 16), ("splits32", 0, 32)]:
+            d = L.DykWgradDesc()
+            d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+            d.dtype = L.DYK_BF16
+            d.ldx, d.lddy = ci, co
+            d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, ci, H, W, co
+            d.isy = d.isx = 1
+            taps = ops.fwd_taps(k, k // 2)
+            d.ntaps = len(taps)
+            for i, (ty, tx, wt) in enumerate(taps):
+                d.tdy[i], d.tdx[i], d.twt[i] = ty, tx, wt
+            if splits < 0:       # relative to the K-grouped default: -2 = half, -3 = double
+                tiles = ((co + 127) // 128) * ((ci + 127) // 128) * k * k
+                base = max(1, -(-256 // tiles))
+                splits = max(1, base // 2) if splits == -2 else base * 2
+            d.splits, d.lddw, d.tune = splits, 0, tune
+            fn = L.load().dyk_conv_wgrad
+            for _ in range(3):
+                fn(C.byref(d), None)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn(C.byref(d), None)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            fl = 2.0 * B * H * W * ci * co * k * k
+            rows.append((ci, co, H, k, name, round(ms * 1e3, 1), round(fl / ms / 1e9)))
+            print(rows[-1], flush=True)
+    res["wgablate"] = rows
+
 with open(os.path.join(OUT, "probe.json"), "w") as f:
     json.dump(res, f, indent=1)
 print("wrote probe.json")
