@@ -1,0 +1,608 @@
+// Implicit-GEMM convolution (forward and data gradient) on the CDNA4 matrix cores.
+//
+// GEMM view: M = output channels (A operand = packed weights [tap][Cout][Cin]),
+//            N = launch-grid positions (B operand = channels-last activations),
+//            K = taps x Cin, walked as (Cin chunk outer, tap inner) so that the nine
+//            shifted re-reads of one activation chunk hit L1/L2 instead of HBM.
+// Block = 256 threads = 4 waves, tile BM x BN (BN = 80 | 128 | 160 pixels), K step = BKB bytes of channels
+// (64 or 128 B per row).  Global -> LDS by LDS-DMA (XOR-swizzled 16-byte slots, zero fill for
+// padding taps / ragged tiles from a zero page), 2- or 3-stage ring, one barrier per K step.
+// MFMA: v_mfma_f32_16x16x32_bf16 (bf16) or 4 x v_mfma_f32_16x16x4_f32 (f32) per 16-byte
+// fragment pair; both operands are read from LDS with the same (row = lane&15,
+// slot = lane>>4) pattern so the K permutation inside a fragment cancels.
+// D layout: acc[r] = D[m = (lane>>4)*4 + r][n = lane&15]  -> four consecutive output
+// channels of one pixel per lane = one 8/16-byte channels-last store.
+//
+// Replaces: nn.Conv2d forward at reference models.py:34-42 (+ the BatchNorm2d/activation
+// that follow it at :46-62 when run with the AFFINE epilogue), and autograd's
+// convolution_backward (input gradient) for the same layers.
+#pragma once
+#pragma once
+#include <stdlib.h>
+#include <type_traits>
+#include "dyk_common.h"
+
+namespace {
+
+struct ConvArgs {
+    DykConvDesc d;
+};
+
+// set by the launcher when y / ldy allow 8/16-byte vector stores
+constexpr int EPI_INTERNAL_VEC = 1 << 30;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ inline void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                      __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static __device__ inline void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+// byte offset of 16-byte slot `slot` of row `row` in a [rows][BKB] tile.
+// BKB=128: 2 rows per 256-B bank row, slot ^= (row>>1)&7 ; BKB=64: 4 rows per bank row,
+// slot ^= 3*((row>>3)&1).  Both make every ds_read_b128 lane group (MI355X_MICROARCH §LDS)
+// hit 16 distinct slots for the (row = lane&15, slot = lane>>4) fragment pattern.
+template <int BKB> __device__ inline int lds_off(int row, int slot) {
+    if (BKB == 128) return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+    return row * 64 + ((slot ^ (((row >> 3) & 1) * 3)) << 4);
+}
+
+// all-zero source for padding taps / ragged rows of the LDS-DMA path
+__device__ uint4 dyk_zero_page[8];
+
+#define DYK_AS3 __attribute__((address_space(3)))
+
+// One LDS-DMA wave instruction: 64 lanes x 16 B from per-lane global addresses to the wave-uniform
+// LDS byte address `lds_addr` + lane*16.  Issued through inline asm on purpose: hipcc drains
+// vmcnt(0) in front of every ds_read while a *builtin* LDS-DMA is in flight (it cannot prove the
+// ring slots disjoint), which serialises the pipeline; hidden in asm, the DMA is ordered solely by
+// the counted s_waitcnt vmcnt(N) + s_barrier below (cdna_hip_programming.md §5.7).
+__device__ inline void glds16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+__device__ inline unsigned lds_addr_of(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(DYK_AS3 const char*)p);
+}
+
+// how the four waves of a workgroup tile BM (channels) x BN (pixels): BN = 128 -> 2x2 / 1x4, BN = 160 -> 2x2,
+// BN = 80 -> 4x1 (80 and 160 pixels = 5 and 10 MFMA columns: the feature maps of this path have 5*2^k pixels, so
+// these tile widths give whole waves of workgroups where 128 leaves 1.25 or 0.6)
+template <int BM, int BN> struct WaveGrid {
+    static constexpr int WM = (BN == 80) ? 4 : ((BN == 160) ? 2 : ((BM >= 128) ? 2 : 1));
+    static constexpr int WN = 4 / WM;
+    static_assert(BM / WM >= 16 && (BN / WN) % 16 == 0, "unsupported tile");
+};
+template <int BN> constexpr int table_bytes() { return BN * (3 * 4 + 2 * 2) + 1024 + 4 * 32 * 4 + 2 * 128 * 4; }
+
+// PIPE: LDS-DMA ring stages (2 | 3)
+template <typename T, int BM, int BN, int BKB, int PIPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_kernel(const ConvArgs args) {
+    const DykConvDesc& a = args.d;
+    constexpr int TABLE_BYTES = table_bytes<BN>();
+    constexpr int EPV = 16 / (int)sizeof(T);
+    constexpr int BK = BKB / (int)sizeof(T);
+    constexpr int WM = WaveGrid<BM, BN>::WM;  // waves along M
+    constexpr int WN = WaveGrid<BM, BN>::WN;
+    constexpr int WTM = BM / WM;
+    constexpr int WTN = BN / WN;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    constexpr int KK = BKB / 64;
+    constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
+    constexpr int NSTAGE = PIPE;
+
+    // LDS: [pixel / tap tables | dummy-DMA sink | stats scratch] then the operand ring, which the
+    // epilogue re-uses as the output staging tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* t_in = (int*)smem;                   // [BN] input base offset
+    int* t_out = t_in + BN;                   // [BN] output offset or -1
+    int* t_res = t_out + BN;                  // [BN] residual offset
+    short* t_y = (short*)(t_res + BN);        // [BN] input row of tap (0,0)
+    short* t_x = t_y + BN;                    // [BN]
+    char* sink = (char*)(t_x + BN);           // [1024] target of dummy LDS-DMA writes (DMA path only)
+    int* tap_x = (int*)(sink + 1024);         // [32] activation element offset of a tap: (dy*Wi + dx)*ldx
+    int* tap_w = tap_x + 32;                  // [32] weight element offset of a tap: twt*Cout*Cin
+    int* tap_dy = tap_w + 32;                 // [32]
+    int* tap_dx = tap_dy + 32;                // [32]
+    float* s_stat = (float*)(tap_dx + 32);    // [2][BM] per-workgroup channel sums (STATS epilogue)
+    char* sA = smem + TABLE_BYTES;                 // [NSTAGE][A_BYTES]
+    char* sB = sA + NSTAGE * A_BYTES;              // [NSTAGE][B_BYTES]
+    char* sC = sA;                                 // epilogue staging tile (overlays the ring)
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    if ((a.tune >> 18) & 1) return;            // ablation: empty kernel
+
+    // Consecutive remapped ids share an XCD (and its 4 MB L2).  Pixel tiles vary fastest so that an XCD sees few
+    // channel tiles: one 128-row slab of 3x3 weights is 9 x heavier than one 128-pixel slab of activations, and
+    // the full weight tensor of the deep layers (4.7-18 MB) does not fit one L2.
+    const int HWg = a.Hg * a.Wg;
+    const int Ntot = a.B * HWg;
+    const int tiles_n = (Ntot + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (bid / tiles_n) * BM;
+    const int n0 = (bid % tiles_n) * BN;
+
+    if (tid < BN) {
+        const int n = n0 + tid;
+        if (n < Ntot) {
+            const int b = n / HWg;
+            const int r = n - b * HWg;
+            const int yo = r / a.Wg;
+            const int xo = r - yo * a.Wg;
+            const int yi = yo * a.isy, xi = xo * a.isx;
+            t_in[tid] = ((b * a.Hi + yi) * a.Wi + xi) * a.ldx;
+            t_y[tid] = (short)yi;
+            t_x[tid] = (short)xi;
+            const int py = yo * a.osy + a.ooy, px = xo * a.osx + a.oox;
+            t_out[tid] = ((b * a.Ho + py) * a.Wo + px) * a.ldy;
+            t_res[tid] = ((b * a.Ho + py) * a.Wo + px) * a.ldr;
+        } else {
+            t_in[tid] = 0; t_y[tid] = -20000; t_x[tid] = -20000; t_out[tid] = -1; t_res[tid] = 0;
+        }
+    }
+    if (tid >= 256 - 32 && tid < 256 - 32 + a.ntaps) {   // tap tables in LDS: no vector-memory loads inside the K loop
+        const int q = tid - (256 - 32);
+        const int dy = a.tdy[q], dx = a.tdx[q];
+        tap_dy[q] = dy; tap_dx[q] = dx;
+        tap_x[q] = (dy * a.Wi + dx) * a.ldx;
+        tap_w[q] = a.twt[q] * a.Cout * a.Cin;
+    }
+    __syncthreads();
+    if ((a.tune >> 19) & 1) return;            // ablation: tables only
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const T* __restrict__ xg = (const T*)a.x;
+    const T* __restrict__ wg = (const T*)a.w;
+    // bits 16.. of `tune` are ablation switches for kernel analysis (tools/gpu_probe.py ablate): never set by the plan
+    const bool abl_nostore = (a.tune >> 16) & 1, abl_noloop = (a.tune >> 17) & 1;
+    const int S = abl_noloop ? 0 : (a.Cin / BK) * a.ntaps;
+    const int frow = lane & 15, fslot = lane >> 4;
+
+    auto compute = [&](const char* pa, const char* pb) {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            uint4 fa[MI], fb[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                fa[mi] = *(const uint4*)(pa + lds_off<BKB>(wm * WTM + mi * 16 + frow, kk * 4 + fslot));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                fb[ni] = *(const uint4*)(pb + lds_off<BKB>(wn * WTN + ni * 16 + frow, kk * 4 + fslot));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], fa[mi], fb[ni]);
+        }
+    };
+
+    {
+        // ---- LDS-DMA pipeline: global_load_lds (16 B per lane, 1 KiB per wave instruction) straight
+        // into a 3-deep ring of swizzled tiles; step s+2 is in flight while step s feeds the MFMAs.
+        // A wave instruction fills RPI consecutive tile rows; lane -> (row, physical slot); the XOR
+        // swizzle is applied on the SOURCE side (the LDS image of an LDS-DMA is lane-linear).
+        constexpr int SPR = BKB / 16;                  // 16-byte slots per tile row
+        constexpr int RPI = 64 / SPR;                  // tile rows per wave instruction
+        constexpr int NI_A = BM * BKB / 1024, NI_B = BN * BKB / 1024;
+        constexpr int NIA_W = (NI_A + 3) / 4, NIB_W = (NI_B + 3) / 4;
+        constexpr int NPW = NIA_W + NIB_W;             // DMA instructions per wave per step (uniform count)
+        const int wv = __builtin_amdgcn_readfirstlane(wid);
+        const int lrow = lane / SPR, pslot = lane % SPR;
+        int a_off[NIA_W]; bool a_ok[NIA_W];
+#pragma unroll
+        for (int j = 0; j < NIA_W; ++j) {
+            const int inst = j * 4 + wv;
+            const int row = inst * RPI + lrow;
+            const int co = m0 + row;
+            const int ls = (lds_off<BKB>(row, pslot) - row * BKB) >> 4;    // logical slot stored at this physical slot
+            a_ok[j] = (inst < NI_A) && (co < a.Cout);
+            a_off[j] = co * a.Cin + ls * EPV;
+        }
+        int b_off[NIB_W]; unsigned b_mask[NIB_W];
+#pragma unroll
+        for (int j = 0; j < NIB_W; ++j) {
+            const int inst = j * 4 + wv;
+            const int row = inst * RPI + lrow;
+            const int ls = (lds_off<BKB>(row, pslot) - row * BKB) >> 4;
+            const bool live = (NI_B % 4 == 0) || inst < NI_B;
+            b_off[j] = live ? t_in[row] + ls * EPV : 0;
+            const int y0 = live ? t_y[row] : -20000, x0 = live ? t_x[row] : -20000;
+            unsigned m = 0;
+            for (int q = 0; q < a.ntaps; ++q) {
+                const int yi = y0 + tap_dy[q], xi = x0 + tap_dx[q];
+                if (((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi)) m |= 1u << q;
+            }
+            b_mask[j] = m;
+        }
+        const T* zero = (const T*)dyk_zero_page;
+        auto stage = [&](int buf, int c0, int t) {
+            const int toff = tap_x[t] + c0;
+            const long wbase = (long)tap_w[t] + c0;
+            char* da = sA + buf * A_BYTES;
+            char* db = sB + buf * B_BYTES;
+#pragma unroll
+            for (int j = 0; j < NIA_W; ++j) {
+                const int inst = j * 4 + wv;
+                if (NI_A % 4 == 0 || inst < NI_A) {
+                    const T* src = a_ok[j] ? wg + wbase + a_off[j] : zero;
+                    glds16(src, lds_addr_of(da + inst * 1024));
+                } else {
+                    // keep the per-wave DMA count uniform so that one counted vmcnt fits all waves
+                    glds16(zero, lds_addr_of(sink));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NIB_W; ++j) {
+                const int inst = j * 4 + wv;
+                const T* src = ((b_mask[j] >> t) & 1u) ? xg + (long)b_off[j] + toff : zero;
+                glds16(src, lds_addr_of((NI_B % 4 == 0 || inst < NI_B) ? db + inst * 1024 : sink));
+            }
+        };
+        // staging iterator (runs two steps ahead of the compute iterator)
+        int sc0 = 0, st = 0;
+        auto stage_next = [&](int buf) {
+            stage(buf, sc0, st);
+            if (++st == a.ntaps) { st = 0; sc0 += BK; }
+        };
+        if constexpr (PIPE >= 3) {
+            // N-stage ring: AHEAD = N-1 steps are in flight while one is computed.  Workgroups that sit alone on a
+            // CU (deep layers: few, long-K tiles) need the depth: with two stages a K step costs one L2 round trip.
+            constexpr int AHEAD = PIPE - 1;
+            constexpr int KEEP = (AHEAD - 1) * NPW;        // DMA instructions that may still be in flight per wave
+            static_assert(KEEP <= 63, "vmcnt range");
+#pragma unroll
+            for (int i = 0; i < AHEAD; ++i)
+                if (S > i) stage_next(i);
+            if (S >= AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int cur = 0, nxt = AHEAD;
+            for (int s = 0; s < S; ++s) {
+                const bool more = (s + AHEAD < S);
+                if (more) stage_next(nxt);
+                compute(sA + cur * A_BYTES, sB + cur * B_BYTES);
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                cur = (cur == PIPE - 1) ? 0 : cur + 1;
+                nxt = (nxt == PIPE - 1) ? 0 : nxt + 1;
+            }
+        } else {
+            // 2-stage ring for short K loops (1x1 convs, small Cin): half the LDS, 2-3x the resident
+            // workgroups per CU -- latency is hidden across workgroups instead of inside one
+            if (S > 0) stage_next(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int s = 0; s < S; ++s) {
+                if (s + 1 < S) stage_next((s + 1) & 1);
+                compute(sA + (s & 1) * A_BYTES, sB + (s & 1) * B_BYTES);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // (both pipelines leave the loop behind a workgroup barrier: the ring is free to be overwritten)
+    if ((a.tune >> 20) & 1) {                  // ablation: no epilogue (keep the accumulators alive)
+        float sum = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) sum += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+        if (sum == 123.456f) ((float*)a.y)[0] = sum;
+        return;
+    }
+    const int flags = a.flags;
+    const int mlane = (lane >> 4) * 4;
+    if (flags & DYK_EPI_STATS) {
+        // per-channel sum / sum of squares of the raw accumulators: in-lane over ni, DPP row rotate-adds over the
+        // 16 pixel lanes, LDS atomics across the waves of the workgroup, then ONE fp64 atomic per channel
+        // and workgroup into a replica of the statistics buffer.
+        for (int i = tid; i < 2 * BM; i += 256) s_stat[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const float v = acc[mi][ni][r];
+                    s1 += v; s2 += v * v;
+                }
+                s1 = row16_sum(s1);
+                s2 = row16_sum(s2);
+                if ((lane & 15) == 0) {
+                    const int ml = wm * WTM + mi * 16 + mlane + r;
+                    atomicAdd(s_stat + ml, s1);
+                    atomicAdd(s_stat + BM + ml, s2);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BM) {
+            const int ml = tid % BM, which = tid / BM;
+            if (m0 + ml < a.Cout) {
+                double* st = a.stats + (size_t)(blockIdx.x % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
+                atomicAdd(st + which * a.Cout + m0 + ml, (double)s_stat[tid]);
+            }
+        }
+    }
+    const bool affine = flags & DYK_EPI_AFFINE;
+    const bool has_res = flags & DYK_EPI_RESIDUAL;
+    const bool accum = flags & DYK_EPI_ACCUM;
+    const bool out_f32 = (flags & DYK_EPI_OUT_F32) || sizeof(T) == 4;
+
+    if (flags & EPI_INTERNAL_VEC) {
+        // ---- staged, coalesced store: accumulators -> LDS tile [pixel][channel] -> 16-byte global stores
+        // in which 16 consecutive lanes cover one contiguous channel row of a pixel (the per-lane 8-byte
+        // scatter of the MFMA layout wrote 32-byte fragments and cost 2-3x the store time).
+        // The code is instantiated per (output type, activation) and selected by ONE switch: with the
+        // activation switch inside the 64-value unrolled loop the epilogue was 20k instructions of
+        // branches and cost 9 us per launch (tools/gpu_probe.py ablate).
+        auto staged = [&](auto of32_tag, auto act_tag, auto affine_tag) {
+            constexpr bool OF32 = decltype(of32_tag)::value;
+            constexpr int ACT = decltype(act_tag)::value;
+            constexpr bool AFF = decltype(affine_tag)::value;
+            constexpr int eso = OF32 ? 4 : 2;                     // output element size
+            constexpr int rstride = BM * eso + 16;                // padded row stride (bytes)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int ml = wm * WTM + mi * 16 + mlane;
+                const int m = m0 + ml;
+                float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (AFF) {
+                    if (m + 3 < a.Cout) {
+                        if (a.scale) { const float4 t = *(const float4*)(a.scale + m); sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; }
+                        if (a.shift) { const float4 t = *(const float4*)(a.shift + m); sh[0] = t.x; sh[1] = t.y; sh[2] = t.z; sh[3] = t.w; }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (m + r < a.Cout) {
+                                if (a.scale) sc[r] = a.scale[m + r];
+                                if (a.shift) sh[r] = a.shift[m + r];
+                            }
+                    }
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int nl = wn * WTN + ni * 16 + (lane & 15);
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float u = acc[mi][ni][r];
+                        if constexpr (AFF) u = u * sc[r] + sh[r];
+                        v[r] = act_fwd_c<ACT>(u, a.act);
+                    }
+                    char* dst = sC + nl * rstride + ml * eso;
+                    if constexpr (OF32) {
+                        *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        uint2 pk;
+                        pk.x = f32x2_to_bf16x2(v[0], v[1]);
+                        pk.y = f32x2_to_bf16x2(v[2], v[3]);
+                        *(uint2*)dst = pk;
+                    }
+                }
+            }
+            __syncthreads();
+            constexpr int epv_o = 16 / eso;                       // output elements per 16-byte chunk
+            constexpr int cpr = BM / epv_o;                       // chunks per tile row
+            constexpr int nchunk = BN * cpr;
+            for (int q = tid; q < nchunk; q += 256) {
+                const int row = q / cpr, cc = q % cpr;
+                const int po = t_out[row];
+                const int mc = m0 + cc * epv_o;
+                if (po < 0 || mc >= a.Cout) continue;
+                if (abl_nostore && t_out[0] != -12345) continue;
+                uint4 val = *(const uint4*)(sC + row * rstride + cc * 16);
+                const bool whole = (mc + epv_o <= a.Cout);
+                if constexpr (OF32) {
+                    float* yp = (float*)a.y + (long)po + mc;
+                    float f[4] = {__uint_as_float(val.x), __uint_as_float(val.y), __uint_as_float(val.z), __uint_as_float(val.w)};
+                    if (has_res) {
+                        const T* rp = (const T*)a.res + (long)t_res[row] + mc;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (mc + j < a.Cout) f[j] += ElemTraits<T>::to_f32(rp[j]);
+                    }
+                    if (accum) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (mc + j < a.Cout) f[j] += yp[j];
+                    }
+                    if (whole) *(float4*)yp = make_float4(f[0], f[1], f[2], f[3]);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (mc + j < a.Cout) yp[j] = f[j];
+                    }
+                } else {
+                    bf16_t* yp = (bf16_t*)a.y + (long)po + mc;
+                    if (whole && !has_res && !accum) {
+                        *(uint4*)yp = val;
+                    } else if (whole) {
+                        float f[8];
+                        vec_unpack<bf16_t>(val, f);
+                        if (has_res) {
+                            float g[8];
+                            vec_unpack<bf16_t>(*(const uint4*)((const bf16_t*)a.res + (long)t_res[row] + mc), g);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) f[j] += g[j];
+                        }
+                        if (accum) {
+                            float g[8];
+                            vec_unpack<bf16_t>(*(const uint4*)yp, g);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) f[j] += g[j];
+                        }
+                        *(uint4*)yp = vec_pack<bf16_t>(f);
+                    } else {
+                        float f[8];
+                        vec_unpack<bf16_t>(val, f);
+                        for (int j = 0; j < 8; ++j) {
+                            if (mc + j >= a.Cout) break;
+                            float u = f[j];
+                            if (has_res) u += bf16_to_f32(((const bf16_t*)a.res + (long)t_res[row] + mc)[j]);
+                            if (accum) u += bf16_to_f32(yp[j]);
+                            yp[j] = f32_to_bf16(u);
+                        }
+                    }
+                }
+            }
+        };
+        using std::integral_constant;
+        using std::true_type;
+        using std::false_type;
+        if (out_f32) {
+            // heads (bias, linear) and the fp32 dtype: runtime activation, few launches
+            if (!affine && a.act == 0) staged(true_type{}, integral_constant<int, 0>{}, false_type{});
+            else if (a.act == 0) staged(true_type{}, integral_constant<int, 0>{}, true_type{});
+            else staged(true_type{}, integral_constant<int, -1>{}, true_type{});
+            return;
+        }
+        if (!affine && a.act == 0) { staged(false_type{}, integral_constant<int, 0>{}, false_type{}); return; }
+        switch (a.act) {
+        case DYK_ACT_LINEAR: staged(false_type{}, integral_constant<int, DYK_ACT_LINEAR>{}, true_type{}); break;
+        case DYK_ACT_LEAKY: staged(false_type{}, integral_constant<int, DYK_ACT_LEAKY>{}, true_type{}); break;
+        case DYK_ACT_MISH: staged(false_type{}, integral_constant<int, DYK_ACT_MISH>{}, true_type{}); break;
+        default: staged(false_type{}, integral_constant<int, -1>{}, true_type{}); break;
+        }
+        return;
+    }
+    // ---- fallback: per-lane stores straight from the MFMA layout (unaligned / odd-stride outputs)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * WTM + mi * 16 + mlane;
+        if (m >= a.Cout) continue;
+        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (affine) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (m + r < a.Cout) {
+                    if (a.scale) sc[r] = a.scale[m + r];
+                    if (a.shift) sh[r] = a.shift[m + r];
+                }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int nl = wn * WTN + ni * 16 + (lane & 15);
+            const int po = t_out[nl];
+            if (po < 0) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = acc[mi][ni][r];
+                if (affine) u = u * sc[r] + sh[r];
+                v[r] = act_fwd(a.act, u);
+            }
+            if (has_res) {
+                const T* rp = (const T*)a.res + (long)t_res[nl] + m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < a.Cout) v[r] += ElemTraits<T>::to_f32(rp[r]);
+            }
+            if (out_f32) {
+                float* yp = (float*)a.y + (long)po + m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < a.Cout) yp[r] = accum ? yp[r] + v[r] : v[r];
+            } else {
+                bf16_t* yp = (bf16_t*)a.y + (long)po + m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < a.Cout) yp[r] = f32_to_bf16(accum ? bf16_to_f32(yp[r]) + v[r] : v[r]);
+            }
+        }
+    }
+}
+
+
+template <typename T, int BM, int BN, int BKB, int PIPE>
+int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
+    constexpr int TABLE_BYTES = table_bytes<BN>();
+    constexpr size_t ring = PIPE * (size_t)(BM + BN) * BKB;
+    const bool of32 = (d->flags & DYK_EPI_OUT_F32) || sizeof(T) == 4;
+    const size_t stage_c = (size_t)BN * (BM * (of32 ? 4 : 2) + 16);
+    const size_t lds = TABLE_BYTES + (ring > stage_c ? ring : stage_c);
+    static bool attr_set = false;
+    auto kfn = conv_igemm_kernel<T, BM, BN, BKB, PIPE>;
+    if (!attr_set) {
+        constexpr size_t lds_max = TABLE_BYTES + (ring > (size_t)BN * (BM * 4 + 16) ? ring : (size_t)BN * (BM * 4 + 16));
+        DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        attr_set = true;
+    }
+    const long Ntot = (long)d->B * d->Hg * d->Wg;
+    const int tiles_n = dyk_div_up(Ntot, BN);
+    const int tiles_m = dyk_div_up(d->Cout, BM);
+    ConvArgs args;
+    args.d = *d;
+    // the staged epilogue needs 16-byte aligned pixel rows of the output (and residual)
+    const int eso = of32 ? 4 : 2;
+    bool vec = ((size_t)d->ldy * eso) % 16 == 0 && ((uintptr_t)d->y % 16) == 0;
+    if ((d->flags & DYK_EPI_RESIDUAL) && (((size_t)d->ldr * sizeof(T)) % 16 != 0 || ((uintptr_t)d->res % 16) != 0)) vec = false;
+    static int force_scatter = -1;
+    if (force_scatter < 0) { const char* e = getenv("DYK_CONV_EPI"); force_scatter = (e && e[0] == 's') ? 1 : 0; }
+    if (force_scatter) vec = false;
+    if (vec) args.d.flags |= EPI_INTERNAL_VEC;
+    else args.d.flags &= ~EPI_INTERNAL_VEC;
+    hipLaunchKernelGGL(kfn, dim3(tiles_n * tiles_m), dim3(256), lds, stream, args);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+template <typename T, int BM, int BN, int BKB>
+int launch_conv(const DykConvDesc* d, hipStream_t stream) {
+    // 2-stage ring by default: 2-4 resident workgroups per CU beat a deeper ring unless the autotuner says otherwise
+    switch ((d->tune >> 8) & 0xf) {
+    case 3: return launch_conv_impl<T, BM, BN, BKB, 3>(d, stream);
+    case 4: return launch_conv_impl<T, BM, BN, BKB, 4>(d, stream);
+    case 6: if constexpr ((size_t)6 * (BM + BN) * BKB + table_bytes<BN>() <= 160 * 1024) return launch_conv_impl<T, BM, BN, BKB, 6>(d, stream);
+            else return launch_conv_impl<T, BM, BN, BKB, 4>(d, stream);
+    default: return launch_conv_impl<T, BM, BN, BKB, 2>(d, stream);
+    }
+}
+
+// tune word: bits 0..7 K-step bytes (64 | 128), 8..11 ring stages (2 | 3 | 4 | 6), 12..15 pixel tile (0 = 128, 1 = 80, 2 = 160),
+// 24..27 channel tile (0 = by Cout, 1 = 32, 2 = 64, 3 = 128); bits 16..23 are analysis switches
+template <typename T, int BN>
+int dispatch_conv_bn(const DykConvDesc* d, hipStream_t stream) {
+    const int row_bytes = d->Cin * (int)sizeof(T);
+    if ((row_bytes % 64) != 0) return DYK_ERR_ARG;
+    // default K step: 128 bytes for long loops over wide inputs, else 64 (more resident workgroups); see DESIGN.md
+    bool k128 = (row_bytes % 128) == 0 && (row_bytes / 128) * d->ntaps > 4 && d->Cin >= 512;
+    if ((d->tune & 0xff) == 64) k128 = false;
+    if ((d->tune & 0xff) == 128 && (row_bytes % 128) == 0) k128 = true;
+    int bm = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
+    const int bm_code = (d->tune >> 24) & 0xf;
+    if (bm_code >= 1 && bm_code <= 3) bm = 16 << bm_code;
+    if constexpr (BN == 80) { if (bm == 32) bm = 64; }          // a wave needs 16 channel rows
+    if (k128) {
+        if (bm == 128) return launch_conv<T, 128, BN, 128>(d, stream);
+        if (bm == 64) return launch_conv<T, 64, BN, 128>(d, stream);
+        if constexpr (BN != 80) return launch_conv<T, 32, BN, 128>(d, stream);
+    }
+    if (bm == 128) return launch_conv<T, 128, BN, 64>(d, stream);
+    if (bm == 64) return launch_conv<T, 64, BN, 64>(d, stream);
+    if constexpr (BN != 80) return launch_conv<T, 32, BN, 64>(d, stream);
+    return DYK_ERR_UNSUPPORTED;
+}
+
+}  // namespace

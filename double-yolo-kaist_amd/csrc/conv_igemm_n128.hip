@@ -1,0 +1,9 @@
+// Instantiations of the implicit-GEMM convolution for the 128-pixel tile (one translation unit per tile width so
+// that make -j builds them in parallel).
+#include "conv_igemm_kernel.h"
+
+int dyk_conv_launch_n128(const DykConvDesc* d, hipStream_t s) {
+    if (d->dtype == DYK_BF16) return dispatch_conv_bn<bf16_t, 128>(d, s);
+    if (d->dtype == DYK_F32) return dispatch_conv_bn<float, 128>(d, s);
+    return DYK_ERR_UNSUPPORTED;
+}

@@ -161,7 +161,7 @@ def make_conv_desc(x, w, y, *, Hi, Wi, Cin, Cout, Hg, Wg, Ho, Wo, taps, isy=1, i
 
 
 def conv2d_fwd(x, wp, k, stride, pad, Cout, *, act="linear", scale=None, shift=None, res=None, stats=None,
-               out=None, out_f32=False):
+               out=None, out_f32=False, tune=0, stats_slots=0):
     """y = epilogue(conv(x, w)); x [B,Hi,Wi,Cin] channels-last, wp = pack_weight(w)."""
     _require_cuda(x, wp)
     B, Hi, Wi, Cin = x.shape
@@ -171,6 +171,7 @@ def conv2d_fwd(x, wp, k, stride, pad, Cout, *, act="linear", scale=None, shift=N
     d = make_conv_desc(x, wp, out, Hi=Hi, Wi=Wi, Cin=Cin, Cout=Cout, Hg=Ho, Wg=Wo, Ho=Ho, Wo=Wo,
                        taps=fwd_taps(k, pad), isy=stride, isx=stride, act=act, scale=scale, shift=shift,
                        res=res, stats=stats, out_f32=out_f32)
+    d.tune, d.stats_slots = tune, stats_slots
     check(load().dyk_conv_igemm(ctypes.byref(d), _stream()), "dyk_conv_igemm")
     return out
 

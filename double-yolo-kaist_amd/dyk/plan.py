@@ -738,7 +738,24 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
 # ======================================================================================
 _TUNE_CACHE = {}     # process-wide: the same problem always runs the same tile configuration (bit-reproducible
                      # results across plans / model instances within a process)
-_CONV_CANDIDATES = [64 | (2 << 8), 64 | (3 << 8), 128 | (2 << 8), 128 | (3 << 8)]
+def _conv_candidates(d):
+    """tile configurations of dyk_conv_igemm for one problem: K-step bytes | ring stages << 8 | pixel tile << 12
+    (0 = 128, 1 = 80, 2 = 160 pixels; bf16 only) | channel tile << 24 (0 = by Cout, 2 = 64, 1 = 32)"""
+    es = 2 if d.dtype == L.DYK_BF16 else 4
+    bkbs = [64] + ([128] if (d.Cin * es) % 128 == 0 else [])
+    tiles = [0, 1, 2] if d.dtype == L.DYK_BF16 else [0]
+    bms = [0] + ([2] if d.Cout > 64 else ([1] if d.Cout > 32 else []))
+    out = []
+    for bkb in bkbs:
+        for pipe in (2, 3, 4, 6):
+            for t in tiles:
+                for bm in bms:
+                    if t == 1 and bm == 1:
+                        continue                      # 80-pixel tile needs >= 64 channel rows
+                    out.append(bkb | (pipe << 8) | (t << 12) | (bm << 24))
+    return out
+
+
 _WGRAD_CANDIDATES = [2, 3, 2 | (2 << 8)]      # LDS ring stages | K-groups per workgroup << 8
 
 
@@ -774,8 +791,7 @@ def autotune(plan, cache=None):
         if best is None:
             d = descs[0]
             if key[0] == "c":
-                es = 2 if d.dtype == L.DYK_BF16 else 4
-                cands = [c for c in _CONV_CANDIDATES if (c & 0xff) == 64 or (d.Cin * es) % 128 == 0]
+                cands = _conv_candidates(d)
                 fn = lib.dyk_conv_igemm
             else:
                 cands, fn = _WGRAD_CANDIDATES, lib.dyk_conv_wgrad

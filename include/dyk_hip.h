@@ -102,8 +102,10 @@ typedef struct DykConvDesc {
     int32_t act;                    /* DYK_ACT_* applied after the affine */
     int32_t flags;                  /* DYK_EPI_* */
     int32_t stats_slots;            /* number of stats replicas (>= 1; 0 is read as 1) */
-    int32_t tune;                   /* 0 = built-in heuristic; else (K-step bytes: 64|128) | (LDS ring stages 2|3) << 8,
-                                       as chosen by the plan compiler's per-shape measurement */
+    int32_t tune;                   /* 0 = built-in heuristic; else tile configuration chosen by the plan compiler's
+                                       per-shape measurement: bits 0..7 K-step bytes (64|128), 8..11 LDS ring stages
+                                       (2|3|4|6), 12..15 pixel tile (0 = 128, 1 = 80, 2 = 160; bf16), 24..27 channel
+                                       tile (0 = by Cout, 1 = 32, 2 = 64, 3 = 128); bits 16..23 analysis switches */
 } DykConvDesc;
 
 int dyk_conv_igemm(const DykConvDesc* desc, void* stream);

@@ -218,3 +218,38 @@ def test_depthwise_conv_fwd_dgrad_wgrad(case, dtype):
     dw_ref = w.grad.reshape(C, k * k).t()
     err = (dw.cpu() - dw_ref).abs().max().item()
     assert err <= 1e-4 * max(1.0, dw_ref.abs().max().item()), "wgrad max err %g" % err
+
+
+@pytest.mark.parametrize("case", [(2, 64, 128, 16, 20, 3, 1), (1, 128, 96, 17, 23, 3, 1), (3, 64, 64, 9, 13, 1, 1),
+                                  (2, 32, 32, 20, 24, 3, 2)])
+def test_conv_every_tile_configuration(case):
+    """every instantiation the autotuner may pick (K step x ring depth x pixel tile 80/128/160 x channel tile) gives
+    the same result, with the statistics + affine/activation epilogues"""
+    from dyk import ops
+    from dyk.plan import _conv_candidates
+    B, Cin, Cout, H, W, k, s = case
+    pad = k // 2
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(B, Cin, H, W, generator=g)).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g)
+    y_ref = F.conv2d(x, w, stride=s, padding=pad)
+    z_ref = F.leaky_relu(y_ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0.1)
+    xd = ops.to_nhwc(x.cuda(), torch.bfloat16)
+    wp = ops.pack_weight(w.cuda(), torch.bfloat16)
+    probe = ops.make_conv_desc(xd, wp, xd, Hi=H, Wi=W, Cin=Cin, Cout=Cout, Hg=1, Wg=1, Ho=1, Wo=1, taps=ops.fwd_taps(k, pad))
+    cands = _conv_candidates(probe)
+    assert len(cands) >= 6
+    n = B * y_ref.shape[2] * y_ref.shape[3]
+    for tune in cands:
+        stats = torch.zeros(4, 2, Cout, dtype=torch.float64, device="cuda")
+        y = ops.conv2d_fwd(xd, wp, k, s, pad, Cout, stats=stats, stats_slots=4, tune=tune)
+        err = (ops.to_nchw(y).cpu() - y_ref).abs().max().item()
+        assert err <= 1.2e-2 * max(1.0, y_ref.abs().max().item()), (hex(tune), err)
+        st = stats.sum(0).cpu()
+        assert torch.allclose(st[0], y_ref.double().sum((0, 2, 3)), rtol=1e-3, atol=2e-2 * n ** 0.5), hex(tune)
+        assert torch.allclose(st[1], (y_ref.double() ** 2).sum((0, 2, 3)), rtol=2e-3, atol=1e-2), hex(tune)
+        z = ops.conv2d_fwd(xd, wp, k, s, pad, Cout, act="leaky", scale=scale.cuda(), shift=shift.cuda(), tune=tune)
+        err = (ops.to_nchw(z).cpu() - z_ref).abs().max().item()
+        assert err <= 1.5e-2 * max(1.0, z_ref.abs().max().item()), (hex(tune), err)

@@ -120,6 +120,40 @@ if "ablate" in what:
             print(rows[-1], flush=True)
     res["ablate"] = rows
 
+if "tunes" in what:
+    import ctypes as C
+    from dyk import lib as L
+    from dyk.plan import _conv_candidates
+    rows = []
+    for (ci, co, H, W, k) in [(512, 512, 16, 20, 3), (256, 256, 32, 40, 3), (128, 128, 64, 80, 3), (1024, 512, 16, 20, 1), (256, 256, 32, 40, 1)]:
+        B, dt = 16, torch.bfloat16
+        x = torch.randn(B, H, W, ci, device="cuda").to(dt)
+        w = torch.randn(co, ci, k, k, device="cuda") * 0.05
+        wp = ops.pack_weight(w, dt)
+        out = torch.empty(B, H, W, co, device="cuda", dtype=dt)
+        stats = torch.zeros(64 * co, dtype=torch.float64, device="cuda")
+        d = ops.make_conv_desc(x, wp, out, Hi=H, Wi=W, Cin=ci, Cout=co, Hg=H, Wg=W, Ho=H, Wo=W, taps=ops.fwd_taps(k, k // 2), stats=stats)
+        d.stats_slots = 32
+        fn = L.load().dyk_conv_igemm
+        res_ = []
+        for tune in _conv_candidates(d):
+            d.tune = tune
+            for _ in range(3):
+                fn(C.byref(d), None)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn(C.byref(d), None)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            res_.append((round(ms * 1e3, 1), "bkb%d p%d tile%d bm%d" % (tune & 0xff, (tune >> 8) & 0xf, (tune >> 12) & 0xf, (tune >> 24) & 0xf)))
+        res_.sort()
+        fl = 2.0 * B * H * W * ci * co * k * k
+        print((ci, co, H, k), "best", res_[:6], "worst", res_[-2:], "best TF %.0f" % (fl / res_[0][0] / 1e6), flush=True)
+        rows.append(((ci, co, H, k), res_))
+    res["tunes"] = rows
+
 if "wgablate" in what:
     import ctypes as C
     from dyk import lib as L
