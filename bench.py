@@ -231,9 +231,18 @@ def main():
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = 2.0 * f1 / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0      # forward + data-gradient launches
             tot_ms = sum(a[1] for w in prof.values() for a in w.values())
+            # HBM-side bytes per launch of the same kernel from the committed rocprofv3 PMC passes of this command
+            # (tools/run_gpu_round.sh: --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 fetch correction)
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+                    traffic = json.load(f)["conv_igemm_kernel"]["hbm_bytes_per_launch"]
+            except Exception:
+                pass
             out["roofline"] = {
                 "bound": "mfma", "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.json)",
                 "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1),
                 "flops_per_launch": 2.0 * f1 / max(ig_n, 1),
                 "detail": {

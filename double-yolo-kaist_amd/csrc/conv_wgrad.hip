@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc
 
     const int tiles_m = (a.Cout + BM - 1) / BM;
     const int tiles_n = (a.Cin + BN - 1) / BN;
-    int bid = blockIdx.x;
+    // consecutive remapped ids run on one XCD: the tiles and taps of one pixel range share that XCD's L2, so dy / x
+    // of the range are fetched from HBM once instead of once per tap and tile (measured 3.2x over-fetch without)
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = bid % tiles_m; bid /= tiles_m;
     const int tn = bid % tiles_n; bid /= tiles_n;
     const int tap = bid % a.ntaps;

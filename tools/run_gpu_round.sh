@@ -1,10 +1,20 @@
 #!/bin/bash
-# One GPU-box session: full GPU test suite, bench, rocprofv3 kernel-trace summary.  Outputs under gpurun_out/.
+# One GPU-box session: full GPU test suite, smoke, bench, rocprofv3 kernel-trace summary, PMC passes (HBM traffic).
+# Outputs under gpurun_out/ (copy what should be judged into profiles/).
 set -x
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err
 tail -c 3000 gpurun_out/bench.json
-rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
+rm -rf gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write && mkdir -p gpurun_out/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r1 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/prof/bench_under_prof.json 2> gpurun_out/prof/err.log
+# counters in their own runs, one pass per counter (TCC slots), kernel trace only
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_write.log 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_summary.json > gpurun_out/pmc_summary.txt 2>&1
+cat gpurun_out/pmc_summary.txt
+# keep the merge small: drop the per-dispatch traces
+find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*kernel_trace.csv" -delete
+find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*counter_collection.csv" -size +20M -delete
 ls -R gpurun_out/prof | head -30
