@@ -124,6 +124,59 @@ def cpu_baseline(cfg_name, steps=6):
                       % (steps, cfg_name, B, dt)}
 
 
+def eval_bench(args):
+    """inference pass of a cfg: forward + YOLO decode + non_max_suppression, batch images resident in HBM.
+    Also times NMS alone on the dense worst case (every candidate survives, untrained weights) and on a
+    trained-like synthetic prediction (~300 survivors per image)."""
+    from build_utils.parse_config import materialize_cfg
+    from build_utils.utils import non_max_suppression
+    from models import YOLO
+    device = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = YOLO(materialize_cfg(args.cfg))
+    model.dyk_dtype = args.dtype
+    model = model.to(device).eval()
+    B, H, W = args.batch, 512, 640
+    v8, l8, _ = synth_batch(B, H, W, 0, device)
+
+    def step(conf):
+        with torch.no_grad():
+            io, _ = model(v8.float() / 255.0, l8.float() / 255.0)
+            return io, non_max_suppression(io, conf_thres=conf, iou_thres=0.6)
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.time() - t0) / n, r
+
+    for _ in range(args.warmup):
+        step(0.1)
+    dt, (io, dets) = timed(lambda: step(0.1), args.steps)
+    nfwd, _ = timed(lambda: model(v8.float() / 255.0, l8.float() / 255.0), args.steps)
+    ncand = int((io[..., 4] > 0.1).sum().item())
+    dense = io.clone()
+    dense[..., 4:] = dense[..., 4:].clamp(min=0.5)
+    dense[..., 2:4] = dense[..., 2:4].clamp(3.0, 600.0)
+    t_dense, _ = timed(lambda: non_max_suppression(dense, conf_thres=0.1, iou_thres=0.6), max(3, args.steps // 4))
+    g = torch.Generator().manual_seed(3)
+    sparse = dense.clone()
+    keep = torch.rand(sparse.shape[:2], generator=g) < 300.0 / sparse.shape[1]
+    sparse[..., 4] = torch.where(keep.to(device), sparse[..., 4], torch.full_like(sparse[..., 4], 0.01))
+    t_sparse, _ = timed(lambda: non_max_suppression(sparse, conf_thres=0.1, iou_thres=0.6), args.steps)
+    out = {"metric": "paired RGB+LWIR images/sec (eval: forward + decode + NMS)", "value": B / dt, "unit": "pairs/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "%s.cfg eval forward + decode + NMS, 640x512 pairs, batch %d" % (args.cfg, B)},
+           "forward_ms": nfwd * 1e3, "candidates_over_conf": ncand,
+           "nms": {"rows_per_image": int(io.shape[1]),
+                   "dense_all_survive": {"ms_per_batch": t_dense * 1e3, "images_per_s": B / t_dense, "candidates_per_s": B * io.shape[1] / t_dense},
+                   "sparse_300_survivors": {"ms_per_batch": t_sparse * 1e3, "images_per_s": B / t_sparse}}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,7 +188,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-layers", default=None, help="write per-conv-launch timings to this JSON file")
+    ap.add_argument("--mode", default="train", choices=["train", "eval"],
+                    help="train: the BASELINE metric (default).  eval: forward + decode + NMS of --cfg (SURVEY 8d, config C2)")
     args = ap.parse_args()
+    if args.mode == "eval":
+        return eval_bench(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
