@@ -35,11 +35,12 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DykDwDesc d, int CVB) {
 #pragma unroll
     for (int j = 0; j < EPV; ++j) s1[j] = s2[j] = 0.f;
     if (active) {
-        for (long p = (long)blockIdx.y * PY + ty; p < npix; p += (long)gridDim.y * PY) {
-            const int xo = (int)(p % Wout);
-            const long q = p / Wout;
-            const int yo = (int)(q % Hout);
-            const int b = (int)(q / Hout);
+        // image rows over grid.y, pixels of a row over the pixel lanes: no per-pixel integer division
+        const int nrows = d.B * Hout;
+        for (int row = blockIdx.y; row < nrows; row += gridDim.y) {
+          const int b = row / Hout, yo = row - b * Hout;
+          for (int xo = ty; xo < Wout; xo += PY) {
+            const long p = (long)row * Wout + xo;
             float acc[EPV];
 #pragma unroll
             for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DykDwDesc d, int CVB) {
                 for (int j = 0; j < EPV; ++j) acc[j] += old[j];
             }
             *(uint4*)yp = vec_pack<T>(acc);
+          }
         }
     }
     if (stats) {
@@ -111,8 +113,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DykDwDesc d, int CVB) {
     }
 }
 
-// dw[t][c] += sum_p dy[p][c] * x[src(p, t)][c];  grid.z = tap
-template <typename T>
+// dw[t][c] += sum_p dy[p][c] * x[src(p, t)][c].  grid.z = kernel row kh; a thread keeps the K taps of that row for its
+// 8 channels in registers (K*8 accumulators), reads the output-gradient vector of a pixel once and the K input vectors of
+// the row from L1 -- one pass over dy per kernel row instead of one per tap, K x fewer workgroup reductions and atomics.
+template <typename T, int K>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DykDwDesc d, int CVB) {
     constexpr int EPV = ElemTraits<T>::EPV;
     __shared__ float red[256 * 8];
@@ -121,41 +125,59 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DykDwDesc d, int CVB)
     const int cv = blockIdx.x * CVB + tx;
     const int c = cv * EPV;
     const bool active = c < d.C;
-    const int tap = blockIdx.z;
-    const int kh = tap / d.k, kw = tap - kh * d.k;
+    const int kh = blockIdx.z;
     const T* __restrict__ x = (const T*)d.x;
     const T* __restrict__ dy = (const T*)d.y;       // output gradient [B,Ho,Wo,C]
     const long npix = (long)d.B * d.Ho * d.Wo;
-    float acc[EPV];
+    float acc[K][EPV];
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) acc[t][j] = 0.f;
     if (active) {
-        for (long p = (long)blockIdx.y * PY + ty; p < npix; p += (long)gridDim.y * PY) {
-            const int xo = (int)(p % d.Wo);
-            const long q = p / d.Wo;
-            const int yo = (int)(q % d.Ho);
-            const int b = (int)(q / d.Ho);
-            const int yi = yo * d.stride + kh - d.pad, xi = xo * d.stride + kw - d.pad;
-            if (yi < 0 || yi >= d.Hi || xi < 0 || xi >= d.Wi) continue;
-            float g[EPV], xv[EPV];
+        const int nrows = d.B * d.Ho;
+        for (int row = blockIdx.y; row < nrows; row += gridDim.y) {
+          const int b = row / d.Ho, yo = row - b * d.Ho;
+            const int yi = yo * d.stride + kh - d.pad;
+            if (yi < 0 || yi >= d.Hi) continue;
+          for (int xo = ty; xo < d.Wo; xo += PY) {
+            const long p = (long)row * d.Wo + xo;
+            float g[EPV];
             vec_unpack<T>(*(const uint4*)(dy + p * d.ldy + c), g);
-            vec_unpack<T>(*(const uint4*)(x + (((long)b * d.Hi + yi) * d.Wi + xi) * d.ldx + c), xv);
+            const T* xrow = x + ((long)b * d.Hi + yi) * d.Wi * d.ldx + c;
+            const int xi0 = xo * d.stride - d.pad;
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) acc[j] += g[j] * xv[j];
+            for (int t = 0; t < K; ++t) {
+                const int xi = xi0 + t;
+                if (xi < 0 || xi >= d.Wi) continue;
+                float xv[EPV];
+                vec_unpack<T>(*(const uint4*)(xrow + (long)xi * d.ldx), xv);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) acc[t][j] += g[j] * xv[j];
+            }
+          }
         }
     }
-    float* mine = red + threadIdx.x * 8;
+    // fold the pixel lanes through LDS, one tap at a time (8 floats per thread)
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) mine[j] = acc[j];
-    __syncthreads();
-    if (ty == 0 && active) {
-        for (int q = 1; q < PY; ++q) {
-            const float* o = red + (q * CVB + tx) * 8;
+    for (int t = 0; t < K; ++t) {
+        float* mine = red + threadIdx.x * 8;
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) acc[j] += o[j];
+        for (int j = 0; j < EPV; ++j) mine[j] = acc[t][j];
+        __syncthreads();
+        if (ty == 0 && active) {
+            float s[EPV];
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) s[j] = acc[t][j];
+            for (int q = 1; q < PY; ++q) {
+                const float* o = red + (q * CVB + tx) * 8;
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) s[j] += o[j];
+            }
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) unsafeAtomicAdd(d.dw + (long)(kh * K + t) * d.C + c + j, s[j]);
         }
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) unsafeAtomicAdd(d.dw + (long)tap * d.C + c + j, acc[j]);
+        __syncthreads();
     }
 }
 
@@ -168,12 +190,12 @@ int check_dw(const DykDwDesc* d) {
     return DYK_OK;
 }
 
-inline int grid2d(int CV, long npix, int* gx, int* gy, int per_thread, int cap_blocks) {
+// grid.x = channel-vector groups, grid.y = image rows (strided), capped at cap_blocks workgroups
+inline int grid2d(int CV, long nrows, int* gx, int* gy, int cap_blocks) {
     int CVB = 1;
     while (CVB < CV && CVB < 32) CVB <<= 1;
-    const int PY = 256 / CVB;
     *gx = (CV + CVB - 1) / CVB;
-    long g = (npix + (long)PY * per_thread - 1) / ((long)PY * per_thread);
+    long g = nrows;
     const long cap = cap_blocks / *gx > 0 ? cap_blocks / *gx : 1;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
@@ -189,7 +211,7 @@ extern "C" int dyk_dwconv_fwd(const DykDwDesc* d, void* stream) {
     if (!d->w) return DYK_ERR_ARG;
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     int gx, gy;
-    const int CVB = grid2d(d->C / epv, (long)d->B * d->Ho * d->Wo, &gx, &gy, 2, 4096);
+    const int CVB = grid2d(d->C / epv, (long)d->B * d->Ho, &gx, &gy, 4096);
     if (d->dtype == DYK_BF16)
         hipLaunchKernelGGL((dwconv_kernel<bf16_t, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
     else
@@ -204,11 +226,25 @@ extern "C" int dyk_dwconv_dgrad(const DykDwDesc* d, void* stream) {
     if (!d->w) return DYK_ERR_ARG;
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     int gx, gy;
-    const int CVB = grid2d(d->C / epv, (long)d->B * d->Hi * d->Wi, &gx, &gy, 2, 4096);
+    const int CVB = grid2d(d->C / epv, (long)d->B * d->Hi, &gx, &gy, 4096);
     if (d->dtype == DYK_BF16)
         hipLaunchKernelGGL((dwconv_kernel<bf16_t, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
     else
         hipLaunchKernelGGL((dwconv_kernel<float, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+template <typename T>
+int launch_dw_wgrad(const DykDwDesc* d, hipStream_t s, int gx, int gy, int CVB) {
+    const dim3 grid(gx, gy, d->k);
+    switch (d->k) {
+    case 1: hipLaunchKernelGGL((dwconv_wgrad_kernel<T, 1>), grid, dim3(256), 0, s, *d, CVB); break;
+    case 3: hipLaunchKernelGGL((dwconv_wgrad_kernel<T, 3>), grid, dim3(256), 0, s, *d, CVB); break;
+    case 5: hipLaunchKernelGGL((dwconv_wgrad_kernel<T, 5>), grid, dim3(256), 0, s, *d, CVB); break;
+    case 7: hipLaunchKernelGGL((dwconv_wgrad_kernel<T, 7>), grid, dim3(256), 0, s, *d, CVB); break;
+    default: return DYK_ERR_UNSUPPORTED;
+    }
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -219,11 +255,8 @@ extern "C" int dyk_dwconv_wgrad(const DykDwDesc* d, void* stream) {
     if (!d->dw) return DYK_ERR_ARG;
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     int gx, gy;
-    const int CVB = grid2d(d->C / epv, (long)d->B * d->Ho * d->Wo, &gx, &gy, 16, 512);
-    if (d->dtype == DYK_BF16)
-        hipLaunchKernelGGL(dwconv_wgrad_kernel<bf16_t>, dim3(gx, gy, d->k * d->k), dim3(256), 0, (hipStream_t)stream, *d, CVB);
-    else
-        hipLaunchKernelGGL(dwconv_wgrad_kernel<float>, dim3(gx, gy, d->k * d->k), dim3(256), 0, (hipStream_t)stream, *d, CVB);
-    DYK_LAUNCH_CHECK();
-    return DYK_OK;
+    // few, long-running workgroups: every workgroup ends with one atomic per (tap, channel) on only k*k*C addresses
+    const int CVB = grid2d(d->C / epv, (long)d->B * d->Ho, &gx, &gy, 768 / d->k);
+    if (d->dtype == DYK_BF16) return launch_dw_wgrad<bf16_t>(d, (hipStream_t)stream, gx, gy, CVB);
+    return launch_dw_wgrad<float>(d, (hipStream_t)stream, gx, gy, CVB);
 }

@@ -282,6 +282,18 @@ __global__ __launch_bounds__(256) void se_pool_kernel(DykEwDesc d, float* __rest
     }
 }
 
+// dot(W[row], v) for the SE matrix-vector products: a 16-lane group per output row (4 rows per wave in flight),
+// float4 loads, DPP row reduction -- the wave-per-row version spent its time in 6-step ds_bpermute reductions.
+// n is a multiple of 4 (channel counts are multiples of 8); every lane of the group returns the sum.
+__device__ inline float dot16(const float* __restrict__ wrow, const float* v, int n, int l16) {
+    float acc = 0.f;
+    for (int i = l16 * 4; i < n; i += 64) {
+        const float4 w4 = *(const float4*)(wrow + i);
+        acc += w4.x * v[i] + w4.y * v[i + 1] + w4.z * v[i + 2] + w4.w * v[i + 3];
+    }
+    return row16_sum(acc);
+}
+
 // one block per image: h = relu(W1 pooled + b1); s = hardsigmoid(W2 h + b2)   (layers.py:185-189)
 __global__ __launch_bounds__(1024) void se_fc_fwd_kernel(DykSeFcDesc d) {
     extern __shared__ float sm[];           // pooled[C] | h[Cs]
@@ -290,19 +302,15 @@ __global__ __launch_bounds__(1024) void se_fc_fwd_kernel(DykSeFcDesc d) {
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < d.C; i += blockDim.x) pooled[i] = d.pooled[(long)b * d.C + i];
     __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int j = w; j < d.Cs; j += nw) {           // one wave per output
-        float acc = 0.f;
-        for (int i = lane; i < d.C; i += 64) acc += d.w1[(long)j * d.C + i] * pooled[i];
-        acc = wave_sum(acc);
-        if (lane == 0) h[j] = fmaxf(acc + d.b1[j], 0.f);
+    const int l16 = threadIdx.x & 15, g16 = threadIdx.x >> 4, ng = blockDim.x >> 4;
+    for (int j = g16; j < d.Cs; j += ng) {
+        const float acc = dot16(d.w1 + (long)j * d.C, pooled, d.C, l16);
+        if (l16 == 0) h[j] = fmaxf(acc + d.b1[j], 0.f);
     }
     __syncthreads();
-    for (int c = w; c < d.C; c += nw) {
-        float acc = 0.f;
-        for (int j = lane; j < d.Cs; j += 64) acc += d.w2[(long)c * d.Cs + j] * h[j];
-        acc = wave_sum(acc);
-        if (lane == 0) d.scale[(long)b * d.C + c] = fminf(fmaxf(acc + d.b2[c] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    for (int c = g16; c < d.C; c += ng) {
+        const float acc = dot16(d.w2 + (long)c * d.Cs, h, d.Cs, l16);
+        if (l16 == 0) d.scale[(long)b * d.C + c] = fminf(fmaxf(acc + d.b2[c] + 3.f, 0.f), 6.f) * (1.f / 6.f);
     }
 }
 
@@ -318,19 +326,15 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(DykSeFcDesc d) {
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < d.C; i += blockDim.x) pooled[i] = d.pooled[(long)b * d.C + i];
     __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int j = w; j < d.Cs; j += nw) {
-        float acc = 0.f;
-        for (int i = lane; i < d.C; i += 64) acc += d.w1[(long)j * d.C + i] * pooled[i];
-        acc = wave_sum(acc);
-        if (lane == 0) { t1[j] = acc + d.b1[j]; h[j] = fmaxf(t1[j], 0.f); }
+    const int l16 = threadIdx.x & 15, g16 = threadIdx.x >> 4, ng = blockDim.x >> 4;
+    for (int j = g16; j < d.Cs; j += ng) {
+        const float acc = dot16(d.w1 + (long)j * d.C, pooled, d.C, l16);
+        if (l16 == 0) { t1[j] = acc + d.b1[j]; h[j] = fmaxf(t1[j], 0.f); }
     }
     __syncthreads();
-    for (int c = w; c < d.C; c += nw) {
-        float acc = 0.f;
-        for (int j = lane; j < d.Cs; j += 64) acc += d.w2[(long)c * d.Cs + j] * h[j];
-        acc = wave_sum(acc);
-        if (lane == 0) {
+    for (int c = g16; c < d.C; c += ng) {
+        const float acc = dot16(d.w2 + (long)c * d.Cs, h, d.Cs, l16);
+        if (l16 == 0) {
             const float t2 = acc + d.b2[c];
             const float g = (t2 > -3.f && t2 < 3.f) ? d.dscale[(long)b * d.C + c] * (1.f / 6.f) : 0.f;
             dt2[c] = g;
@@ -338,32 +342,55 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(DykSeFcDesc d) {
         }
     }
     __syncthreads();
-    // dW2[c][j] += dt2[c]*h[j] ; dh[j] = sum_c W2[c][j]*dt2[c]
-    for (int i = threadIdx.x; i < d.C * d.Cs; i += blockDim.x) {
-        const int c = i / d.Cs, j = i - c * d.Cs;
-        const float g = dt2[c] * h[j];
-        if (g != 0.f) unsafeAtomicAdd(d.dw2 + i, g);
-    }
-    for (int j = w; j < d.Cs; j += nw) {             // dh[j] = sum_c W2[c][j] dt2[c]: one wave per j
-        float acc = 0.f;
-        for (int c = lane; c < d.C; c += 64) acc += d.w2[(long)c * d.Cs + j] * dt2[c];
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            const float g = t1[j] > 0.f ? acc : 0.f;
-            dt1[j] = g;
-            if (g != 0.f) unsafeAtomicAdd(d.db1 + j, g);
+    // dh[j] = sum_c W2[c][j] dt2[c]: column sums, coalesced over j; 4 row groups of the block split c, folded in dt1
+    for (int j = threadIdx.x; j < d.Cs; j += blockDim.x) dt1[j] = 0.f;
+    __syncthreads();
+    {
+        const int jt = threadIdx.x & 255, rg = threadIdx.x >> 8, nrg = blockDim.x >> 8;
+        for (int j = jt; j < d.Cs; j += 256) {
+            float acc = 0.f;
+            for (int c = rg; c < d.C; c += nrg) acc += d.w2[(long)c * d.Cs + j] * dt2[c];
+            atomicAdd(dt1 + j, acc);               // LDS, 4-way
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < d.C * d.Cs; i += blockDim.x) {
-        const int j = i / d.C, c = i - j * d.C;
-        const float g = dt1[j] * pooled[c];
-        if (g != 0.f) unsafeAtomicAdd(d.dw1 + i, g);
+    for (int j = threadIdx.x; j < d.Cs; j += blockDim.x) {
+        const float g = t1[j] > 0.f ? dt1[j] : 0.f;
+        dt1[j] = g;
+        if (g != 0.f) unsafeAtomicAdd(d.db1 + j, g);
     }
+    __syncthreads();
+    // park what the weight-gradient kernel needs: h | dt1 | dt2
+    float* wsh = d.ws + (long)b * d.Cs;
+    float* wsd1 = d.ws + (long)d.B * d.Cs + (long)b * d.Cs;
+    float* wsd2 = d.ws + 2L * d.B * d.Cs + (long)b * d.C;
+    for (int j = threadIdx.x; j < d.Cs; j += blockDim.x) { wsh[j] = h[j]; wsd1[j] = dt1[j]; }
+    for (int c = threadIdx.x; c < d.C; c += blockDim.x) wsd2[c] = dt2[c];
     for (int c = threadIdx.x; c < d.C; c += blockDim.x) {      // coalesced over c, short loop over Cs
         float acc = 0.f;
         for (int j = 0; j < d.Cs; ++j) acc += d.w1[(long)j * d.C + c] * dt1[j];
         d.dpooled[(long)b * d.C + c] = acc;
+    }
+}
+
+// dW2[c][j] += sum_b dt2[b][c] h[b][j] ;  dW1[j][c] += sum_b dt1[b][j] pooled[b][c]   (one thread per element)
+__global__ __launch_bounds__(256) void se_fc_wgrad_kernel(DykSeFcDesc d) {
+    const long n = (long)d.C * d.Cs;
+    const float* h = d.ws;
+    const float* dt1 = d.ws + (long)d.B * d.Cs;
+    const float* dt2 = d.ws + 2L * d.B * d.Cs;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < 2 * n; i += (long)gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        if (i < n) {
+            const int c = (int)(i / d.Cs), j = (int)(i - (long)c * d.Cs);
+            for (int b = 0; b < d.B; ++b) acc += dt2[(long)b * d.C + c] * h[(long)b * d.Cs + j];
+            d.dw2[i] += acc;
+        } else {
+            const long k = i - n;
+            const int j = (int)(k / d.C), c = (int)(k - (long)j * d.C);
+            for (int b = 0; b < d.B; ++b) acc += dt1[(long)b * d.Cs + j] * d.pooled[(long)b * d.C + c];
+            d.dw1[k] += acc;
+        }
     }
 }
 
@@ -595,10 +622,13 @@ extern "C" int dyk_se_fc_fwd(const DykSeFcDesc* d, void* stream) {
 
 extern "C" int dyk_se_fc_bwd(const DykSeFcDesc* d, void* stream) {
     if (!d || !d->pooled || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->dscale || !d->dpooled || !d->dw1 || !d->db1 ||
-        !d->dw2 || !d->db2 || d->B <= 0 || d->C <= 0 || d->Cs <= 0)
+        !d->dw2 || !d->db2 || !d->ws || d->B <= 0 || d->C <= 0 || d->Cs <= 0)
         return DYK_ERR_ARG;
     const size_t lds = (size_t)(2 * d->C + 3 * d->Cs) * sizeof(float);
     hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(d->B), dim3(1024), lds, (hipStream_t)stream, *d);
+    const long n2 = 2L * d->C * d->Cs;
+    hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3((unsigned)((n2 + 255) / 256 < 4096 ? (n2 + 255) / 256 : 4096)), dim3(256), 0,
+                       (hipStream_t)stream, *d);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

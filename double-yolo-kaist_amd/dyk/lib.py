@@ -80,7 +80,7 @@ class DykBnFinalizeDesc(ctypes.Structure):
 class DykSeFcDesc(ctypes.Structure):
     _fields_ = [
         ("pooled", _vp), ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("scale", _vp), ("dscale", _vp),
-        ("dpooled", _vp), ("dw1", _vp), ("db1", _vp), ("dw2", _vp), ("db2", _vp),
+        ("dpooled", _vp), ("dw1", _vp), ("db1", _vp), ("dw2", _vp), ("db2", _vp), ("ws", _vp),
         ("B", _i32), ("C", _i32), ("Cs", _i32),
     ]
 

@@ -672,6 +672,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 x_in, C, Cs = rec["x"], rec["C"], rec["Cs"]
                 dscale = new_ws(B * C * 4)
                 dpooled = new_ws(B * C * 4)
+                fcws = new_ws(B * (C + 2 * Cs) * 4)
                 pd = ew_desc(a=dz, b=x_in, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W, alpha=1.0)
                 later(lambda pd=pd, dscale=dscale: setattr(pd, "aux", ws.ptr(dscale)))
                 plan.bwd.append((L.OP_SE_POOL, pd))
@@ -683,9 +684,9 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 fd.dw1, fd.db1 = store.g_ptr(pre + "fc1.weight"), store.g_ptr(pre + "fc1.bias")
                 fd.dw2, fd.db2 = store.g_ptr(pre + "fc2.weight"), store.g_ptr(pre + "fc2.bias")
                 fd.B, fd.C, fd.Cs = B, C, Cs
-                later(lambda fd=fd, rec=rec, dscale=dscale, dpooled=dpooled: (
+                later(lambda fd=fd, rec=rec, dscale=dscale, dpooled=dpooled, fcws=fcws: (
                     setattr(fd, "pooled", ws.ptr(rec["pooled"])), setattr(fd, "dscale", ws.ptr(dscale)),
-                    setattr(fd, "dpooled", ws.ptr(dpooled))))
+                    setattr(fd, "dpooled", ws.ptr(dpooled)), setattr(fd, "ws", ws.ptr(fcws))))
                 plan.bwd.append((L.OP_SE_FC_BWD, fd))
                 gx = gref(x_in)
                 sd = ew_desc(a=dz, out=gx, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W, alpha=1.0 / (x_in.H * x_in.W), flags=acc_flag(x_in))

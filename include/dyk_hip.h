@@ -237,7 +237,9 @@ int dyk_maxpool_bwd(const DykEwDesc* desc, const uint8_t* argmax, void* stream);
  *                 per-channel scale)
  *   dyk_se_fc_fwd : scale = hardsigmoid(W2 relu(W1 pooled + b1) + b2), one block per image
  *   dyk_se_scale  : out[b,hw,c] = a[b,hw,c]*p0[b*C+c] (+ alpha*p1[b*C+c])
- *   dyk_se_fc_bwd : from dscale = d(loss)/d(scale) produce dpooled and accumulate dW1,db1,dW2,db2 */
+ *   dyk_se_fc_bwd : from dscale = d(loss)/d(scale) produce dpooled and accumulate dW1,db1,dW2,db2.  Two launches:
+ *                   per image the FC chain (h, dt2, dt1 parked in `ws`), then one thread per weight element
+ *                   sums its outer products over the batch -- no atomics on the weight gradients. */
 typedef struct DykSeFcDesc {
     const float* pooled;   /* [B][C] */
     const float* w1;       /* [Cs][C]  fc1.weight */
@@ -248,6 +250,7 @@ typedef struct DykSeFcDesc {
     const float* dscale;   /* [B][C] (bwd) */
     float* dpooled;        /* [B][C] out (bwd) */
     float* dw1; float* db1; float* dw2; float* db2;   /* accumulated (bwd) */
+    float* ws;             /* bwd scratch, B*(C + 2*Cs) floats: h [B][Cs] | dt1 [B][Cs] | dt2 [B][C] */
     int32_t B, C, Cs;
 } DykSeFcDesc;
 int dyk_se_pool(const DykEwDesc* desc, float* pooled, void* stream);

@@ -203,6 +203,8 @@ def test_squeeze_excitation_fwd_bwd(dtype):
     grads = [torch.zeros_like(t) for t in prm]
     fd.dscale, fd.dpooled = dscale.data_ptr(), dpooled.data_ptr()
     fd.dw1, fd.db1, fd.dw2, fd.db2 = (t.data_ptr() for t in grads)
+    fcws = torch.zeros(B * (C + 2 * Cs), device="cuda")
+    fd.ws = fcws.data_ptr()
     ops.call("dyk_se_fc_bwd", fd)
     for got, ref, nm in zip(grads, (w1, b1, w2, b2), ("dw1", "db1", "dw2", "db2")):
         _close(got.cpu().view(-1), ref.grad.view(-1), 20 * tol, nm)
