@@ -288,7 +288,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)),
                 setattr(d, "shift", ws.ptr(vecs + 4 * cout))))
             plan.fwd.append((L.OP_CONV, d))
-            rec.update(z=z)
+            rec.update(z=z, conv_desc=d)
             return z, rec
         if dw:
             raise NotImplementedError("depthwise conv without batch_normalize (layer %d)" % i)
@@ -370,6 +370,27 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             C = min(x_in.C, a.C)
             if x_in.C != a.C:
                 raise NotImplementedError("[shortcut] with mismatched channel counts (layer %d)" % i)
+            prev = info[i - 1] if i > 0 else {}
+            fusable = (not mod.weight and prev.get("kind") == "conv" and prev.get("bn") and prev.get("z") is x_in
+                       and not model.routs[i - 1] and a is not x_in
+                       and ("bn_act_desc" in prev or "conv_desc" in prev) and not os.environ.get("DYK_DEBUG_PLAN"))
+            if fusable:
+                # plain residual add straight after conv+BN+act whose output nobody else reads: the add rides on the
+                # normalise+activation pass (training) / the conv epilogue (eval); z of the conv IS the shortcut output
+                if "bn_act_desc" in prev:
+                    e = prev["bn_act_desc"]
+                    e.ldb = a.ld
+                    later(lambda e=e, a=a: setattr(e, "b", ptr_of(a)))
+                else:
+                    cd = prev["conv_desc"]
+                    cd.flags |= L.EPI_RESIDUAL
+                    cd.ldr = a.ld
+                    later(lambda cd=cd, a=a: setattr(cd, "res", ptr_of(a)))
+                rec.update(weighted=False, fused=True, x=x_in, a=a, z=x_in)
+                cur = x_in
+                outs.append(cur)
+                info.append(rec)
+                continue
             z = new_act(B, x_in.H, x_in.W, x_in.C)
             if mod.weight:
                 weff = new_ws(16)
@@ -641,6 +662,10 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     continue
                 dz = gref(z)
                 x_in, a = rec["x"], rec["a"]
+                if rec.get("fused"):
+                    # z is the conv's own output: its gradient stays where it is, the skip branch gets a copy
+                    plan.bwd.append((L.OP_AXPBY, ew_desc(a=dz, out=gref(a), flags=acc_flag(a))))
+                    continue
                 if rec["weighted"]:
                     red = new_red(16)
                     d0 = ew_desc(a=dz, b=x_in)
