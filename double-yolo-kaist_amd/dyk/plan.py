@@ -130,6 +130,49 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         esize = esize or es
         return TRef("act", act_arena.alloc(Bn * Hn * Wn * ld * esize), Bn, Hn, Wn, C, ld, esize)
 
+    # ---- concat placement: a layer whose output is an input of a multi-source [route] writes straight into its
+    # channel slice of the concatenation buffer (no copy at the route).  Decided up front from the channel counts.
+    chans = []
+    for j, md in enumerate(defs):
+        tj = md["type"]
+        if tj in ("convolutional", "depthwiseconvolutional"):
+            chans.append(md["filters"])
+        elif tj == "route":
+            chans.append(sum(chans[q] for q in mods[j].layers))
+        else:
+            chans.append(chans[j - 1] if j else 3)
+    concat_slot, route_buf = {}, {}
+    for j, md in enumerate(defs):
+        if md["type"] == "route" and len(mods[j].layers) > 1:
+            c0 = 0
+            for q in mods[j].layers:
+                head_conv = q + 1 < len(defs) and defs[q + 1]["type"] == "yolo"
+                if (q not in concat_slot and chans[q] % 32 == 0 and not head_conv
+                        and defs[q]["type"] in ("convolutional", "depthwiseconvolutional", "maxpool", "upsample", "se")
+                        and list(mods[j].layers).count(q) == 1 and not os.environ.get("DYK_NO_CONCAT_PLACEMENT")):
+                    concat_slot[q] = (j, c0, sum(chans[r] for r in mods[j].layers))
+                c0 += chans[q]
+
+    nrefs = [0] * len(defs)           # how many sections read the output of section j
+    for j, md in enumerate(defs):
+        if md["type"] in ("route", "shortcut"):
+            for q in mods[j].layers:
+                nrefs[q] += 1
+        if md["type"] != "route" and j > 0:
+            nrefs[j - 1] += 1
+
+    def alloc_out(layer, Bn, Hn, Wn, C):
+        """output tensor of cfg section `layer`: a slice of its concat buffer when it has one"""
+        slot = concat_slot.get(layer)
+        if slot is None:
+            return new_act(Bn, Hn, Wn, C)
+        j, c0, ctot = slot
+        if j not in route_buf:
+            route_buf[j] = new_act(Bn, Hn, Wn, ctot)
+        buf = route_buf[j]
+        assert (buf.H, buf.W) == (Hn, Wn)
+        return buf.chan_slice(c0, C)
+
     def new_ws(nbytes):
         return ws.alloc(nbytes)
 
@@ -172,7 +215,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     head_idx = 0
     na_no = []
 
-    def conv_forward(i, x_in, stem_src, wname, bnpre, bnm, bias_name, k, stride, pad, cout, act, groups=1):
+    def conv_forward(i, x_in, stem_src, wname, bnpre, bnm, bias_name, k, stride, pad, cout, act, groups=1, out_layer=None):
         """emit forward commands of Conv2d [+ BatchNorm2d] [+ activation]; returns (out TRef, info dict).
         wname / bnpre / bias_name are parameter-store names (bnpre None = no BatchNorm)."""
         bn = bnpre is not None
@@ -237,7 +280,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         if bn:
             if training:
                 y_raw = new_act(B, Ho, Wo, cout)
-                z = new_act(B, Ho, Wo, cout)
+                z = alloc_out(out_layer, B, Ho, Wo, cout)
                 # replicas of the fp64 statistics accumulators: keep the atomics per address at a few dozen
                 tiles = (B * Ho * Wo + 127) // 128
                 slots = STAT_SLOTS if tiles <= 1024 else min(256, 1 << max(5, (tiles // 32 - 1).bit_length()))
@@ -266,7 +309,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 return z, rec
             # eval: running statistics folded into an affine (conv epilogue for the MFMA conv, one more
             # streaming pass for the depthwise conv)
-            z = new_act(B, Ho, Wo, cout)
+            z = alloc_out(out_layer, B, Ho, Wo, cout)
             vecs = new_ws(2 * cout * 4)
             fo = misc()
             fo.p[0], fo.p[1] = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
@@ -299,7 +342,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             z = new_act(B, Ho, Wo, cout, ld=HEAD_LD, esize=4)
             d.flags = L.EPI_AFFINE | L.EPI_OUT_F32
         else:
-            z = new_act(B, Ho, Wo, cout)
+            z = alloc_out(out_layer, B, Ho, Wo, cout)
             d.flags = L.EPI_AFFINE
         d.ldy, d.act = z.ld, act
         d.shift = store.p_ptr(bias_name)
@@ -328,7 +371,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             cur, rec = conv_forward(i, cur, stem, pre + "Conv2d.weight", (pre + "BatchNorm2d.") if bn else None,
                                     mod[1] if bn else None, pre + "Conv2d.bias", k, m["stride"],
                                     k // 2 if m["pad"] else 0, m["filters"], L.ACT_CODES.get(m["activation"], 0),
-                                    groups=m.get("groups", 1))
+                                    groups=m.get("groups", 1), out_layer=i)
         elif t == "depthwiseconvolutional":
             # DepthwiseSeparableConv2d (layers.py:218-231): depthwise k x k (padding fixed at 1) + BN + ReLU6,
             # then pointwise 1x1 + BN + ReLU6
@@ -340,7 +383,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             mid, rec_dw = conv_forward(i, cur, None, pre + "0.weight", pre + "1.", mod.conv[1], None, ks, m["stride"], 1,
                                        cur.C, relu6, groups=cur.C)
             cur, rec_pw = conv_forward(i, mid, None, pre + "3.weight", pre + "4.", mod.conv[4], None, 1, 1, 0,
-                                       m["filters"], relu6)
+                                       m["filters"], relu6, out_layer=i)
             rec = {"kind": "dwsep", "i": i, "parts": [rec_dw, rec_pw]}
         elif t == "route":
             layers = mod.layers
@@ -351,12 +394,15 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 srcs = [outs[j] for j in layers]
                 ctot = sum(s.C for s in srcs)
                 s0 = srcs[0]
-                cat = new_act(B, s0.H, s0.W, ctot)
+                cat = route_buf.get(i)
+                if cat is None:
+                    cat = new_act(B, s0.H, s0.W, ctot)
+                assert cat.C == ctot
                 c0 = 0
                 parts = []
-                for s in srcs:
-                    sl = cat.chan_slice(c0, s.C)
-                    plan.fwd.append((L.OP_AXPBY, ew_desc(a=s, out=sl)))
+                for j, s in zip(layers, srcs):
+                    if concat_slot.get(j, (None,))[0] != i:          # not produced in place: copy
+                        plan.fwd.append((L.OP_AXPBY, ew_desc(a=s, out=cat.chan_slice(c0, s.C))))
                     parts.append((s, c0))
                     c0 += s.C
                 cur = cat
@@ -413,7 +459,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             C, Cs = mod.fc1.in_channels, mod.fc1.out_channels
             pooled = new_ws(B * C * 4)
             scale = new_ws(B * C * 4)
-            z = new_act(B, x_in.H, x_in.W, C)
+            z = alloc_out(i, B, x_in.H, x_in.W, C)
             pd = ew_desc(a=x_in, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W, alpha=1.0 / (x_in.H * x_in.W))
             later(lambda pd=pd, pooled=pooled: setattr(pd, "aux", ws.ptr(pooled)))
             plan.fwd.append((L.OP_SE_POOL, pd))
@@ -435,7 +481,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             k, stride = m["size"], m["stride"]
             if stride != 1:
                 raise NotImplementedError("[maxpool] stride %d" % stride)
-            z = new_act(B, x_in.H, x_in.W, x_in.C)
+            z = alloc_out(i, B, x_in.H, x_in.W, x_in.C)
             amax = new_ws(x_in.npix * x_in.C) if training else None
             pd = ew_desc(a=x_in, out=z, Bn=B, Hn=x_in.H, Wn=x_in.W, k=k)
             if amax is not None:
@@ -447,7 +493,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             x_in = cur
             if m["stride"] != 2:
                 raise NotImplementedError("[upsample] stride %s" % m["stride"])
-            z = new_act(B, 2 * x_in.H, 2 * x_in.W, x_in.C)
+            z = alloc_out(i, B, 2 * x_in.H, 2 * x_in.W, x_in.C)
             plan.fwd.append((L.OP_UPSAMPLE_FWD, ew_desc(a=x_in, out=z, Bn=B, Hn=x_in.H, Wn=x_in.W)))
             rec.update(x=x_in, z=z)
             cur = z
@@ -652,7 +698,14 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 if out.tid not in ginit:
                     continue
                 go = gref(out)
-                for (s, c0) in rec["parts"]:
+                for (s, c0), q in zip(rec["parts"], mods[i].layers):
+                    if concat_slot.get(q, (None,))[0] == i and nrefs[q] == 1 and s.tid not in grads:
+                        # produced in place and read by nobody else: its gradient IS the slice of the concat gradient
+                        g = go.chan_slice(c0, s.C)
+                        g.tid = s.tid
+                        grads[s.tid] = g
+                        ginit.add(s.tid)
+                        continue
                     gs = gref(s)
                     fl = acc_flag(s)
                     plan.bwd.append((L.OP_AXPBY, ew_desc(a=go.chan_slice(c0, s.C), out=gs, C=s.C, flags=fl)))
