@@ -58,7 +58,7 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
 // lane; grid.x walks channel-vector groups, grid.y strides over pixels.  No integer division in the
 // loop, per-channel parameters live in registers, and a wave touches CVB*16 contiguous bytes per pixel
 // row (whole rows for C <= 256 bf16), i.e. fully coalesced when ld == C.
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwDesc d, int CVB) {
     constexpr int EPV = ElemTraits<T>::EPV;
     const int PY = 256 / CVB;
@@ -72,7 +72,6 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwDesc d, int CVB) {
     const T* __restrict__ a = (const T*)d.a;
     const T* __restrict__ r = (const T*)d.b;
     T* __restrict__ o = (T*)d.out;
-    const int act = d.act;
     constexpr int U = 4;                      // pixels in flight per thread (memory-level parallelism)
     const long pstep = (long)gridDim.y * PY;
     for (long p0 = (long)blockIdx.y * PY + ty; p0 < d.npix; p0 += pstep * U) {
@@ -92,7 +91,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwDesc d, int CVB) {
             float x[EPV], y[EPV];
             vec_unpack<T>(vx[u], x);
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) y[j] = act_fwd(act, x[j] * sc[j] + sh[j]);
+            for (int j = 0; j < EPV; ++j) y[j] = act_fwd_c<ACT>(x[j] * sc[j] + sh[j]);
             if (r) {
                 float rr[EPV];
                 vec_unpack<T>(vr[u], rr);
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwDesc d, int CVB) {
 }
 
 // block = (CVB channel vectors) x (PY pixel lanes); grid.x over channel-vector groups, grid.y over pixels
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(DykEwDesc d, int CVB) {
     constexpr int EPV = ElemTraits<T>::EPV;
     __shared__ float red[256 * 2 * 8];
@@ -128,8 +127,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(DykEwDesc d, int
         const T* __restrict__ y = (const T*)d.b;
         constexpr int U = 4;
         const long pstep = (long)gridDim.y * PY;
-        const int act = d.act;
-        for (long p0 = (long)blockIdx.y * PY + ty; p0 < d.npix; p0 += pstep * U) {
+            for (long p0 = (long)blockIdx.y * PY + ty; p0 < d.npix; p0 += pstep * U) {
             uint4 vg[U], vy[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -144,7 +142,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(DykEwDesc d, int
                 vec_unpack<T>(vy[u], yy);
 #pragma unroll
                 for (int j = 0; j < EPV; ++j) {
-                    const float da = g[j] * act_bwd(act, yy[j] * sc[j] + sh[j]);
+                    const float da = g[j] * act_bwd_c<ACT>(yy[j] * sc[j] + sh[j]);
                     s1[j] += da;
                     s2[j] += da * ((yy[j] - mu[j]) * rs[j]);
                 }
@@ -185,7 +183,7 @@ __global__ __launch_bounds__(256) void bn_bwd_params_kernel(double* red, float* 
     if (dgamma) dgamma[c] += (float)s2;
 }
 
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwDesc d, int CVB) {
     constexpr int EPV = ElemTraits<T>::EPV;
     const int PY = 256 / CVB;
@@ -203,7 +201,6 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwDesc d, int 
     const T* __restrict__ dz = (const T*)d.a;
     const T* __restrict__ y = (const T*)d.b;
     T* __restrict__ o = (T*)d.out;
-    const int act = d.act;
     const bool accum = d.flags & DYK_EW_ACCUM;
     constexpr int U = 4;
     const long pstep = (long)gridDim.y * PY;
@@ -227,7 +224,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwDesc d, int 
             vec_unpack<T>(vy[u], yy);
 #pragma unroll
             for (int j = 0; j < EPV; ++j) {
-                const float da = g[j] * act_bwd(act, yy[j] * sc[j] + sh[j]);
+                const float da = g[j] * act_bwd_c<ACT>(yy[j] * sc[j] + sh[j]);
                 const float xh = (yy[j] - mu[j]) * rs[j];
                 r[j] = sc[j] * (da - m1[j] - xh * m2[j]);      // sc = gamma * rstd
             }
@@ -255,6 +252,23 @@ inline int ew_grid2d(int CV, long npix, int* gx, int* gy) {
     *gy = (int)g;
     return CVB;
 }
+
+// one instantiation per (element type, activation): the activation switch is resolved on the host, the kernels'
+// inner loops are branch-free
+#define DYK_BN_LAUNCH_ACT(KERNEL, T, ...)                                                                         \
+    switch (d->act) {                                                                                              \
+    case DYK_ACT_LINEAR: hipLaunchKernelGGL((KERNEL<T, DYK_ACT_LINEAR>), __VA_ARGS__); break;                      \
+    case DYK_ACT_LEAKY: hipLaunchKernelGGL((KERNEL<T, DYK_ACT_LEAKY>), __VA_ARGS__); break;                        \
+    case DYK_ACT_MISH: hipLaunchKernelGGL((KERNEL<T, DYK_ACT_MISH>), __VA_ARGS__); break;                          \
+    case DYK_ACT_RELU: hipLaunchKernelGGL((KERNEL<T, DYK_ACT_RELU>), __VA_ARGS__); break;                          \
+    case DYK_ACT_RELU6: hipLaunchKernelGGL((KERNEL<T, DYK_ACT_RELU6>), __VA_ARGS__); break;                        \
+    case DYK_ACT_HSIGMOID: hipLaunchKernelGGL((KERNEL<T, DYK_ACT_HSIGMOID>), __VA_ARGS__); break;                  \
+    case DYK_ACT_HSWISH: hipLaunchKernelGGL((KERNEL<T, DYK_ACT_HSWISH>), __VA_ARGS__); break;                      \
+    default: return DYK_ERR_ARG;                                                                                   \
+    }
+#define DYK_BN_LAUNCH(KERNEL, ...)                                        \
+    if (d->dtype == DYK_BF16) { DYK_BN_LAUNCH_ACT(KERNEL, bf16_t, __VA_ARGS__) } \
+    else { DYK_BN_LAUNCH_ACT(KERNEL, float, __VA_ARGS__) }
 
 inline int ew_check(const DykEwDesc* d, bool need_b) {
     if (!d || !d->a || !d->out || d->npix <= 0 || d->C <= 0) return DYK_ERR_ARG;
@@ -290,10 +304,7 @@ extern "C" int dyk_bn_act_fwd(const DykEwDesc* d, void* stream) {
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     int gx, gy;
     const int CVB = ew_grid2d(d->C / epv, d->npix, &gx, &gy);
-    if (d->dtype == DYK_BF16)
-        hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
-    else
-        hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
+    DYK_BN_LAUNCH(bn_act_fwd_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB)
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -312,10 +323,7 @@ extern "C" int dyk_bn_act_bwd_reduce(const DykEwDesc* d, void* stream) {
     const long cap = 2048 / gx > 0 ? 2048 / gx : 1;
     if (gy > cap) gy = cap;
     if (gy < 1) gy = 1;
-    if (d->dtype == DYK_BF16)
-        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
-    else
-        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
+    DYK_BN_LAUNCH(bn_act_bwd_reduce_kernel, dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, *d, CVB)
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -335,10 +343,7 @@ extern "C" int dyk_bn_act_bwd_apply(const DykEwDesc* d, void* stream) {
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     int gx, gy;
     const int CVB = ew_grid2d(d->C / epv, d->npix, &gx, &gy);
-    if (d->dtype == DYK_BF16)
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
-    else
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
+    DYK_BN_LAUNCH(bn_act_bwd_apply_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB)
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

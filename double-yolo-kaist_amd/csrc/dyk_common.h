@@ -99,9 +99,9 @@ __device__ inline float act_fwd(int act, float x) {
     switch (act) {
     case DYK_ACT_LEAKY: return x > 0.f ? x : 0.1f * x;
     case DYK_ACT_MISH: {
-        // x * tanh(softplus(x)) with tanh(log(1+e^x)) = n / (n + 2), n = e^x (e^x + 2)
-        if (x > 20.f) return x;  // softplus threshold of torch
-        const float e = __expf(x);
+        // x * tanh(softplus(x)) with tanh(log(1+e^x)) = n / (n + 2), n = e^x (e^x + 2).  torch switches softplus to the
+        // identity above 20; clamping the exponent there gives n/(n+2) == 1.0f exactly, i.e. the same value, branch-free
+        const float e = __expf(fminf(x, 20.f));
         const float n = e * (e + 2.f);
         return x * (n * __builtin_amdgcn_rcpf(n + 2.f));      // v_rcp_f32: 1 ulp, no IEEE-division expansion
     }
@@ -113,17 +113,21 @@ __device__ inline float act_fwd(int act, float x) {
     }
 }
 // compile-time activation (hoists the switch out of unrolled epilogues)
+__device__ inline float act_bwd(int act, float x);
 template <int ACT> __device__ inline float act_fwd_c(float x, int runtime_act = 0) {
     if constexpr (ACT == DYK_ACT_LINEAR) return x;
     else if constexpr (ACT < 0) return act_fwd(runtime_act, x);      // ACT = -1: runtime switch
     else return act_fwd(ACT, x);
 }
+template <int ACT> __device__ inline float act_bwd_c(float x, int runtime_act = 0) {
+    if constexpr (ACT < 0) return act_bwd(runtime_act, x);
+    else return act_bwd(ACT, x);
+}
 __device__ inline float act_bwd(int act, float x) {
     switch (act) {
     case DYK_ACT_LEAKY: return x > 0.f ? 1.f : 0.1f;
     case DYK_ACT_MISH: {
-        if (x > 20.f) return 1.f;
-        const float e = __expf(x);
+        const float e = __expf(fminf(x, 20.f));               // x > 20: t == 1, derivative == 1 (see act_fwd)
         const float n = e * (e + 2.f);
         const float t = n * __builtin_amdgcn_rcpf(n + 2.f);   // tanh(softplus(x))
         const float sg = e * __builtin_amdgcn_rcpf(1.f + e);  // sigmoid(x)
