@@ -7,6 +7,7 @@
 // Backward:
 //   dyk_bn_act_bwd_reduce (sum dact, sum dact*xhat) -> dyk_bn_bwd_params (dgamma, dbeta)
 //   -> dyk_bn_act_bwd_apply (gradient w.r.t. the raw conv output) -> conv dgrad / wgrad.
+#include <stdlib.h>
 #include "dyk_common.h"
 
 namespace {
@@ -245,8 +246,10 @@ inline int ew_grid2d(int CV, long npix, int* gx, int* gy) {
     while (CVB < CV && CVB < 32) CVB <<= 1;
     const int PY = 256 / CVB;
     *gx = (CV + CVB - 1) / CVB;
-    long g = (npix + (long)PY * 8 - 1) / ((long)PY * 8);        // >= 8 pixels per thread (2 unrolled iterations)
-    const long cap = 2048 / *gx > 0 ? 2048 / *gx : 1;
+    static int ppt = 0, capb = 0;                               // DYK_EW_PPT / DYK_EW_CAP: sweep knobs (tools/gpu_probe.py bnbench)
+    if (!ppt) { const char* e = getenv("DYK_EW_PPT"); ppt = e ? atoi(e) : 8; const char* c = getenv("DYK_EW_CAP"); capb = c ? atoi(c) : 2048; }
+    long g = (npix + (long)PY * ppt - 1) / ((long)PY * ppt);    // >= 8 pixels per thread (2 unrolled iterations)
+    const long cap = capb / *gx > 0 ? capb / *gx : 1;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     *gy = (int)g;

@@ -218,6 +218,46 @@ extern "C" int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream,
     return DYK_OK;
 }
 
+// Backward lists: the weight-gradient launches are off the critical path (nothing in the same pass reads dW), so they
+// go to a second HIP stream and fill the gaps the chain  bn-apply -> dgrad -> bn-reduce -> ...  of short kernels leaves.
+// Each one waits (event) for everything enqueued before it on the main stream; the main stream joins at the end.
+extern "C" int dyk_run_commands_overlap(const DykCommand* cmds, int32_t n, void* stream, int32_t* failed_index) {
+    if (!cmds || n < 0) return DYK_ERR_ARG;
+    static hipStream_t aux = nullptr;
+    static hipEvent_t ring[64];
+    static hipEvent_t done = nullptr;
+    if (!aux) {
+        if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) return DYK_ERR_HIP;
+        for (auto& e : ring)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
+        if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
+    }
+    hipStream_t main_s = (hipStream_t)stream;
+    int k0 = 0, ev = 0;
+    bool used_aux = false;
+    for (int32_t k = 0; k <= n; ++k) {
+        const bool side = k < n && (cmds[k].op == DYK_OP_WGRAD || cmds[k].op == DYK_OP_DW_WGRAD);
+        if (k < n && !side) continue;
+        if (k > k0) {                                  // flush the main-stream run [k0, k)
+            int32_t f = -1;
+            const int rc = dyk_run_commands(cmds + k0, k - k0, stream, &f);
+            if (rc != DYK_OK) { if (failed_index) *failed_index = k0 + f; return rc; }
+        }
+        if (side) {
+            hipEvent_t e = ring[ev++ & 63];
+            if (hipEventRecord(e, main_s) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) return DYK_ERR_HIP;
+            const int rc = dyk_run_commands(cmds + k, 1, (void*)aux, nullptr);
+            if (rc != DYK_OK) { if (failed_index) *failed_index = k; return rc; }
+            used_aux = true;
+        }
+        k0 = k + 1;
+    }
+    if (used_aux) {
+        if (hipEventRecord(done, aux) != hipSuccess || hipStreamWaitEvent(main_s, done, 0) != hipSuccess) return DYK_ERR_HIP;
+    }
+    return DYK_OK;
+}
+
 extern "C" int dyk_run_commands_timed(const DykCommand* cmds, int32_t n, void* stream, float* ms_out) {
     if (!cmds || n <= 0 || !ms_out) return DYK_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;

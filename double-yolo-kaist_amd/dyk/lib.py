@@ -176,6 +176,7 @@ SIGNATURES = {
     "dyk_dwconv_dgrad": (_i32, [_P(DykDwDesc), _vp]),
     "dyk_dwconv_wgrad": (_i32, [_P(DykDwDesc), _vp]),
     "dyk_run_commands": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
+    "dyk_run_commands_overlap": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
     "dyk_yolo_decode": (_i32, [_P(DykDecodeDesc), _vp]),
     "dyk_build_targets": (_i32, [_P(DykTargetsDesc), _vp]),
     "dyk_yolo_loss": (_i32, [_P(DykLossDesc), _P(DykTargetsDesc), _vp]),

@@ -98,7 +98,9 @@ class Plan:
             return
         sub = ctypes.cast(ctypes.addressof(arr) + start * ctypes.sizeof(L.DykCommand), ctypes.POINTER(L.DykCommand))
         failed = ctypes.c_int32(-1)
-        rc = L.load().dyk_run_commands(sub, end - start, ctypes.c_void_p(stream_ptr), ctypes.byref(failed))
+        overlap = which == "bwd" and os.environ.get("DYK_OVERLAP_WGRAD", "1") != "0"
+        fn = L.load().dyk_run_commands_overlap if overlap else L.load().dyk_run_commands
+        rc = fn(sub, end - start, ctypes.c_void_p(stream_ptr), ctypes.byref(failed))
         if rc != 0 and failed.value >= 0:
             failed.value += start
         if rc != 0:

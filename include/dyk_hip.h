@@ -392,6 +392,10 @@ typedef struct DykCommand {
 /* Enqueue cmds[0..n) in order.  Stops at the first failure and returns its code; *failed_index
  * (may be NULL) receives the index of the failing command. */
 int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream, int32_t* failed_index);
+/* Same, for backward lists: weight-gradient commands (DYK_OP_WGRAD, DYK_OP_DW_WGRAD) are enqueued on a library-owned
+ * second stream, each behind an event that covers everything enqueued before it on `stream`; `stream` waits for the
+ * second stream before the call returns control of the ordering to the caller (no host synchronisation). */
+int dyk_run_commands_overlap(const DykCommand* cmds, int32_t n, void* stream, int32_t* failed_index);
 
 /* ------------------------------------------------------------------------------------
  * YOLOLayer inference decode (models.py:234-258): p [B,na,ny,nx,no] fp32 raw logits ->

@@ -154,6 +154,37 @@ if "tunes" in what:
         rows.append(((ci, co, H, k), res_))
     res["tunes"] = rows
 
+if "bnbench" in what:
+    import ctypes as C
+    from dyk import lib as L
+    rows = []
+    for (H, W, c) in [(64, 80, 128), (32, 40, 256), (128, 160, 64), (16, 20, 1024), (256, 320, 64)]:
+        B, dt = 16, torch.bfloat16
+        y = torch.randn(B, H, W, c, device="cuda").to(dt)
+        dz = torch.randn(B, H, W, c, device="cuda").to(dt)
+        z = torch.empty_like(y)
+        vec = [torch.rand(c, device="cuda") + 0.5 for _ in range(4)]
+        red = torch.zeros(32 * 2 * c, dtype=torch.float64, device="cuda")
+        out = []
+        for name, fn, d in [("fwd", "dyk_bn_act_fwd", ops.ew_desc(a=y, out=z, act="mish", p0=vec[0], p1=vec[1])),
+                            ("reduce", "dyk_bn_act_bwd_reduce", ops.ew_desc(a=dz, b=y, act="mish", p0=vec[0], p1=vec[1], p2=vec[2], p3=vec[3], red=red)),
+                            ("apply", "dyk_bn_act_bwd_apply", ops.ew_desc(a=dz, b=y, out=z, act="mish", p0=vec[0], p1=vec[1], p2=vec[2], p3=vec[3], red=red))]:
+            d.slots = 32
+            f = getattr(L.load(), fn)
+            for _ in range(3):
+                f(C.byref(d), None)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                f(C.byref(d), None)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            nb = y.numel() * 2 * (2 if name != "apply" else 3)
+            out.append("%s %.1fus %.0fGB/s" % (name, ms * 1e3, nb / ms / 1e6))
+        print((H, W, c), "  ".join(out), flush=True)
+    res["bnbench"] = rows
+
 if "wgablate" in what:
     import ctypes as C
     from dyk import lib as L
