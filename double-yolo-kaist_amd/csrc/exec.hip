@@ -218,42 +218,55 @@ extern "C" int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream,
     return DYK_OK;
 }
 
-// Backward lists: the weight-gradient launches are off the critical path (nothing in the same pass reads dW), so they
-// go to a second HIP stream and fill the gaps the chain  bn-apply -> dgrad -> bn-reduce -> ...  of short kernels leaves.
-// Each one waits (event) for everything enqueued before it on the main stream; the main stream joins at the end.
+// Concurrency beyond one in-order stream (the lists are chains of short kernels whose ramp-up and tail leave CUs idle):
+//  * the weight-gradient launches of a backward list are off the critical path (nothing in the pass reads dW): they go
+//    to a side stream, each behind an event covering everything enqueued before it on the issuing stream;
+//  * the second backbone of a dual-stream net is independent of the first between its fork and join points
+//    (DykCommand.lane, set by the plan compiler): it runs on a branch stream.
+// The caller's stream waits for both at the end; nothing synchronises with the host.
 extern "C" int dyk_run_commands_overlap(const DykCommand* cmds, int32_t n, void* stream, int32_t* failed_index) {
     if (!cmds || n < 0) return DYK_ERR_ARG;
-    static hipStream_t aux = nullptr;
+    static hipStream_t branch = nullptr, side = nullptr;
     static hipEvent_t ring[64];
-    static hipEvent_t done = nullptr;
-    if (!aux) {
-        if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) return DYK_ERR_HIP;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr;
+    if (!branch) {
+        if (hipStreamCreateWithFlags(&branch, hipStreamNonBlocking) != hipSuccess) return DYK_ERR_HIP;
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return DYK_ERR_HIP;
         for (auto& e : ring)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
-        if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
+        if (hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
+        if (hipEventCreateWithFlags(&ev_done, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
     }
     hipStream_t main_s = (hipStream_t)stream;
-    int k0 = 0, ev = 0;
-    bool used_aux = false;
-    for (int32_t k = 0; k <= n; ++k) {
-        const bool side = k < n && (cmds[k].op == DYK_OP_WGRAD || cmds[k].op == DYK_OP_DW_WGRAD);
-        if (k < n && !side) continue;
-        if (k > k0) {                                  // flush the main-stream run [k0, k)
-            int32_t f = -1;
-            const int rc = dyk_run_commands(cmds + k0, k - k0, stream, &f);
-            if (rc != DYK_OK) { if (failed_index) *failed_index = k0 + f; return rc; }
+    int ev = 0;
+    bool forked = false, used_side = false;
+    auto join_branch = [&]() -> bool {
+        if (hipEventRecord(ev_join, branch) != hipSuccess || hipStreamWaitEvent(main_s, ev_join, 0) != hipSuccess) return false;
+        forked = false;
+        return true;
+    };
+    for (int32_t k = 0; k < n; ++k) {
+        const int lane = cmds[k].lane;
+        if ((lane & 4) && forked && !join_branch()) return DYK_ERR_HIP;
+        if (lane & 2) {
+            if (forked && !join_branch()) return DYK_ERR_HIP;
+            if (hipEventRecord(ev_fork, main_s) != hipSuccess || hipStreamWaitEvent(branch, ev_fork, 0) != hipSuccess) return DYK_ERR_HIP;
+            forked = true;
         }
-        if (side) {
+        hipStream_t target = (forked && (lane & 1)) ? branch : main_s;
+        if (cmds[k].op == DYK_OP_WGRAD || cmds[k].op == DYK_OP_DW_WGRAD) {
             hipEvent_t e = ring[ev++ & 63];
-            if (hipEventRecord(e, main_s) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) return DYK_ERR_HIP;
-            const int rc = dyk_run_commands(cmds + k, 1, (void*)aux, nullptr);
-            if (rc != DYK_OK) { if (failed_index) *failed_index = k; return rc; }
-            used_aux = true;
+            if (hipEventRecord(e, target) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return DYK_ERR_HIP;
+            target = side;
+            used_side = true;
         }
-        k0 = k + 1;
+        const int rc = dyk_run_commands(cmds + k, 1, (void*)target, nullptr);
+        if (rc != DYK_OK) { if (failed_index) *failed_index = k; return rc; }
     }
-    if (used_aux) {
-        if (hipEventRecord(done, aux) != hipSuccess || hipStreamWaitEvent(main_s, done, 0) != hipSuccess) return DYK_ERR_HIP;
+    if (forked && !join_branch()) return DYK_ERR_HIP;
+    if (used_side) {
+        if (hipEventRecord(ev_done, side) != hipSuccess || hipStreamWaitEvent(main_s, ev_done, 0) != hipSuccess) return DYK_ERR_HIP;
     }
     return DYK_OK;
 }

@@ -102,7 +102,7 @@ class DykMiscDesc(ctypes.Structure):
 
 
 class DykCommand(ctypes.Structure):
-    _fields_ = [("op", _i32), ("_pad", _i32), ("desc", _vp)]
+    _fields_ = [("op", _i32), ("lane", _i32), ("desc", _vp)]
 
 
 class DykDecodeDesc(ctypes.Structure):

@@ -80,16 +80,17 @@ class Plan:
         self._keep = []
         self._cfwd = self._cbwd = None
 
-    def _pack(self, cmds):
+    def _pack(self, cmds, lanes):
         arr = (L.DykCommand * max(len(cmds), 1))()
         for i, (op, desc) in enumerate(cmds):
             arr[i].op = op
+            arr[i].lane = lanes.get(i, 0)
             arr[i].desc = ctypes.addressof(desc)
         return arr
 
     def finalize(self):
-        self._cfwd = self._pack(self.fwd)
-        self._cbwd = self._pack(self.bwd)
+        self._cfwd = self._pack(self.fwd, getattr(self, "fwd_lanes", {}))
+        self._cbwd = self._pack(self.bwd, getattr(self, "bwd_lanes", {}))
 
     def run(self, which, stream_ptr, start=0, end=None):
         arr, n = (self._cfwd, len(self.fwd)) if which == "fwd" else (self._cbwd, len(self.bwd))
@@ -98,7 +99,7 @@ class Plan:
             return
         sub = ctypes.cast(ctypes.addressof(arr) + start * ctypes.sizeof(L.DykCommand), ctypes.POINTER(L.DykCommand))
         failed = ctypes.c_int32(-1)
-        overlap = which == "bwd" and os.environ.get("DYK_OVERLAP_WGRAD", "1") != "0"
+        overlap = os.environ.get("DYK_OVERLAP", "1") != "0"
         fn = L.load().dyk_run_commands_overlap if overlap else L.load().dyk_run_commands
         rc = fn(sub, end - start, ctypes.c_void_p(stream_ptr), ctypes.byref(failed))
         if rc != 0 and failed.value >= 0:
@@ -355,10 +356,12 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             raise NotImplementedError("activation on a conv without batch_normalize (layer %d)" % i)
         return z, rec
 
+    fwd_start = []            # index of the first forward command of each section
     for i, m in enumerate(defs):
         t = m["type"]
         mod = mods[i]
         rec = {"kind": t, "i": i}
+        fwd_start.append(len(plan.fwd))
         if t == "convolutional":
             stem = None
             if i == 0:
@@ -798,6 +801,31 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         hi = max(o + n for o, n in red_offs)
         memset_desc.n, memset_desc.i[0] = hi - lo, 0
         later(lambda ms=memset_desc, lo=lo: ms.p.__setitem__(0, ws.ptr(lo)))
+
+    # ---------------------------------------------------------------- branch lanes (dual-stream nets)
+    # sections [second, F) -- the second backbone up to the first section that reads anything of the first one -- are
+    # independent of sections [0, second): tag them for the branch stream of dyk_run_commands_overlap
+    plan.fwd_lanes, plan.bwd_lanes = {}, {}
+    if second is not None and 0 < second < len(defs) and os.environ.get("DYK_BRANCH_LANES", "1") != "0":
+        F = len(defs)
+        for j in range(second, len(defs)):
+            if defs[j]["type"] in ("route", "shortcut") and any(q < second for q in mods[j].layers):
+                F = j
+                break
+        if second < F < len(defs):
+            lo, hi = fwd_start[second], fwd_start[F]
+            if 0 < lo < hi < len(plan.fwd):
+                plan.fwd_lanes[0] = 2                               # fork at the very start
+                for q in range(lo, hi):
+                    plan.fwd_lanes[q] = plan.fwd_lanes.get(q, 0) | 1
+                plan.fwd_lanes[hi] = plan.fwd_lanes.get(hi, 0) | 4  # join in front of the fusion section
+            if training:
+                mark = {li: n for n, li in plan.bwd_marks}          # commands emitted before section li's backward
+                b0, a0 = mark.get(F - 1), mark.get(second - 1)
+                if b0 is not None and a0 is not None and 0 < b0 < a0 < len(plan.bwd):
+                    plan.bwd_lanes[b0] = 2                          # fork once the fusion sections' gradients exist
+                    for q in range(a0, len(plan.bwd)):
+                        plan.bwd_lanes[q] = plan.bwd_lanes.get(q, 0) | 1
 
     # ---------------------------------------------------------------- materialise
     for a in plan.arenas.values():

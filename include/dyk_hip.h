@@ -385,16 +385,20 @@ enum {
 
 typedef struct DykCommand {
     int32_t op;
-    int32_t _pad;
+    int32_t lane;         /* scheduling hints for dyk_run_commands_overlap (ignored by dyk_run_commands):
+                             bit 0 = belongs to the second, independent branch (the LWIR backbone of a dual-stream
+                             net); bit 1 = fork point (the branch may start once everything before this command is
+                             done); bit 2 = join (this command needs both branches) */
     const void* desc;
 } DykCommand;
 
 /* Enqueue cmds[0..n) in order.  Stops at the first failure and returns its code; *failed_index
  * (may be NULL) receives the index of the failing command. */
 int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream, int32_t* failed_index);
-/* Same, for backward lists: weight-gradient commands (DYK_OP_WGRAD, DYK_OP_DW_WGRAD) are enqueued on a library-owned
- * second stream, each behind an event that covers everything enqueued before it on `stream`; `stream` waits for the
- * second stream before the call returns control of the ordering to the caller (no host synchronisation). */
+/* Same result, more concurrency: commands tagged as the second branch (DykCommand.lane) run on a library-owned
+ * stream between their fork and join points, and weight-gradient commands (DYK_OP_WGRAD, DYK_OP_DW_WGRAD; nothing
+ * in a backward pass reads dW) on another one, each behind an event that covers everything enqueued before it on
+ * the issuing stream.  `stream` waits for both side streams before the call returns (no host synchronisation). */
 int dyk_run_commands_overlap(const DykCommand* cmds, int32_t n, void* stream, int32_t* failed_index);
 
 /* ------------------------------------------------------------------------------------
