@@ -13,6 +13,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement): whole-job pairs
 Synthetic data per SURVEY.md §8(d): uint8 uniform paired images, 4 boxes per image, seeds 1234+rank.
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -133,7 +134,8 @@ def eval_bench(args):
     from models import YOLO
     device = torch.device("cuda", 0)
     torch.manual_seed(0)
-    model = YOLO(materialize_cfg(args.cfg))
+    with contextlib.redirect_stdout(sys.stderr):
+        model = YOLO(materialize_cfg(args.cfg))
     model.dyk_dtype = args.dtype
     model = model.to(device).eval()
     B, H, W = args.batch, 512, 640
@@ -213,7 +215,8 @@ def main():
     from models import YOLO
 
     torch.manual_seed(0)
-    model = YOLO(materialize_cfg(args.cfg))
+    with contextlib.redirect_stdout(sys.stderr):          # the reference-style "Model Summary" line is not bench output
+        model = YOLO(materialize_cfg(args.cfg))
     model.nc, model.hyp, model.gr = 1, load_hyp(), 1.0
     model.dyk_dtype = args.dtype
     model = model.to(device).train()

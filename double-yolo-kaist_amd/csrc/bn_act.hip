@@ -184,12 +184,41 @@ __global__ __launch_bounds__(256) void bn_bwd_params_kernel(double* red, float* 
     if (dgamma) dgamma[c] += (float)s2;
 }
 
+// The totals of the reduce pass are folded here (every workgroup sums the `slots` replicas of its own <= 256
+// channels through LDS -- 2 x 32 coalesced fp64 loads per thread), and the workgroups of grid row 0 add them to
+// dgamma / dbeta (aux / aux2): no separate parameter-gradient launch on the critical chain of the backward pass.
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwDesc d, int CVB) {
     constexpr int EPV = ElemTraits<T>::EPV;
+    __shared__ float s_tot[2][256];
     const int PY = 256 / CVB;
     const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
     const int cv = blockIdx.x * CVB + tx;
+    {
+        const int c_base = blockIdx.x * CVB * EPV;
+        const int nch = min(CVB * EPV, d.C - c_base);
+        const int slots = d.slots > 0 ? d.slots : 1;
+        for (int idx = threadIdx.x; idx < 2 * nch; idx += 256) {
+            const int which = idx >= nch, cl = idx - which * nch;
+            const double* p = d.red + (size_t)which * d.C + c_base + cl;
+            // 8 independent loads in flight (a dependent chain of `slots` L2 round trips would cost ~10 us here)
+            double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            const size_t rs = (size_t)2 * d.C;
+            int r = 0;
+            for (; r + 8 <= slots; r += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a8[u] += p[(size_t)(r + u) * rs];
+            }
+            for (; r < slots; ++r) a8[0] += p[(size_t)r * rs];
+            const double acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+            s_tot[which][cl] = (float)acc;
+            if (blockIdx.y == 0) {
+                float* g = which ? (float*)d.aux : (float*)d.aux2;      // sum(dact * xhat) -> dgamma, sum(dact) -> dbeta
+                if (g) g[c_base + cl] += (float)acc;
+            }
+        }
+        __syncthreads();
+    }
     if (cv * EPV >= d.C) return;
     const int c = cv * EPV;
     const float invn = 1.f / (float)d.npix;
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwDesc d, int 
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
         sc[j] = d.p0[c + j]; sh[j] = d.p1[c + j]; mu[j] = d.p2[c + j]; rs[j] = d.p3[c + j];
-        m1[j] = (float)d.red[c + j] * invn; m2[j] = (float)d.red[d.C + c + j] * invn;
+        m1[j] = s_tot[0][tx * EPV + j] * invn; m2[j] = s_tot[1][tx * EPV + j] * invn;
     }
     const T* __restrict__ dz = (const T*)d.a;
     const T* __restrict__ y = (const T*)d.b;

@@ -62,7 +62,7 @@ class DykWgradDesc(ctypes.Structure):
 class DykEwDesc(ctypes.Structure):
     _fields_ = [
         ("a", _vp), ("b", _vp), ("out", _vp), ("p0", _vp), ("p1", _vp), ("p2", _vp), ("p3", _vp), ("red", _vp),
-        ("aux", _vp),
+        ("aux", _vp), ("aux2", _vp),
         ("dtype", _i32), ("npix", _i32), ("C", _i32), ("lda", _i32), ("ldb", _i32), ("ldo", _i32),
         ("act", _i32), ("flags", _i32), ("B", _i32), ("H", _i32), ("W", _i32), ("k", _i32),
         ("alpha", _f32), ("beta", _f32), ("slots", _i32),

@@ -657,15 +657,13 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     setattr(r, "p2", ws.ptr(vecs + 8 * cout)), setattr(r, "p3", ws.ptr(vecs + 12 * cout)),
                     setattr(r, "red", ws.ptr(red))))
                 plan.bwd.append((L.OP_BN_BWD_REDUCE, r))
-                pm = misc()
-                pm.p[1], pm.p[2] = store.g_ptr(bnpre + "weight"), store.g_ptr(bnpre + "bias")
-                pm.i[0], pm.i[1] = cout, STAT_SLOTS
-                later(lambda pm=pm, red=red: pm.p.__setitem__(0, ws.ptr(red)))
-                plan.bwd.append((L.OP_BN_BWD_PARAMS, pm))
                 dyr = dz
                 if os.environ.get("DYK_DEBUG_PLAN"):      # keep dz intact for per-layer gradient dumps
                     dyr = TRef("grad", grad_arena.alloc(dz.npix * dz.ld * es), dz.B, dz.H, dz.W, dz.C, dz.ld, es)
                 ap = ew_desc(a=dz, b=rec["y_raw"], out=dyr, act=rec["act"])     # in place: dz -> dy_raw
+                # the apply pass folds the replicas of the reduction itself and adds them to dgamma / dbeta
+                ap.slots = STAT_SLOTS
+                ap.aux, ap.aux2 = store.g_ptr(bnpre + "weight"), store.g_ptr(bnpre + "bias")
                 later(lambda ap=ap, vecs=vecs, red=red, cout=cout: (
                     setattr(ap, "p0", ws.ptr(vecs)), setattr(ap, "p1", ws.ptr(vecs + 4 * cout)),
                     setattr(ap, "p2", ws.ptr(vecs + 8 * cout)), setattr(ap, "p3", ws.ptr(vecs + 12 * cout)),

@@ -157,7 +157,8 @@ typedef struct DykEwDesc {
     const float* p2;
     const float* p3;
     double* red;
-    void* aux;                      /* op-specific extra pointer (max-pool argmax map, SE pooled vector) */
+    void* aux;                      /* op-specific extra pointer (max-pool argmax map, SE pooled vector, BN dgamma) */
+    void* aux2;                     /* second op-specific pointer (BN dbeta) */
     int32_t dtype;
     int32_t npix, C;
     int32_t lda, ldb, ldo;

@@ -73,6 +73,23 @@ def test_bn_act_train_fwd_bwd(dtype, act):
     # in-place form used by the plan (out aliases a)
     ops.call("dyk_bn_act_bwd_apply", ops.ew_desc(a=dzd, b=yd, out=dzd, act=act, p0=scale, p1=shift, p2=mean, p3=rstd, red=red))
     _close(ops.to_nchw(dzd).cpu(), yr.grad, tol, "dy in place")
+    # fused form used by the plan: apply folds the replicas itself and adds the totals to dgamma / dbeta
+    dzd = ops.to_nhwc(dz.cuda(), dtype)
+    red.zero_()
+    ops.call("dyk_bn_act_bwd_reduce", _redesc(ops, dzd, yd, act, scale, shift, mean, rstd, red, slots))
+    dgamma2, dbeta2 = torch.ones(C, device="cuda"), torch.ones(C, device="cuda")       # accumulate onto existing values
+    ap = ops.ew_desc(a=dzd, b=yd, out=dzd, act=act, p0=scale, p1=shift, p2=mean, p3=rstd, red=red)
+    ap.slots, ap.aux, ap.aux2 = slots, dgamma2.data_ptr(), dbeta2.data_ptr()
+    ops.call("dyk_bn_act_bwd_apply", ap)
+    _close(ops.to_nchw(dzd).cpu(), yr.grad, tol, "dy fused")
+    _close(dgamma2.cpu() - 1, gamma.grad, 10 * tol, "dgamma fused")
+    _close(dbeta2.cpu() - 1, beta.grad, 10 * tol, "dbeta fused")
+
+
+def _redesc(ops, dzd, yd, act, scale, shift, mean, rstd, red, slots):
+    rd = ops.ew_desc(a=dzd, b=yd, act=act, p0=scale, p1=shift, p2=mean, p3=rstd, red=red)
+    rd.slots = slots
+    return rd
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
