@@ -87,222 +87,17 @@ template <int BM, int BN> struct WaveGrid {
 };
 template <int BN> constexpr int table_bytes() { return BN * (3 * 4 + 2 * 2) + 1024 + 4 * 32 * 4 + 2 * 128 * 4; }
 
-// PIPE: LDS-DMA ring stages (2 | 3)
-template <typename T, int BM, int BN, int BKB, int PIPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_kernel(const ConvArgs args) {
-    const DykConvDesc& a = args.d;
-    constexpr int TABLE_BYTES = table_bytes<BN>();
-    constexpr int EPV = 16 / (int)sizeof(T);
-    constexpr int BK = BKB / (int)sizeof(T);
-    constexpr int WM = WaveGrid<BM, BN>::WM;  // waves along M
-    constexpr int WN = WaveGrid<BM, BN>::WN;
-    constexpr int WTM = BM / WM;
-    constexpr int WTN = BN / WN;
+// Shared epilogue of the convolution kernels: BN statistics, affine / activation / residual / accumulate, staged
+// coalesced stores.  Called by every thread after the K loop's last barrier (the operand ring is free: sC overlays it).
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&acc)[(BM / WaveGrid<BM, BN>::WM) / 16][(BN / WaveGrid<BM, BN>::WN) / 16],
+                                              char* sC, float* s_stat, const int* t_out, const int* t_res, int m0) {
+    constexpr int WM = WaveGrid<BM, BN>::WM, WN = WaveGrid<BM, BN>::WN;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = WTM / 16, NI = WTN / 16;
-    constexpr int KK = BKB / 64;
-    constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
-    constexpr int NSTAGE = PIPE;
-
-    // LDS: [pixel / tap tables | dummy-DMA sink | stats scratch] then the operand ring, which the
-    // epilogue re-uses as the output staging tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* t_in = (int*)smem;                   // [BN] input base offset
-    int* t_out = t_in + BN;                   // [BN] output offset or -1
-    int* t_res = t_out + BN;                  // [BN] residual offset
-    short* t_y = (short*)(t_res + BN);        // [BN] input row of tap (0,0)
-    short* t_x = t_y + BN;                    // [BN]
-    char* sink = (char*)(t_x + BN);           // [1024] target of dummy LDS-DMA writes (DMA path only)
-    int* tap_x = (int*)(sink + 1024);         // [32] activation element offset of a tap: (dy*Wi + dx)*ldx
-    int* tap_w = tap_x + 32;                  // [32] weight element offset of a tap: twt*Cout*Cin
-    int* tap_dy = tap_w + 32;                 // [32]
-    int* tap_dx = tap_dy + 32;                // [32]
-    float* s_stat = (float*)(tap_dx + 32);    // [2][BM] per-workgroup channel sums (STATS epilogue)
-    char* sA = smem + TABLE_BYTES;                 // [NSTAGE][A_BYTES]
-    char* sB = sA + NSTAGE * A_BYTES;              // [NSTAGE][B_BYTES]
-    char* sC = sA;                                 // epilogue staging tile (overlays the ring)
-
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    if ((a.tune >> 18) & 1) return;            // ablation: empty kernel
-
-    // Consecutive remapped ids share an XCD (and its 4 MB L2).  Pixel tiles vary fastest so that an XCD sees few
-    // channel tiles: one 128-row slab of 3x3 weights is 9 x heavier than one 128-pixel slab of activations, and
-    // the full weight tensor of the deep layers (4.7-18 MB) does not fit one L2.
-    const int HWg = a.Hg * a.Wg;
-    const int Ntot = a.B * HWg;
-    const int tiles_n = (Ntot + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (bid / tiles_n) * BM;
-    const int n0 = (bid % tiles_n) * BN;
-
-    if (tid < BN) {
-        const int n = n0 + tid;
-        if (n < Ntot) {
-            const int b = n / HWg;
-            const int r = n - b * HWg;
-            const int yo = r / a.Wg;
-            const int xo = r - yo * a.Wg;
-            const int yi = yo * a.isy, xi = xo * a.isx;
-            t_in[tid] = ((b * a.Hi + yi) * a.Wi + xi) * a.ldx;
-            t_y[tid] = (short)yi;
-            t_x[tid] = (short)xi;
-            const int py = yo * a.osy + a.ooy, px = xo * a.osx + a.oox;
-            t_out[tid] = ((b * a.Ho + py) * a.Wo + px) * a.ldy;
-            t_res[tid] = ((b * a.Ho + py) * a.Wo + px) * a.ldr;
-        } else {
-            t_in[tid] = 0; t_y[tid] = -20000; t_x[tid] = -20000; t_out[tid] = -1; t_res[tid] = 0;
-        }
-    }
-    if (tid >= 256 - 32 && tid < 256 - 32 + a.ntaps) {   // tap tables in LDS: no vector-memory loads inside the K loop
-        const int q = tid - (256 - 32);
-        const int dy = a.tdy[q], dx = a.tdx[q];
-        tap_dy[q] = dy; tap_dx[q] = dx;
-        tap_x[q] = (dy * a.Wi + dx) * a.ldx;
-        tap_w[q] = a.twt[q] * a.Cout * a.Cin;
-    }
-    __syncthreads();
-    if ((a.tune >> 19) & 1) return;            // ablation: tables only
-
-    f32x4_t acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    const T* __restrict__ xg = (const T*)a.x;
-    const T* __restrict__ wg = (const T*)a.w;
-    // bits 16.. of `tune` are ablation switches for kernel analysis (tools/gpu_probe.py ablate): never set by the plan
-    const bool abl_nostore = (a.tune >> 16) & 1, abl_noloop = (a.tune >> 17) & 1;
-    const int S = abl_noloop ? 0 : (a.Cin / BK) * a.ntaps;
-    const int frow = lane & 15, fslot = lane >> 4;
-
-    auto compute = [&](const char* pa, const char* pb) {
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            uint4 fa[MI], fb[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                fa[mi] = *(const uint4*)(pa + lds_off<BKB>(wm * WTM + mi * 16 + frow, kk * 4 + fslot));
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                fb[ni] = *(const uint4*)(pb + lds_off<BKB>(wn * WTN + ni * 16 + frow, kk * 4 + fslot));
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], fa[mi], fb[ni]);
-        }
-    };
-
-    {
-        // ---- LDS-DMA pipeline: global_load_lds (16 B per lane, 1 KiB per wave instruction) straight
-        // into a 3-deep ring of swizzled tiles; step s+2 is in flight while step s feeds the MFMAs.
-        // A wave instruction fills RPI consecutive tile rows; lane -> (row, physical slot); the XOR
-        // swizzle is applied on the SOURCE side (the LDS image of an LDS-DMA is lane-linear).
-        constexpr int SPR = BKB / 16;                  // 16-byte slots per tile row
-        constexpr int RPI = 64 / SPR;                  // tile rows per wave instruction
-        constexpr int NI_A = BM * BKB / 1024, NI_B = BN * BKB / 1024;
-        constexpr int NIA_W = (NI_A + 3) / 4, NIB_W = (NI_B + 3) / 4;
-        constexpr int NPW = NIA_W + NIB_W;             // DMA instructions per wave per step (uniform count)
-        const int wv = __builtin_amdgcn_readfirstlane(wid);
-        const int lrow = lane / SPR, pslot = lane % SPR;
-        int a_off[NIA_W]; bool a_ok[NIA_W];
-#pragma unroll
-        for (int j = 0; j < NIA_W; ++j) {
-            const int inst = j * 4 + wv;
-            const int row = inst * RPI + lrow;
-            const int co = m0 + row;
-            const int ls = (lds_off<BKB>(row, pslot) - row * BKB) >> 4;    // logical slot stored at this physical slot
-            a_ok[j] = (inst < NI_A) && (co < a.Cout);
-            a_off[j] = co * a.Cin + ls * EPV;
-        }
-        int b_off[NIB_W]; unsigned b_mask[NIB_W];
-#pragma unroll
-        for (int j = 0; j < NIB_W; ++j) {
-            const int inst = j * 4 + wv;
-            const int row = inst * RPI + lrow;
-            const int ls = (lds_off<BKB>(row, pslot) - row * BKB) >> 4;
-            const bool live = (NI_B % 4 == 0) || inst < NI_B;
-            b_off[j] = live ? t_in[row] + ls * EPV : 0;
-            const int y0 = live ? t_y[row] : -20000, x0 = live ? t_x[row] : -20000;
-            unsigned m = 0;
-            for (int q = 0; q < a.ntaps; ++q) {
-                const int yi = y0 + tap_dy[q], xi = x0 + tap_dx[q];
-                if (((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi)) m |= 1u << q;
-            }
-            b_mask[j] = m;
-        }
-        const T* zero = (const T*)dyk_zero_page;
-        auto stage = [&](int buf, int c0, int t) {
-            const int toff = tap_x[t] + c0;
-            const long wbase = (long)tap_w[t] + c0;
-            char* da = sA + buf * A_BYTES;
-            char* db = sB + buf * B_BYTES;
-#pragma unroll
-            for (int j = 0; j < NIA_W; ++j) {
-                const int inst = j * 4 + wv;
-                if (NI_A % 4 == 0 || inst < NI_A) {
-                    const T* src = a_ok[j] ? wg + wbase + a_off[j] : zero;
-                    glds16(src, lds_addr_of(da + inst * 1024));
-                } else {
-                    // keep the per-wave DMA count uniform so that one counted vmcnt fits all waves
-                    glds16(zero, lds_addr_of(sink));
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < NIB_W; ++j) {
-                const int inst = j * 4 + wv;
-                const T* src = ((b_mask[j] >> t) & 1u) ? xg + (long)b_off[j] + toff : zero;
-                glds16(src, lds_addr_of((NI_B % 4 == 0 || inst < NI_B) ? db + inst * 1024 : sink));
-            }
-        };
-        // staging iterator (runs two steps ahead of the compute iterator)
-        int sc0 = 0, st = 0;
-        auto stage_next = [&](int buf) {
-            stage(buf, sc0, st);
-            if (++st == a.ntaps) { st = 0; sc0 += BK; }
-        };
-        if constexpr (PIPE >= 3) {
-            // N-stage ring: AHEAD = N-1 steps are in flight while one is computed.  Workgroups that sit alone on a
-            // CU (deep layers: few, long-K tiles) need the depth: with two stages a K step costs one L2 round trip.
-            constexpr int AHEAD = PIPE - 1;
-            constexpr int KEEP = (AHEAD - 1) * NPW;        // DMA instructions that may still be in flight per wave
-            static_assert(KEEP <= 63, "vmcnt range");
-#pragma unroll
-            for (int i = 0; i < AHEAD; ++i)
-                if (S > i) stage_next(i);
-            if (S >= AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            int cur = 0, nxt = AHEAD;
-            for (int s = 0; s < S; ++s) {
-                const bool more = (s + AHEAD < S);
-                if (more) stage_next(nxt);
-                compute(sA + cur * A_BYTES, sB + cur * B_BYTES);
-                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                cur = (cur == PIPE - 1) ? 0 : cur + 1;
-                nxt = (nxt == PIPE - 1) ? 0 : nxt + 1;
-            }
-        } else {
-            // 2-stage ring for short K loops (1x1 convs, small Cin): half the LDS, 2-3x the resident
-            // workgroups per CU -- latency is hidden across workgroups instead of inside one
-            if (S > 0) stage_next(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            for (int s = 0; s < S; ++s) {
-                if (s + 1 < S) stage_next((s + 1) & 1);
-                compute(sA + (s & 1) * A_BYTES, sB + (s & 1) * B_BYTES);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-        }
-    }
-
-    // ------------------------------------------------------------------ epilogue
-    // (both pipelines leave the loop behind a workgroup barrier: the ring is free to be overwritten)
+    const bool abl_nostore = (a.tune >> 16) & 1;
     if ((a.tune >> 20) & 1) {                  // ablation: no epilogue (keep the accumulators alive)
         float sum = 0.f;
 #pragma unroll
@@ -534,6 +329,476 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     }
 }
 
+// PIPE: LDS-DMA ring stages (2 | 3)
+template <typename T, int BM, int BN, int BKB, int PIPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_kernel(const ConvArgs args) {
+    const DykConvDesc& a = args.d;
+    constexpr int TABLE_BYTES = table_bytes<BN>();
+    constexpr int EPV = 16 / (int)sizeof(T);
+    constexpr int BK = BKB / (int)sizeof(T);
+    constexpr int WM = WaveGrid<BM, BN>::WM;  // waves along M
+    constexpr int WN = WaveGrid<BM, BN>::WN;
+    constexpr int WTM = BM / WM;
+    constexpr int WTN = BN / WN;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    constexpr int KK = BKB / 64;
+    constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
+    constexpr int NSTAGE = PIPE;
+
+    // LDS: [pixel / tap tables | dummy-DMA sink | stats scratch] then the operand ring, which the
+    // epilogue re-uses as the output staging tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* t_in = (int*)smem;                   // [BN] input base offset
+    int* t_out = t_in + BN;                   // [BN] output offset or -1
+    int* t_res = t_out + BN;                  // [BN] residual offset
+    short* t_y = (short*)(t_res + BN);        // [BN] input row of tap (0,0)
+    short* t_x = t_y + BN;                    // [BN]
+    char* sink = (char*)(t_x + BN);           // [1024] target of dummy LDS-DMA writes (DMA path only)
+    int* tap_x = (int*)(sink + 1024);         // [32] activation element offset of a tap: (dy*Wi + dx)*ldx
+    int* tap_w = tap_x + 32;                  // [32] weight element offset of a tap: twt*Cout*Cin
+    int* tap_dy = tap_w + 32;                 // [32]
+    int* tap_dx = tap_dy + 32;                // [32]
+    float* s_stat = (float*)(tap_dx + 32);    // [2][BM] per-workgroup channel sums (STATS epilogue)
+    char* sA = smem + TABLE_BYTES;                 // [NSTAGE][A_BYTES]
+    char* sB = sA + NSTAGE * A_BYTES;              // [NSTAGE][B_BYTES]
+    char* sC = sA;                                 // epilogue staging tile (overlays the ring)
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    if ((a.tune >> 18) & 1) return;            // ablation: empty kernel
+
+    // Consecutive remapped ids share an XCD (and its 4 MB L2).  Pixel tiles vary fastest so that an XCD sees few
+    // channel tiles: one 128-row slab of 3x3 weights is 9 x heavier than one 128-pixel slab of activations, and
+    // the full weight tensor of the deep layers (4.7-18 MB) does not fit one L2.
+    const int HWg = a.Hg * a.Wg;
+    const int Ntot = a.B * HWg;
+    const int tiles_n = (Ntot + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (bid / tiles_n) * BM;
+    const int n0 = (bid % tiles_n) * BN;
+
+    if (tid < BN) {
+        const int n = n0 + tid;
+        if (n < Ntot) {
+            const int b = n / HWg;
+            const int r = n - b * HWg;
+            const int yo = r / a.Wg;
+            const int xo = r - yo * a.Wg;
+            const int yi = yo * a.isy, xi = xo * a.isx;
+            t_in[tid] = ((b * a.Hi + yi) * a.Wi + xi) * a.ldx;
+            t_y[tid] = (short)yi;
+            t_x[tid] = (short)xi;
+            const int py = yo * a.osy + a.ooy, px = xo * a.osx + a.oox;
+            t_out[tid] = ((b * a.Ho + py) * a.Wo + px) * a.ldy;
+            t_res[tid] = ((b * a.Ho + py) * a.Wo + px) * a.ldr;
+        } else {
+            t_in[tid] = 0; t_y[tid] = -20000; t_x[tid] = -20000; t_out[tid] = -1; t_res[tid] = 0;
+        }
+    }
+    if (tid >= 256 - 32 && tid < 256 - 32 + a.ntaps) {   // tap tables in LDS: no vector-memory loads inside the K loop
+        const int q = tid - (256 - 32);
+        const int dy = a.tdy[q], dx = a.tdx[q];
+        tap_dy[q] = dy; tap_dx[q] = dx;
+        tap_x[q] = (dy * a.Wi + dx) * a.ldx;
+        tap_w[q] = a.twt[q] * a.Cout * a.Cin;
+    }
+    __syncthreads();
+    if ((a.tune >> 19) & 1) return;            // ablation: tables only
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const T* __restrict__ xg = (const T*)a.x;
+    const T* __restrict__ wg = (const T*)a.w;
+    // bits 16.. of `tune` are ablation switches for kernel analysis (tools/gpu_probe.py ablate): never set by the plan
+    const bool abl_nostore = (a.tune >> 16) & 1, abl_noloop = (a.tune >> 17) & 1;
+    const int S = abl_noloop ? 0 : (a.Cin / BK) * a.ntaps;
+    const int frow = lane & 15, fslot = lane >> 4;
+
+    // `mid` (the DMA issue of a later step) runs between the first fragment reads and their MFMAs: the ~100 cycles per
+    // global_load_lds instruction are then spent while the LDS reads are in flight / the matrix pipe drains, instead
+    // of in front of the step with nothing else going on in the wave.
+    auto compute = [&](const char* pa, const char* pb, auto&& mid) {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            uint4 fa[MI], fb[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                fa[mi] = *(const uint4*)(pa + lds_off<BKB>(wm * WTM + mi * 16 + frow, kk * 4 + fslot));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                fb[ni] = *(const uint4*)(pb + lds_off<BKB>(wn * WTN + ni * 16 + frow, kk * 4 + fslot));
+            if (kk == 0) mid();
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], fa[mi], fb[ni]);
+        }
+    };
+
+    {
+        // ---- LDS-DMA pipeline: global_load_lds (16 B per lane, 1 KiB per wave instruction) straight
+        // into a 3-deep ring of swizzled tiles; step s+2 is in flight while step s feeds the MFMAs.
+        // A wave instruction fills RPI consecutive tile rows; lane -> (row, physical slot); the XOR
+        // swizzle is applied on the SOURCE side (the LDS image of an LDS-DMA is lane-linear).
+        constexpr int SPR = BKB / 16;                  // 16-byte slots per tile row
+        constexpr int RPI = 64 / SPR;                  // tile rows per wave instruction
+        constexpr int NI_A = BM * BKB / 1024, NI_B = BN * BKB / 1024;
+        constexpr int NIA_W = (NI_A + 3) / 4, NIB_W = (NI_B + 3) / 4;
+        constexpr int NPW = NIA_W + NIB_W;             // DMA instructions per wave per step (uniform count)
+        const int wv = __builtin_amdgcn_readfirstlane(wid);
+        const int lrow = lane / SPR, pslot = lane % SPR;
+        int a_off[NIA_W]; bool a_ok[NIA_W];
+#pragma unroll
+        for (int j = 0; j < NIA_W; ++j) {
+            const int inst = j * 4 + wv;
+            const int row = inst * RPI + lrow;
+            const int co = m0 + row;
+            const int ls = (lds_off<BKB>(row, pslot) - row * BKB) >> 4;    // logical slot stored at this physical slot
+            a_ok[j] = (inst < NI_A) && (co < a.Cout);
+            a_off[j] = co * a.Cin + ls * EPV;
+        }
+        int b_off[NIB_W]; unsigned b_mask[NIB_W];
+#pragma unroll
+        for (int j = 0; j < NIB_W; ++j) {
+            const int inst = j * 4 + wv;
+            const int row = inst * RPI + lrow;
+            const int ls = (lds_off<BKB>(row, pslot) - row * BKB) >> 4;
+            const bool live = (NI_B % 4 == 0) || inst < NI_B;
+            b_off[j] = live ? t_in[row] + ls * EPV : 0;
+            const int y0 = live ? t_y[row] : -20000, x0 = live ? t_x[row] : -20000;
+            unsigned m = 0;
+            for (int q = 0; q < a.ntaps; ++q) {
+                const int yi = y0 + tap_dy[q], xi = x0 + tap_dx[q];
+                if (((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi)) m |= 1u << q;
+            }
+            b_mask[j] = m;
+        }
+        const T* zero = (const T*)dyk_zero_page;
+        auto stage = [&](int buf, int c0, int t) {
+            const int toff = tap_x[t] + c0;
+            const long wbase = (long)tap_w[t] + c0;
+            char* da = sA + buf * A_BYTES;
+            char* db = sB + buf * B_BYTES;
+#pragma unroll
+            for (int j = 0; j < NIA_W; ++j) {
+                const int inst = j * 4 + wv;
+                if (NI_A % 4 == 0 || inst < NI_A) {
+                    const T* src = a_ok[j] ? wg + wbase + a_off[j] : zero;
+                    glds16(src, lds_addr_of(da + inst * 1024));
+                } else {
+                    // keep the per-wave DMA count uniform so that one counted vmcnt fits all waves
+                    glds16(zero, lds_addr_of(sink));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NIB_W; ++j) {
+                const int inst = j * 4 + wv;
+                const T* src = ((b_mask[j] >> t) & 1u) ? xg + (long)b_off[j] + toff : zero;
+                glds16(src, lds_addr_of((NI_B % 4 == 0 || inst < NI_B) ? db + inst * 1024 : sink));
+            }
+        };
+        // staging iterator (runs two steps ahead of the compute iterator)
+        int sc0 = 0, st = 0;
+        auto stage_next = [&](int buf) {
+            stage(buf, sc0, st);
+            if (++st == a.ntaps) { st = 0; sc0 += BK; }
+        };
+        if constexpr (PIPE >= 3) {
+            // N-stage ring: AHEAD = N-1 steps are in flight while one is computed.  Workgroups that sit alone on a
+            // CU (deep layers: few, long-K tiles) need the depth: with two stages a K step costs one L2 round trip.
+            constexpr int AHEAD = PIPE - 1;
+            constexpr int KEEP = (AHEAD - 1) * NPW;        // DMA instructions that may still be in flight per wave
+            static_assert(KEEP <= 63, "vmcnt range");
+#pragma unroll
+            for (int i = 0; i < AHEAD; ++i)
+                if (S > i) stage_next(i);
+            if (S >= AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int cur = 0, nxt = AHEAD;
+            for (int s = 0; s < S; ++s) {
+                const bool more = (s + AHEAD < S);
+                compute(sA + cur * A_BYTES, sB + cur * B_BYTES, [&]() { if (more) stage_next(nxt); });
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                cur = (cur == PIPE - 1) ? 0 : cur + 1;
+                nxt = (nxt == PIPE - 1) ? 0 : nxt + 1;
+            }
+        } else {
+            // 2-stage ring for short K loops (1x1 convs, small Cin): half the LDS, 2-3x the resident
+            // workgroups per CU -- latency is hidden across workgroups instead of inside one
+            if (S > 0) stage_next(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int s = 0; s < S; ++s) {
+                compute(sA + (s & 1) * A_BYTES, sB + (s & 1) * B_BYTES, [&]() { if (s + 1 < S) stage_next((s + 1) & 1); });
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    conv_epilogue<T, BM, BN>(a, acc, sC, s_stat, t_out, t_res, m0);
+}
+
+// ======================================================================================
+// 3x3 stride-1 convolution with a HALO tile.  The generic kernel above re-stages the activation tile for each of the
+// nine taps, which makes L2->LDS bytes (64 flop per byte for a 128x128 tile) its limiter.  Here a workgroup owns a
+// TH x 20 pixel patch of one image (all feature maps of this path are multiples of 20 wide), stages the patch with a
+// one-pixel halo ONCE per 32/64-channel chunk (double buffered, loaded piecewise during the nine tap steps of the
+// previous chunk) and reads the nine taps as row-shifted views of it; only the weight tiles stream per step
+// (3-stage ring).  Bytes per step drop from (BM + BN) to (BM + 1.4 BN / 9) rows.
+// Same descriptor, same epilogue; requires ntaps == 9 with tap offsets in [-1,1]^2, unit strides, bf16.
+template <int TH> struct HaloGeom {
+    static constexpr int TW = 20, HW = TW + 2, BN = TH * TW, HR = (TH + 2) * HW;
+};
+template <int BM, int TH> constexpr int halo_table_bytes() {
+    return HaloGeom<TH>::BN * 8 + 1024 + 2 * 32 * 4 + 2 * 128 * 4;
+}
+
+template <typename T, int BM, int TH, int BKB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_halo_kernel(const ConvArgs args) {
+    const DykConvDesc& a = args.d;
+    using G = HaloGeom<TH>;
+    constexpr int TW = G::TW, HW = G::HW, BN = G::BN, HR = G::HR;
+    constexpr int EPV = 16 / (int)sizeof(T);
+    constexpr int BK = BKB / (int)sizeof(T);
+    constexpr int WM = WaveGrid<BM, BN>::WM, WN = WaveGrid<BM, BN>::WN;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    constexpr int KK = BKB / 64;
+    constexpr int A_BYTES = BM * BKB;
+    constexpr int SPR = BKB / 16, RPI = 64 / SPR;          // slots per row, rows per DMA instruction
+    constexpr int NB = (HR + RPI - 1) / RPI;               // DMA instructions per halo tile
+    constexpr int HB_BYTES = NB * 1024;
+    constexpr int NA = 3;                                  // weight ring stages
+    constexpr int NI_A = BM * BKB / 1024;
+    constexpr int NIA_W = (NI_A + 3) / 4;
+    constexpr int NPW = NIA_W + 1;                         // DMA instructions per wave per step: weights + one halo piece
+    static_assert(NB <= 32, "halo tile must be loadable in 8 steps x 4 waves");
+    constexpr int TABLE_BYTES = halo_table_bytes<BM, TH>();
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* t_out = (int*)smem;                  // [BN]
+    int* t_res = t_out + BN;                  // [BN]
+    char* sink = (char*)(t_res + BN);         // [1024]
+    int* tap_w = (int*)(sink + 1024);         // [32] weight element offset of a tap
+    int* tap_h = tap_w + 32;                  // [32] halo-row offset of a tap: dy*HW + dx
+    float* s_stat = (float*)(tap_h + 32);     // [2][BM]
+    char* sA = smem + TABLE_BYTES;            // [NA][A_BYTES]
+    char* sH = sA + NA * A_BYTES;             // [2][HB_BYTES]
+    int* t_hsrc = (int*)(sH + 2 * HB_BYTES);  // [NB*64] per (instruction, lane): source element offset or -1 (zero page)
+    char* sC = sA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int tiles_x = a.Wi / TW, tiles_y = a.Hi / TH;
+    const int tiles_n = a.B * tiles_y * tiles_x;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (bid / tiles_n) * BM;
+    int nt = bid % tiles_n;
+    const int bimg = nt / (tiles_y * tiles_x);
+    nt -= bimg * (tiles_y * tiles_x);
+    const int ty0 = (nt / tiles_x) * TH, tx0 = (nt % tiles_x) * TW;
+
+    if (tid < BN) {
+        const int py = tid / TW, px = tid - py * TW;
+        const int pix = (bimg * a.Ho + ty0 + py) * a.Wo + tx0 + px;
+        t_out[tid] = pix * a.ldy;
+        t_res[tid] = pix * a.ldr;
+    }
+    if (tid >= 256 - 32 && tid < 256 - 32 + a.ntaps) {
+        const int q = tid - (256 - 32);
+        tap_h[q] = a.tdy[q] * HW + a.tdx[q];
+        tap_w[q] = a.twt[q] * a.Cout * a.Cin;
+    }
+    for (int e = tid; e < NB * 64; e += 256) {
+        const int q = e >> 6, l = e & 63;
+        const int row = q * RPI + l / SPR, pslot = l % SPR;
+        int src = -1;
+        if (row < HR) {
+            const int hy = row / HW, hx = row - hy * HW;
+            const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+            if ((unsigned)y < (unsigned)a.Hi && (unsigned)x < (unsigned)a.Wi) {
+                const int ls = (lds_off<BKB>(row, pslot) - row * BKB) >> 4;
+                src = ((bimg * a.Hi + y) * a.Wi + x) * a.ldx + ls * EPV;
+            }
+        }
+        t_hsrc[e] = src;
+    }
+    __syncthreads();
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const T* __restrict__ xg = (const T*)a.x;
+    const T* __restrict__ wg = (const T*)a.w;
+    const T* zero = (const T*)dyk_zero_page;
+    const int nchunk = a.Cin / BK;
+    const int S = nchunk * 9;
+    const int frow = lane & 15, fslot = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(wid);
+    const int lrow = lane / SPR, pslot = lane % SPR;
+
+    int hrow[NI];                              // halo row of this lane's pixel of fragment ni, tap (0,0)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int p = wn * WTN + ni * 16 + frow;
+        const int py = p / TW;
+        hrow[ni] = (py + 1) * HW + (p - py * TW) + 1;
+    }
+    int a_off[NIA_W]; bool a_ok[NIA_W];
+#pragma unroll
+    for (int j = 0; j < NIA_W; ++j) {
+        const int inst = j * 4 + wv;
+        const int row = inst * RPI + lrow;
+        const int co = m0 + row;
+        const int ls = (lds_off<BKB>(row, pslot) - row * BKB) >> 4;
+        a_ok[j] = (inst < NI_A) && (co < a.Cout);
+        a_off[j] = co * a.Cin + ls * EPV;
+    }
+    auto stage_a = [&](int buf, int c0, int t) {
+        const long wbase = (long)tap_w[t] + c0;
+        char* da = sA + buf * A_BYTES;
+#pragma unroll
+        for (int j = 0; j < NIA_W; ++j) {
+            const int inst = j * 4 + wv;
+            if (NI_A % 4 == 0 || inst < NI_A) {
+                const T* src = a_ok[j] ? wg + wbase + a_off[j] : zero;
+                glds16(src, lds_addr_of(da + inst * 1024));
+            } else {
+                glds16(zero, lds_addr_of(sink));
+            }
+        }
+    };
+    // one halo DMA instruction: piece q of the tile of channel chunk c0 into buffer hb (q >= NB: dummy into the sink)
+    auto stage_h = [&](int hb, int c0, int q) {
+        if (q < NB) {
+            const int so = t_hsrc[q * 64 + lane];
+            const T* src = so >= 0 ? xg + (long)so + c0 : zero;
+            glds16(src, lds_addr_of(sH + hb * HB_BYTES + q * 1024));
+        } else {
+            glds16(zero, lds_addr_of(sink));
+        }
+    };
+    auto compute = [&](const char* pa, const char* ph, int toff) {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            uint4 fa[MI], fb[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                fa[mi] = *(const uint4*)(pa + lds_off<BKB>(wm * WTM + mi * 16 + frow, kk * 4 + fslot));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                fb[ni] = *(const uint4*)(ph + lds_off<BKB>(hrow[ni] + toff, kk * 4 + fslot));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], fa[mi], fb[ni]);
+        }
+    };
+
+    // prologue: whole halo tile of chunk 0, weight tiles of steps 0 and 1
+    for (int q = wv; q < ((NB + 3) / 4) * 4; q += 4) stage_h(0, 0, q);
+    int sc0 = 0, st = 0;                       // weight staging iterator (two steps ahead)
+    auto stage_a_next = [&](int buf) {
+        stage_a(buf, sc0, st);
+        if (++st == 9) { st = 0; sc0 += BK; }
+    };
+    if (S > 0) stage_a_next(0);
+    if (S > 1) stage_a_next(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, nxt = 2, c = 0, t = 0;
+    for (int s = 0; s < S; ++s) {
+        const bool more = (s + 2 < S);
+        if (more) {
+            stage_a_next(nxt);
+            // halo of the next chunk: one piece per wave per step during tap steps 0..7 of this chunk
+            const bool piece = (c + 1 < nchunk) && t < 8;
+            stage_h((c + 1) & 1, (c + 1) * BK, piece ? t * 4 + wv : NB);
+        }
+        compute(sA + cur * A_BYTES, sH + (c & 1) * HB_BYTES, tap_h[t]);
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = (cur == NA - 1) ? 0 : cur + 1;
+        nxt = (nxt == NA - 1) ? 0 : nxt + 1;
+        if (++t == 9) { t = 0; ++c; }
+    }
+    conv_epilogue<T, BM, BN>(a, acc, sC, s_stat, t_out, t_res, m0);
+}
+
+inline bool conv_halo_eligible(const DykConvDesc* d, int TH) {
+    if (d->dtype != DYK_BF16 || d->ntaps != 9) return false;
+    if (d->isy != 1 || d->isx != 1 || d->osy != 1 || d->osx != 1 || d->ooy != 0 || d->oox != 0) return false;
+    if (d->Hg != d->Hi || d->Wg != d->Wi || d->Ho != d->Hi || d->Wo != d->Wi) return false;
+    if (d->Wi % 20 || d->Hi % TH) return false;
+    for (int q = 0; q < 9; ++q)
+        if (d->tdy[q] < -1 || d->tdy[q] > 1 || d->tdx[q] < -1 || d->tdx[q] > 1) return false;
+    return true;
+}
+
+template <typename T, int BM, int TH, int BKB>
+int launch_conv_halo(const DykConvDesc* d, hipStream_t stream) {
+    using G = HaloGeom<TH>;
+    constexpr int BN = G::BN;
+    constexpr int RPI = 64 / (BKB / 16);
+    constexpr int NB = (G::HR + RPI - 1) / RPI;
+    constexpr size_t ring = 3 * (size_t)BM * BKB + 2 * (size_t)NB * 1024;
+    constexpr size_t hsrc = (size_t)NB * 64 * 4;
+    const bool of32 = (d->flags & DYK_EPI_OUT_F32) != 0;
+    const size_t stage_c = (size_t)BN * (BM * (of32 ? 4 : 2) + 16);
+    const size_t body = ring + hsrc > stage_c ? ring + hsrc : stage_c;
+    const size_t lds = halo_table_bytes<BM, TH>() + body;
+    static bool attr_set = false;
+    auto kfn = conv_halo_kernel<T, BM, TH, BKB>;
+    if (!attr_set) {
+        constexpr size_t sc_max = (size_t)BN * (BM * 4 + 16);
+        constexpr size_t lds_max = halo_table_bytes<BM, TH>() + (ring + hsrc > sc_max ? ring + hsrc : sc_max);
+        DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        attr_set = true;
+    }
+    const int tiles_n = d->B * (d->Hi / TH) * (d->Wi / 20);
+    const int tiles_m = dyk_div_up(d->Cout, BM);
+    ConvArgs args;
+    args.d = *d;
+    const int eso = of32 ? 4 : 2;
+    bool vec = ((size_t)d->ldy * eso) % 16 == 0 && ((uintptr_t)d->y % 16) == 0;
+    if ((d->flags & DYK_EPI_RESIDUAL) && (((size_t)d->ldr * sizeof(T)) % 16 != 0 || ((uintptr_t)d->res % 16) != 0)) vec = false;
+    if (vec) args.d.flags |= EPI_INTERNAL_VEC;
+    else args.d.flags &= ~EPI_INTERNAL_VEC;
+    hipLaunchKernelGGL(kfn, dim3(tiles_n * tiles_m), dim3(256), lds, stream, args);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+// pixel-tile codes 3 / 4 of the tune word: halo kernel with 4x20 / 8x20 pixel patches
+template <typename T, int TH>
+int dispatch_conv_halo(const DykConvDesc* d, hipStream_t stream) {
+    if (!conv_halo_eligible(d, TH)) return DYK_ERR_UNSUPPORTED;
+    const int row_bytes = d->Cin * (int)sizeof(T);
+    if (row_bytes % 64) return DYK_ERR_ARG;
+    const bool k128 = (d->tune & 0xff) == 128 && row_bytes % 128 == 0;
+    int bm = d->Cout > 64 ? 128 : 64;
+    const int bm_code = (d->tune >> 24) & 0xf;
+    if (bm_code == 2) bm = 64;
+    if (bm_code == 3) bm = 128;
+    if (k128) return bm == 128 ? launch_conv_halo<T, 128, TH, 128>(d, stream) : launch_conv_halo<T, 64, TH, 128>(d, stream);
+    return bm == 128 ? launch_conv_halo<T, 128, TH, 64>(d, stream) : launch_conv_halo<T, 64, TH, 64>(d, stream);
+}
 
 template <typename T, int BM, int BN, int BKB, int PIPE>
 int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {

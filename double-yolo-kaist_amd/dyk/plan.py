@@ -847,18 +847,23 @@ _TUNE_CACHE = {}     # process-wide: the same problem always runs the same tile 
                      # results across plans / model instances within a process)
 def _conv_candidates(d):
     """tile configurations of dyk_conv_igemm for one problem: K-step bytes | ring stages << 8 | pixel tile << 12
-    (0 = 128, 1 = 80, 2 = 160 pixels; bf16 only) | channel tile << 24 (0 = by Cout, 2 = 64, 1 = 32)"""
+    (0 = 128, 1 = 80, 2 = 160 pixels, 3 / 4 = halo kernel 4x20 / 8x20; bf16 only) | channel tile << 24 (0 = by Cout, 2 = 64, 1 = 32)"""
     es = 2 if d.dtype == L.DYK_BF16 else 4
     bkbs = [64] + ([128] if (d.Cin * es) % 128 == 0 else [])
     tiles = [0, 1, 2] if d.dtype == L.DYK_BF16 else [0]
+    if (d.dtype == L.DYK_BF16 and d.ntaps == 9 and d.isy == 1 and d.osy == 1 and d.Hg == d.Hi and d.Wg == d.Wi
+            and d.Wi % 20 == 0 and d.Hi % 4 == 0):
+        tiles += [3] + ([4] if d.Hi % 8 == 0 else [])       # 3x3 halo kernel, 4x20 / 8x20 pixel patches
     bms = [0] + ([2] if d.Cout > 64 else ([1] if d.Cout > 32 else []))
     out = []
     for bkb in bkbs:
         for pipe in (2, 3, 4, 6):
             for t in tiles:
                 for bm in bms:
-                    if t == 1 and bm == 1:
-                        continue                      # 80-pixel tile needs >= 64 channel rows
+                    if t in (1, 3, 4) and bm == 1:
+                        continue                      # 80-pixel / halo tiles need >= 64 channel rows
+                    if t in (3, 4) and pipe != 2:
+                        continue                      # the halo kernel has a fixed pipeline
                     out.append(bkb | (pipe << 8) | (t << 12) | (bm << 24))
     return out
 
