@@ -104,6 +104,94 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwDesc d, int CVB) {
     }
 }
 
+// bn_finalize + bn_act_fwd in one launch (the 7 us finalize launch sat on the critical chain of the forward pass):
+// every workgroup folds the statistics replicas of its own <= 256 channels (8 independent fp64 loads in flight per
+// thread), derives scale / shift into LDS, and the workgroups of grid row 0 also publish scale / shift / mean / rstd
+// for the backward pass and update the running statistics.  The replicas are NOT re-armed here (other workgroups
+// may still be reading them): the caller zeroes the statistics arena once per forward pass.
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bn_fused_fwd_kernel(DykBnFinalizeDesc f, DykEwDesc d, int CVB) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    __shared__ float s_aff[2][256];
+    const int PY = 256 / CVB;
+    const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
+    const int cv = blockIdx.x * CVB + tx;
+    {
+        const int c_base = blockIdx.x * CVB * EPV;
+        const int nch = min(CVB * EPV, d.C - c_base);
+        const int slots = f.slots > 0 ? f.slots : 1;
+        const size_t rs = (size_t)2 * f.C;
+        for (int cl = threadIdx.x; cl < nch; cl += 256) {
+            const int c = c_base + cl;
+            double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+            int r = 0;
+            for (; r + 4 <= slots; r += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a1[u] += f.stats[(size_t)(r + u) * rs + c]; a2[u] += f.stats[(size_t)(r + u) * rs + f.C + c]; }
+            }
+            for (; r < slots; ++r) { a1[0] += f.stats[(size_t)r * rs + c]; a2[0] += f.stats[(size_t)r * rs + f.C + c]; }
+            const double n = (double)f.count;
+            const double mean = ((a1[0] + a1[1]) + (a1[2] + a1[3])) / n;
+            double var = ((a2[0] + a2[1]) + (a2[2] + a2[3])) / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+            const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+            const float sc = g * rstd, sh = b - (float)mean * sc;
+            s_aff[0][cl] = sc;
+            s_aff[1][cl] = sh;
+            if (blockIdx.y == 0) {
+                f.scale[c] = sc;
+                f.shift[c] = sh;
+                if (f.save_mean) f.save_mean[c] = (float)mean;
+                if (f.save_rstd) f.save_rstd[c] = rstd;
+                if (f.running_mean) {
+                    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+                    f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+                    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (cv * EPV >= d.C) return;
+    const int c = cv * EPV;
+    float sc[EPV], sh[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) { sc[j] = s_aff[0][tx * EPV + j]; sh[j] = s_aff[1][tx * EPV + j]; }
+    const T* __restrict__ a = (const T*)d.a;
+    const T* __restrict__ r = (const T*)d.b;
+    T* __restrict__ o = (T*)d.out;
+    constexpr int U = 4;
+    const long pstep = (long)gridDim.y * PY;
+    for (long p0 = (long)blockIdx.y * PY + ty; p0 < d.npix; p0 += pstep * U) {
+        uint4 vx[U], vr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long p = p0 + u * pstep;
+            if (p < d.npix) {
+                vx[u] = *(const uint4*)(a + p * d.lda + c);
+                if (r) vr[u] = *(const uint4*)(r + p * d.ldb + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long p = p0 + u * pstep;
+            if (p >= d.npix) break;
+            float x[EPV], y[EPV];
+            vec_unpack<T>(vx[u], x);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) y[j] = act_fwd_c<ACT>(x[j] * sc[j] + sh[j]);
+            if (r) {
+                float rr[EPV];
+                vec_unpack<T>(vr[u], rr);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) y[j] += rr[j];
+            }
+            *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(y);
+        }
+    }
+}
+
 // block = (CVB channel vectors) x (PY pixel lanes); grid.x over channel-vector groups, grid.y over pixels
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(DykEwDesc d, int CVB) {
@@ -337,6 +425,19 @@ extern "C" int dyk_bn_act_fwd(const DykEwDesc* d, void* stream) {
     int gx, gy;
     const int CVB = ew_grid2d(d->C / epv, d->npix, &gx, &gy);
     DYK_BN_LAUNCH(bn_act_fwd_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB)
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_bn_finalize_act_fwd(const DykBnFinalizeDesc* f, const DykEwDesc* d, void* stream) {
+    if (!f || !f->stats || !f->scale || !f->shift || f->C <= 0 || f->count <= 0) return DYK_ERR_ARG;
+    const int rc = ew_check(d, false);
+    if (rc) return rc;
+    if (d->C != f->C) return DYK_ERR_ARG;
+    const int epv = d->dtype == DYK_BF16 ? 8 : 4;
+    int gx, gy;
+    const int CVB = ew_grid2d(d->C / epv, d->npix, &gx, &gy);
+    DYK_BN_LAUNCH(bn_fused_fwd_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *f, *d, CVB)
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

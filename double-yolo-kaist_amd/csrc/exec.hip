@@ -205,6 +205,8 @@ extern "C" int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream,
             case DYK_OP_DW_FWD: rc = dyk_dwconv_fwd((const DykDwDesc*)dp, stream); break;
             case DYK_OP_DW_DGRAD: rc = dyk_dwconv_dgrad((const DykDwDesc*)dp, stream); break;
             case DYK_OP_DW_WGRAD: rc = dyk_dwconv_wgrad((const DykDwDesc*)dp, stream); break;
+            case DYK_OP_BN_FWD_FUSED:
+                rc = dyk_bn_finalize_act_fwd((const DykBnFinalizeDesc*)m->p[0], (const DykEwDesc*)m->p[1], stream); break;
             case DYK_OP_CAST_PAD_ROWS:
                 rc = dyk_cast_pad_rows((const float*)m->p[0], m->p[1], m->i[0], m->i[1], m->i[2], m->i[3], stream); break;
             default: rc = DYK_ERR_UNSUPPORTED; break;

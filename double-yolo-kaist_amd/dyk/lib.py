@@ -21,7 +21,7 @@ MAX_TAPS = 25
  OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_SE_POOL, OP_SE_FC_FWD, OP_SE_FC_BWD,
  OP_SE_SCALE, OP_BN_BWD_PARAMS, OP_BN_FOLD, OP_WFUSE_WEIGHTS, OP_WFUSE_BWD_PARAMS, OP_HEAD_PERMUTE_FWD,
  OP_HEAD_PERMUTE_BWD, OP_PATCH_GATHER, OP_MEMSET, OP_YOLO_DECODE, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD,
- OP_CAST_PAD_ROWS) = range(1, 30)
+ OP_CAST_PAD_ROWS, OP_BN_FWD_FUSED) = range(1, 31)
 
 
 class DykLibraryError(RuntimeError):
@@ -146,6 +146,7 @@ SIGNATURES = {
     "dyk_conv_igemm": (_i32, [_P(DykConvDesc), _vp]),
     "dyk_conv_wgrad": (_i32, [_P(DykWgradDesc), _vp]),
     "dyk_bn_finalize": (_i32, [_P(DykBnFinalizeDesc), _vp]),
+    "dyk_bn_finalize_act_fwd": (_i32, [_P(DykBnFinalizeDesc), _P(DykEwDesc), _vp]),
     "dyk_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp]),
     "dyk_bn_act_fwd": (_i32, [_P(DykEwDesc), _vp]),
     "dyk_bn_act_bwd_reduce": (_i32, [_P(DykEwDesc), _vp]),

@@ -119,8 +119,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     code = L.DYK_BF16 if dtype == torch.bfloat16 else L.DYK_F32
     es = 2 if dtype == torch.bfloat16 else 4
     plan = Plan()
-    act_arena, grad_arena, ws = Arena("act"), Arena("grad"), Arena("ws")
-    plan.arenas = {"act": act_arena, "grad": grad_arena, "ws": ws}
+    act_arena, grad_arena, ws, st_arena = Arena("act"), Arena("grad"), Arena("ws"), Arena("stats")
+    plan.arenas = {"act": act_arena, "grad": grad_arena, "ws": ws, "stats": st_arena}
     pending = []        # closures that fill pointers once the arenas exist
     defs = model.module_defs
     mods = model.module_list
@@ -286,14 +286,17 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 z = alloc_out(out_layer, B, Ho, Wo, cout)
                 # replicas of the fp64 statistics accumulators: keep the atomics per address at a few dozen
                 tiles = (B * Ho * Wo + 127) // 128
-                slots = STAT_SLOTS if tiles <= 1024 else min(256, 1 << max(5, (tiles // 32 - 1).bit_length()))
-                stats = new_ws(slots * 2 * cout * 8)
+                # (about 32 workgroups per replica), few enough that the consumer folds them cheaply
+                slots = min(256, max(4, 1 << max(0, (tiles * max(1, (cout + 127) // 128) // 32 - 1).bit_length())))
+                if dw:
+                    slots = max(slots, 32)           # the depthwise kernel spreads up to 4096 workgroups over them
+                stats = st_arena.alloc(slots * 2 * cout * 8)   # fp64 replicas; the whole arena is zeroed at the start of a pass
                 vecs = new_ws(4 * cout * 4)          # scale | shift | mean | rstd
                 d.ldy, d.stats_slots = y_raw.ld, slots
                 if not dw:
                     d.act, d.flags = 0, L.EPI_STATS
                 later(lambda d=d, x_in=x_in, y_raw=y_raw, stats=stats: (
-                    setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", ws.ptr(stats))))
+                    setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", st_arena.ptr(stats))))
                 plan.fwd.append((conv_op, d))
                 f = L.DykBnFinalizeDesc()
                 plan._keep.append(f)
@@ -301,13 +304,18 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 f.running_mean, f.running_var = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
                 f.C, f.count, f.momentum, f.eps, f.slots = cout, B * Ho * Wo, BN_MOMENTUM, BN_EPS, slots
                 later(lambda f=f, stats=stats, vecs=vecs: (
-                    setattr(f, "stats", ws.ptr(stats)), setattr(f, "scale", ws.ptr(vecs)),
+                    setattr(f, "stats", st_arena.ptr(stats)), setattr(f, "scale", ws.ptr(vecs)),
                     setattr(f, "shift", ws.ptr(vecs + 4 * cout)), setattr(f, "save_mean", ws.ptr(vecs + 8 * cout)),
                     setattr(f, "save_rstd", ws.ptr(vecs + 12 * cout))))
-                plan.fwd.append((L.OP_BN_FINALIZE, f))
                 a = ew_desc(a=y_raw, out=z, act=act)
                 later(lambda a=a, vecs=vecs: (setattr(a, "p0", ws.ptr(vecs)), setattr(a, "p1", ws.ptr(vecs + 4 * cout))))
-                plan.fwd.append((L.OP_BN_ACT_FWD, a))
+                if slots <= 32 and os.environ.get("DYK_BN_FUSED_FWD", "1") != "0":
+                    fm = misc()                       # finalize folded into the normalise + activation launch
+                    fm.p[0], fm.p[1] = ctypes.addressof(f), ctypes.addressof(a)
+                    plan.fwd.append((L.OP_BN_FWD_FUSED, fm))
+                else:
+                    plan.fwd.append((L.OP_BN_FINALIZE, f))
+                    plan.fwd.append((L.OP_BN_ACT_FWD, a))
                 rec.update(y_raw=y_raw, z=z, vecs=vecs, bn_act_desc=a)
                 return z, rec
             # eval: running statistics folded into an affine (conv epilogue for the MFMA conv, one more
@@ -356,6 +364,9 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             raise NotImplementedError("activation on a conv without batch_normalize (layer %d)" % i)
         return z, rec
 
+    stats_memset = misc()
+    if training:
+        plan.fwd.append((L.OP_MEMSET, stats_memset))       # re-arm every BatchNorm statistics replica of the pass
     fwd_start = []            # index of the first forward command of each section
     for i, m in enumerate(defs):
         t = m["type"]
@@ -813,7 +824,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         if second < F < len(defs):
             lo, hi = fwd_start[second], fwd_start[F]
             if 0 < lo < hi < len(plan.fwd):
-                plan.fwd_lanes[0] = 2                               # fork at the very start
+                plan.fwd_lanes[1 if training else 0] = 2            # fork at the start (behind the statistics memset)
                 for q in range(lo, hi):
                     plan.fwd_lanes[q] = plan.fwd_lanes.get(q, 0) | 1
                 plan.fwd_lanes[hi] = plan.fwd_lanes.get(hi, 0) | 4  # join in front of the fusion section
@@ -828,6 +839,9 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     # ---------------------------------------------------------------- materialise
     for a in plan.arenas.values():
         a.materialize(device)
+    if training:
+        stats_memset.p[0] = st_arena.ptr(0)
+        stats_memset.n, stats_memset.i[0] = max(st_arena.size, 256), 0
     for fn in pending:
         fn()
     plan.finalize()
@@ -919,4 +933,5 @@ def autotune(plan, cache=None):
     # the trial launches polluted the statistics accumulators / scratch: reset
     plan.arenas["ws"].tensor.zero_()
     plan.arenas["grad"].tensor.zero_()
+    plan.arenas["stats"].tensor.zero_()
     torch.cuda.synchronize()

@@ -190,6 +190,10 @@ typedef struct DykBnFinalizeDesc {
 } DykBnFinalizeDesc;
 
 int dyk_bn_finalize(const DykBnFinalizeDesc* desc, void* stream);
+/* dyk_bn_finalize + dyk_bn_act_fwd in one launch: out = act(a * scale + shift) (+ b) with scale / shift derived from
+ * the statistics replicas inside the kernel; scale, shift, save_mean, save_rstd and the running statistics are written
+ * as by dyk_bn_finalize, but the replicas are left untouched (the caller re-arms them, e.g. one memset per pass). */
+int dyk_bn_finalize_act_fwd(const DykBnFinalizeDesc* fin, const DykEwDesc* act_desc, void* stream);
 
 /* eval-mode BatchNorm folded to scale/shift from the running statistics */
 int dyk_bn_fold(const float* gamma, const float* beta, const float* running_mean,
@@ -381,6 +385,7 @@ enum {
     DYK_OP_DW_DGRAD = 27,       /* DykDwDesc -> dyk_dwconv_dgrad */
     DYK_OP_DW_WGRAD = 28,       /* DykDwDesc -> dyk_dwconv_wgrad */
     DYK_OP_CAST_PAD_ROWS = 29,  /* Misc: p0=src p1=dst i0=R i1=C i2=Cpad i3=dtype */
+    DYK_OP_BN_FWD_FUSED = 30,   /* Misc: p0=DykBnFinalizeDesc* p1=DykEwDesc* -> dyk_bn_finalize_act_fwd */
     DYK_OP_COUNT_
 };
 

@@ -90,7 +90,8 @@ def test_plan_compiles_consistently(name, training):
     assert len(plan.p_out) == 3 and [tuple(p.shape) for p in plan.p_out] == [
         (B, 3, H // s, W // s, 6) for s in ([32, 16, 8] if "yolov3" in name else [8, 16, 32])]
     if training:
-        assert ops.count(L.OP_BN_FINALIZE) == ops.count(L.OP_BN_ACT_FWD) == n_bn
+        assert ops.count(L.OP_BN_FINALIZE) == ops.count(L.OP_BN_ACT_FWD) and ops.count(L.OP_BN_FINALIZE) + ops.count(L.OP_BN_FWD_FUSED) == n_bn
+        assert ops[0] == L.OP_MEMSET
         bops = [op for op, _ in plan.bwd]
         assert bops[0] == L.OP_MEMSET
         assert bops.count(L.OP_WGRAD) == n_conv
