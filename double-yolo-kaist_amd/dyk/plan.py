@@ -218,7 +218,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     head_idx = 0
     na_no = []
 
-    def conv_forward(i, x_in, stem_src, wname, bnpre, bnm, bias_name, k, stride, pad, cout, act, groups=1, out_layer=None):
+    def conv_forward(i, x_in, stem_src, wname, bnpre, bnm, bias_name, k, stride, pad, cout, act, groups=1, out_layer=None,
+                     out_ref=None):
         """emit forward commands of Conv2d [+ BatchNorm2d] [+ activation]; returns (out TRef, info dict).
         wname / bnpre / bias_name are parameter-store names (bnpre None = no BatchNorm)."""
         bn = bnpre is not None
@@ -283,7 +284,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         if bn:
             if training:
                 y_raw = new_act(B, Ho, Wo, cout)
-                z = alloc_out(out_layer, B, Ho, Wo, cout)
+                z = out_ref if out_ref is not None else alloc_out(out_layer, B, Ho, Wo, cout)
                 # replicas of the fp64 statistics accumulators: keep the atomics per address at a few dozen
                 tiles = (B * Ho * Wo + 127) // 128
                 # (about 32 workgroups per replica), few enough that the consumer folds them cheaply
@@ -320,7 +321,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 return z, rec
             # eval: running statistics folded into an affine (conv epilogue for the MFMA conv, one more
             # streaming pass for the depthwise conv)
-            z = alloc_out(out_layer, B, Ho, Wo, cout)
+            z = out_ref if out_ref is not None else alloc_out(out_layer, B, Ho, Wo, cout)
             vecs = new_ws(2 * cout * 4)
             fo = misc()
             fo.p[0], fo.p[1] = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
@@ -401,6 +402,37 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             cur, rec_pw = conv_forward(i, mid, None, pre + "3.weight", pre + "4.", mod.conv[4], None, 1, 1, 0,
                                        m["filters"], relu6, out_layer=i)
             rec = {"kind": "dwsep", "i": i, "parts": [rec_dw, rec_pw]}
+        elif t == "inception":
+            # Inception (layers.py:148-172): 1x1 | 1x1-3x3 | 1x1-3x3-3x3 | maxpool3-1x1, every conv = Conv2d + BN +
+            # LeakyReLU(0.1); the last conv of each branch writes its slice of the concatenated output
+            x_in = cur
+            pre = "module_list.%d." % i
+            leaky = L.ACT_CODES["leaky"]
+            specs = [[(m["n1x1"], 1)], [(m["n3x3_reduce"], 1), (m["n3x3"], 3)],
+                     [(m["n5x5_reduce"], 1), (m["n5x5"], 3), (m["n5x5"], 3)], [(m["pool_proj"], 1)]]
+            ctot = sum(sp[-1][0] for sp in specs)
+            cat = alloc_out(i, B, x_in.H, x_in.W, ctot)
+            pooled = new_act(B, x_in.H, x_in.W, x_in.C)
+            amax = new_ws(x_in.npix * x_in.C) if training else None
+            pd = ew_desc(a=x_in, out=pooled, Bn=B, Hn=x_in.H, Wn=x_in.W, k=3)
+            if amax is not None:
+                later(lambda pd=pd, amax=amax: setattr(pd, "aux", ws.ptr(amax)))
+            plan.fwd.append((L.OP_MAXPOOL_FWD, pd))
+            branches, c0 = [], 0
+            for bi, sp in enumerate(specs):
+                h = pooled if bi == 3 else x_in
+                recs = []
+                for ci, (co, kk) in enumerate(sp):
+                    q = pre + "branch%d.%d.conv." % (bi + 1, ci + (1 if bi == 3 else 0))
+                    bnm_ = getattr(mod, "branch%d" % (bi + 1))[ci + (1 if bi == 3 else 0)].conv[1]
+                    last = ci == len(sp) - 1
+                    h, r_ = conv_forward(i, h, None, q + "0.weight", q + "1.", bnm_, None, kk, 1, kk // 2, co, leaky,
+                                         out_ref=cat.chan_slice(c0, co) if last else None)
+                    recs.append(r_)
+                branches.append((recs, c0, sp[-1][0]))
+                c0 += sp[-1][0]
+            rec.update(x=x_in, z=cat, branches=branches, pooled=pooled, amax=amax)
+            cur = cat
         elif t == "route":
             layers = mod.layers
             if len(layers) == 1:
@@ -707,6 +739,25 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             elif t == "dwsep":
                 for sub in reversed(rec["parts"]):
                     conv_layer_backward(sub)
+            elif t == "inception":
+                z = rec["z"]
+                if z.tid not in ginit:
+                    continue
+                go = gref(z)
+                for recs, c0, co in rec["branches"]:           # the branch outputs' gradients are slices of the concat's
+                    zb = recs[-1]["z"]
+                    g = go.chan_slice(c0, co)
+                    g.tid = zb.tid
+                    grads[zb.tid] = g
+                    ginit.add(zb.tid)
+                for recs, c0, co in reversed(rec["branches"]):
+                    for sub in reversed(recs):
+                        conv_layer_backward(sub)
+                pooled, x_in = rec["pooled"], rec["x"]
+                if pooled.tid in ginit:
+                    pd = ew_desc(a=gref(pooled), out=gref(x_in), Bn=B, Hn=x_in.H, Wn=x_in.W, k=3, flags=acc_flag(x_in))
+                    later(lambda pd=pd, rec=rec: setattr(pd, "aux", ws.ptr(rec["amax"])))
+                    plan.bwd.append((L.OP_MAXPOOL_BWD, pd))
             elif t == "route":
                 out = rec["out"]
                 if out.tid not in ginit:

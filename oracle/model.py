@@ -118,6 +118,20 @@ class OracleNet:
                 self.yolo_layers.append(i)
             elif t == "dropout":
                 L.update(p=m["probability"])
+            elif t == "inception":
+                # layers.py:148-172: four branches of ConvBnActivation (Conv2d + BN + LeakyReLU(0.1)) blocks, concatenated;
+                # models.py:81-85 leaves `filters` untouched (the cfgs keep sum(branches) == input channels)
+                cin = out_filters[-1]
+                br = [[(cin, m["n1x1"], 1)],
+                      [(cin, m["n3x3_reduce"], 1), (m["n3x3_reduce"], m["n3x3"], 3)],
+                      [(cin, m["n5x5_reduce"], 1), (m["n5x5_reduce"], m["n5x5"], 3), (m["n5x5"], m["n5x5"], 3)],
+                      [(cin, m["pool_proj"], 1)]]
+                L.update(branches=br)
+                for bi, convs in enumerate(br):
+                    for ci, (a, b, k) in enumerate(convs):
+                        q = pre + "branch%d.%d.conv." % (bi + 1, ci + (1 if bi == 3 else 0))
+                        self.param_shapes[q + "0.weight"] = (b, a, k, k)
+                        self._bn_shapes(q + "1.", b)
             else:
                 raise NotImplementedError("oracle: cfg section [%s]" % t)
             self.layers.append(L)
@@ -210,6 +224,16 @@ class OracleNet:
                 x = s * x
             elif t == "maxpool":
                 x = F.max_pool2d(x, L["k"], L["stride"], L["pad"])
+            elif t == "inception":
+                outs_b = []
+                for bi, convs in enumerate(L["branches"]):
+                    h = F.max_pool2d(x, 3, 1, 1) if bi == 3 else x
+                    for ci, (a, b, k) in enumerate(convs):
+                        q = pre + "branch%d.%d.conv." % (bi + 1, ci + (1 if bi == 3 else 0))
+                        h = F.conv2d(h, sd[q + "0.weight"], None, 1, k // 2)
+                        h = F.leaky_relu(self._bn(sd, q + "1.", h, training), 0.1)
+                    outs_b.append(h)
+                x = torch.cat(outs_b, 1)
             elif t == "upsample":
                 x = F.interpolate(x, scale_factor=L["scale"], mode="nearest")
             elif t == "route":                                      # layers.py:42-44

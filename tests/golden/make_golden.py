@@ -22,7 +22,8 @@ sys.path.insert(0, HERE)
 from ref_import import import_reference, REF  # noqa: E402
 
 CFGS = ["kaist_yolov3", "kaist_dyolov3_add_sl", "kaist_dyolov4_fshare_global_concat_se3",
-        "kaist_dyolov4_mobilenetv3_fshare_global_cse3", "kaist_dyolov4_mobilenetv2_fshare_global_cse3"]
+        "kaist_dyolov4_mobilenetv3_fshare_global_cse3", "kaist_dyolov4_mobilenetv2_fshare_global_cse3",
+        "kaist_dyolov3_concat_inc"]
 
 QUIRK_CFG = """[net]
 batch = 64

@@ -12,7 +12,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "double-yolo-kaist_amd"), os.path.join(ROOT, "tests")]
-from helpers import C3, C5, oracle_net  # noqa: E402
+from helpers import C3, C5, INC, oracle_net  # noqa: E402
 
 K = 64
 
@@ -54,5 +54,5 @@ def main(name):
 
 
 if __name__ == "__main__":
-    for cfg_name in (sys.argv[1:] or [C3, C5]):
+    for cfg_name in (sys.argv[1:] or [C3, C5, INC]):
         main(cfg_name)

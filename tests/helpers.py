@@ -7,8 +7,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden")
 CFGS = ["kaist_yolov3", "kaist_dyolov3_add_sl", "kaist_dyolov4_fshare_global_concat_se3",
-        "kaist_dyolov4_mobilenetv3_fshare_global_cse3", "kaist_dyolov4_mobilenetv2_fshare_global_cse3"]
-C1, C2, C3, C5, MNV2 = CFGS
+        "kaist_dyolov4_mobilenetv3_fshare_global_cse3", "kaist_dyolov4_mobilenetv2_fshare_global_cse3",
+        "kaist_dyolov3_concat_inc"]
+C1, C2, C3, C5, MNV2, INC = CFGS
 
 
 def golden_sections(name):
