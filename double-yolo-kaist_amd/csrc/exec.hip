@@ -1,4 +1,5 @@
 // Native command-list executor, parameter staging kernels and the YOLO box decode.
+#include <stdlib.h>
 #include "dyk_common.h"
 
 namespace {
@@ -232,8 +233,14 @@ extern "C" int dyk_run_commands_overlap(const DykCommand* cmds, int32_t n, void*
     static hipEvent_t ring[64];
     static hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr;
     if (!branch) {
-        if (hipStreamCreateWithFlags(&branch, hipStreamNonBlocking) != hipSuccess) return DYK_ERR_HIP;
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return DYK_ERR_HIP;
+        // the weight gradients are filler work: lowest priority, so that their workgroups do not delay the kernels of
+        // the critical chain (DYK_SIDE_PRIORITY=0 disables the distinction)
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);             // lo = least, hi = greatest priority (numerically smaller)
+        const char* pe = getenv("DYK_SIDE_PRIORITY");
+        const bool prio = !(pe && pe[0] == '0');
+        if (hipStreamCreateWithPriority(&branch, hipStreamNonBlocking, prio ? hi : 0) != hipSuccess) return DYK_ERR_HIP;
+        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio ? lo : 0) != hipSuccess) return DYK_ERR_HIP;
         for (auto& e : ring)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;

@@ -31,7 +31,12 @@ def _targets_desc(shapes, targets, model):
     t.nt, t.nheads, t.na = nt, nheads, na
     for h, (j, shp) in enumerate(zip(m.yolo_layers, shapes)):
         t.ny[h], t.nx[h] = shp[2], shp[3]
-        av = m.module_list[j].anchor_vec.detach().float().cpu().reshape(-1).tolist()
+        # anchor_vec is a device tensor after model.to(device): reading it back every step would be a host sync in the
+        # middle of the train step (the CPU then enqueues the backward behind an idle GPU) -- read once per model
+        cache = m.__dict__.setdefault("_dyk_anchor_cache", {})
+        av = cache.get(j)
+        if av is None:
+            av = cache[j] = m.module_list[j].anchor_vec.detach().float().cpu().reshape(-1).tolist()
         for q, v in enumerate(av):
             t.anchor_vec[h][q] = v
     t.iou_t = float(m.hyp["iou_t"])

@@ -972,6 +972,8 @@ def autotune(plan, cache=None):
                 fn = lib.dyk_conv_igemm
             else:
                 cands, fn = _WGRAD_CANDIDATES, lib.dyk_conv_wgrad
+                if os.environ.get("DYK_WGRAD_CANDS"):
+                    cands = [int(c, 0) for c in os.environ["DYK_WGRAD_CANDS"].split(",")]
             times = []
             for c in cands:
                 d.tune = c
