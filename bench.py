@@ -200,7 +200,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DYK_FORCE_DDP"):       # DYK_FORCE_DDP=1: exercise the exchange path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
@@ -224,7 +224,7 @@ def main():
     B, H, W = args.batch, 512, 640
     v8, l8, targets = synth_batch(B, H, W, rank, device)
     opt = FusedAdam(model, lr=hyp["lr0"], betas=(hyp["momentum"], 0.999), weight_decay=hyp["weight_decay"])
-    reducer = GradAllReduce(model, dist) if world > 1 else None
+    reducer = GradAllReduce(model, dist) if dist is not None else None
     if reducer is not None:
         opt.grad_scale = 1.0 / world
 
