@@ -13,6 +13,15 @@ extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
     if (d->B <= 0 || d->Hg <= 0 || d->Wg <= 0 || d->Cout <= 0 || d->Cin <= 0) return DYK_ERR_ARG;
     if ((d->flags & DYK_EPI_STATS) && !d->stats) return DYK_ERR_ARG;
     if ((d->flags & DYK_EPI_RESIDUAL) && !d->res) return DYK_ERR_ARG;
+    if (d->flags & DYK_EPI_BNBWD) {
+        if (d->flags & (DYK_EPI_AFFINE | DYK_EPI_RESIDUAL | DYK_EPI_STATS | DYK_EPI_ACCUM | DYK_EPI_OUT_F32)) return DYK_ERR_ARG;
+        if (!d->res || !d->stats || !d->scale || !d->shift || !d->aux0 || !d->aux1) return DYK_ERR_ARG;
+        const int es = d->dtype == DYK_BF16 ? 2 : 4;
+        // needs the staged (vector) epilogue: 16-byte aligned rows of y and res, whole 16-byte channel chunks
+        if (d->Cout % (16 / es) || ((size_t)d->ldy * es) % 16 || ((size_t)d->ldr * es) % 16 || ((uintptr_t)d->y % 16) ||
+            ((uintptr_t)d->res % 16))
+            return DYK_ERR_ARG;
+    }
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     if (d->dtype != DYK_BF16 && d->dtype != DYK_F32) return DYK_ERR_ARG;
     if (d->ldx % epv || ((uintptr_t)d->x % 16) || ((uintptr_t)d->w % 16)) return DYK_ERR_ARG;

@@ -263,9 +263,100 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
                 }
             }
         };
+        // ---- BatchNorm-backward reduce fused into the data gradient that produces dz (DYK_EPI_BNBWD): the staged
+        // gradient tile is read back chunk by chunk together with the matching chunk of the raw conv output, turned
+        // into da = dz * act'(u) and stored; sum(da), sum(da * xhat) go thread -> wave (shuffle) -> workgroup (LDS
+        // atomics) -> one fp64 atomic per channel into a replica of the reduction buffer.
+        auto staged_bnbwd = [&](auto actb_tag) {
+            constexpr int ACTB = decltype(actb_tag)::value;
+            constexpr int eso = (int)sizeof(T);
+            constexpr int rstride = BM * eso + 16;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int ml = wm * WTM + mi * 16 + mlane;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int nl = wn * WTN + ni * 16 + (lane & 15);
+                    char* dst = sC + nl * rstride + ml * eso;
+                    if constexpr (sizeof(T) == 4) {
+                        *(float4*)dst = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+                    } else {
+                        uint2 pk;
+                        pk.x = f32x2_to_bf16x2(acc[mi][ni][0], acc[mi][ni][1]);
+                        pk.y = f32x2_to_bf16x2(acc[mi][ni][2], acc[mi][ni][3]);
+                        *(uint2*)dst = pk;
+                    }
+                }
+            }
+            for (int i = tid; i < 2 * BM; i += 256) s_stat[i] = 0.f;
+            __syncthreads();
+            constexpr int EPVT = 16 / eso;                        // elements per 16-byte chunk
+            constexpr int cpr = BM / EPVT;                        // chunks per tile row (divides 256: one chunk column per thread)
+            constexpr int nchunk = BN * cpr;
+            const int cc = tid % cpr;
+            const int mc = m0 + cc * EPVT;
+            const bool live = mc + EPVT <= a.Cout;
+            float sc[EPVT], sh[EPVT], mu[EPVT], rs[EPVT], s1[EPVT], s2[EPVT];
+#pragma unroll
+            for (int j = 0; j < EPVT; ++j) {
+                sc[j] = live ? a.scale[mc + j] : 0.f; sh[j] = live ? a.shift[mc + j] : 0.f;
+                mu[j] = live ? a.aux0[mc + j] : 0.f; rs[j] = live ? a.aux1[mc + j] : 0.f;
+                s1[j] = s2[j] = 0.f;
+            }
+            if (live) {
+                for (int q = tid; q < nchunk; q += 256) {
+                    const int row = q / cpr;
+                    const int po = t_out[row];
+                    if (po < 0) continue;
+                    float g[EPVT], yv[EPVT];
+                    vec_unpack<T>(*(const uint4*)(sC + row * rstride + cc * 16), g);
+                    vec_unpack<T>(*(const uint4*)((const T*)a.res + (long)t_res[row] + mc), yv);
+#pragma unroll
+                    for (int j = 0; j < EPVT; ++j) {
+                        const float da = g[j] * act_bwd_c<ACTB>(yv[j] * sc[j] + sh[j], a.act);
+                        s1[j] += da;
+                        s2[j] += da * ((yv[j] - mu[j]) * rs[j]);
+                        g[j] = da;
+                    }
+                    *(uint4*)((T*)a.y + (long)po + mc) = vec_pack<T>(g);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < EPVT; ++j) {
+#pragma unroll
+                for (int o = cpr; o < 64; o <<= 1) {
+                    s1[j] += __shfl_xor(s1[j], o, 64);
+                    s2[j] += __shfl_xor(s2[j], o, 64);
+                }
+            }
+            if (lane < cpr && live) {
+#pragma unroll
+                for (int j = 0; j < EPVT; ++j) {
+                    atomicAdd(s_stat + cc * EPVT + j, s1[j]);
+                    atomicAdd(s_stat + BM + cc * EPVT + j, s2[j]);
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * BM) {
+                const int ml = tid % BM, which = tid / BM;
+                if (m0 + ml < a.Cout) {
+                    double* st = a.stats + (size_t)(blockIdx.x % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
+                    atomicAdd(st + which * a.Cout + m0 + ml, (double)s_stat[tid]);
+                }
+            }
+        };
         using std::integral_constant;
         using std::true_type;
         using std::false_type;
+        if (flags & DYK_EPI_BNBWD) {
+            switch (a.act) {
+            case DYK_ACT_LINEAR: staged_bnbwd(integral_constant<int, DYK_ACT_LINEAR>{}); break;
+            case DYK_ACT_LEAKY: staged_bnbwd(integral_constant<int, DYK_ACT_LEAKY>{}); break;
+            case DYK_ACT_MISH: staged_bnbwd(integral_constant<int, DYK_ACT_MISH>{}); break;
+            default: staged_bnbwd(integral_constant<int, -1>{}); break;
+            }
+            return;
+        }
         if (out_f32) {
             // heads (bias, linear) and the fp32 dtype: runtime activation, few launches
             if (!affine && a.act == 0) staged(true_type{}, integral_constant<int, 0>{}, false_type{});

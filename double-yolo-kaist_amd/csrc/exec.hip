@@ -255,23 +255,44 @@ extern "C" int dyk_run_commands_overlap(const DykCommand* cmds, int32_t n, void*
         forked = false;
         return true;
     };
-    for (int32_t k = 0; k < n; ++k) {
-        const int lane = cmds[k].lane;
-        if ((lane & 4) && forked && !join_branch()) return DYK_ERR_HIP;
-        if (lane & 2) {
-            if (forked && !join_branch()) return DYK_ERR_HIP;
-            if (hipEventRecord(ev_fork, main_s) != hipSuccess || hipStreamWaitEvent(branch, ev_fork, 0) != hipSuccess) return DYK_ERR_HIP;
-            forked = true;
-        }
-        hipStream_t target = (forked && (lane & 1)) ? branch : main_s;
-        if (cmds[k].op == DYK_OP_WGRAD || cmds[k].op == DYK_OP_DW_WGRAD) {
+    // issue one command on `target` (weight gradients: on the side stream behind an event of `target`)
+    auto issue = [&](int32_t k, hipStream_t target) -> int {
+        if ((cmds[k].op == DYK_OP_WGRAD || cmds[k].op == DYK_OP_DW_WGRAD) && !(cmds[k].lane & 8)) {
             hipEvent_t e = ring[ev++ & 63];
             if (hipEventRecord(e, target) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return DYK_ERR_HIP;
             target = side;
             used_side = true;
         }
         const int rc = dyk_run_commands(cmds + k, 1, (void*)target, nullptr);
-        if (rc != DYK_OK) { if (failed_index) *failed_index = k; return rc; }
+        if (rc != DYK_OK && failed_index) *failed_index = k;
+        return rc;
+    };
+    int32_t k = 0;
+    while (k < n) {
+        const int lane = cmds[k].lane;
+        if ((lane & 4) && forked && !join_branch()) return DYK_ERR_HIP;
+        if (lane & 2) {
+            if (forked && !join_branch()) return DYK_ERR_HIP;
+            if (hipEventRecord(ev_fork, main_s) != hipSuccess || hipStreamWaitEvent(branch, ev_fork, 0) != hipSuccess) return DYK_ERR_HIP;
+            forked = true;
+            // The list holds the two independent runs back to back: [k, p) for this stream, [p, q) for the branch.
+            // Enqueue them INTERLEAVED -- the host needs ~9 us per command, so issuing 200+ commands of one run
+            // first would start the other stream milliseconds late and waste most of the overlap.
+            int32_t p = k;
+            while (p < n && !(cmds[p].lane & 1) && !(p > k && (cmds[p].lane & 6))) ++p;
+            int32_t q = p;
+            while (q < n && (cmds[q].lane & 1) && !(cmds[q].lane & 6)) ++q;
+            int32_t i = k, j = p;
+            while (i < p || j < q) {
+                if (i < p) { const int rc = issue(i, main_s); if (rc != DYK_OK) return rc; ++i; }
+                if (j < q) { const int rc = issue(j, branch); if (rc != DYK_OK) return rc; ++j; }
+            }
+            k = q;
+            continue;
+        }
+        const int rc = issue(k, (forked && (lane & 1)) ? branch : main_s);
+        if (rc != DYK_OK) return rc;
+        ++k;
     }
     if (forked && !join_branch()) return DYK_ERR_HIP;
     if (used_side) {

@@ -212,6 +212,11 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     # ---------------------------------------------------------------- forward
     outs = []                 # per layer: TRef or None
     info = []                 # per layer: dict of what backward needs
+    tcons = {}                # TRef tid -> number of sections that read the tensor
+    producer_of = {}          # TRef tid of a train-mode conv+BN output -> its record
+
+    def consume(t):
+        tcons[t.tid] = tcons.get(t.tid, 0) + 1
     cur = None                # current x
     img = {"x": None, "y": None}
     yolo_rows = []
@@ -267,6 +272,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             taps, cisy = fwd_taps(k, pad), stride
             rec["wgrad"] = dict(x=x_in, Cin=x_in.C, lddw=0, taps=taps, isy=stride, Hi=Hi, Wi=Wi)
         rec["x"] = x_in
+        if stem_src is None:
+            consume(x_in)
         if not dw:
             d = L.DykConvDesc()
             plan._keep.append(d)
@@ -318,6 +325,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     plan.fwd.append((L.OP_BN_FINALIZE, f))
                     plan.fwd.append((L.OP_BN_ACT_FWD, a))
                 rec.update(y_raw=y_raw, z=z, vecs=vecs, bn_act_desc=a)
+                producer_of[z.tid] = rec
                 return z, rec
             # eval: running statistics folded into an affine (conv epilogue for the MFMA conv, one more
             # streaming pass for the depthwise conv)
@@ -406,6 +414,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             # Inception (layers.py:148-172): 1x1 | 1x1-3x3 | 1x1-3x3-3x3 | maxpool3-1x1, every conv = Conv2d + BN +
             # LeakyReLU(0.1); the last conv of each branch writes its slice of the concatenated output
             x_in = cur
+            consume(x_in)                    # (the branch convs count it again: never a fusion candidate)
             pre = "module_list.%d." % i
             leaky = L.ACT_CODES["leaky"]
             specs = [[(m["n1x1"], 1)], [(m["n3x3_reduce"], 1), (m["n3x3"], 3)],
@@ -440,6 +449,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 rec["alias"] = True
             else:
                 srcs = [outs[j] for j in layers]
+                for s_ in srcs:
+                    consume(s_)
                 ctot = sum(s.C for s in srcs)
                 s0 = srcs[0]
                 cat = route_buf.get(i)
@@ -464,6 +475,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             C = min(x_in.C, a.C)
             if x_in.C != a.C:
                 raise NotImplementedError("[shortcut] with mismatched channel counts (layer %d)" % i)
+            consume(x_in)
+            consume(a)
             prev = info[i - 1] if i > 0 else {}
             fusable = (not mod.weight and prev.get("kind") == "conv" and prev.get("bn") and prev.get("z") is x_in
                        and not model.routs[i - 1] and a is not x_in
@@ -504,6 +517,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             cur = z
         elif t == "se":
             x_in = cur
+            consume(x_in)
             C, Cs = mod.fc1.in_channels, mod.fc1.out_channels
             pooled = new_ws(B * C * 4)
             scale = new_ws(B * C * 4)
@@ -526,6 +540,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             cur = z
         elif t == "maxpool":
             x_in = cur
+            consume(x_in)
             k, stride = m["size"], m["stride"]
             if stride != 1:
                 raise NotImplementedError("[maxpool] stride %d" % stride)
@@ -539,6 +554,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             cur = z
         elif t == "upsample":
             x_in = cur
+            consume(x_in)
             if m["stride"] != 2:
                 raise NotImplementedError("[upsample] stride %s" % m["stride"])
             z = alloc_out(i, B, 2 * x_in.H, 2 * x_in.W, x_in.C)
@@ -547,6 +563,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             cur = z
         elif t == "yolo":
             y_in = cur                       # head conv output, fp32, ld = HEAD_LD
+            consume(y_in)
             na, no = mod.na, mod.no
             ny, nx = y_in.H, y_in.W
             p = torch.empty((B, na, ny, nx, no), dtype=torch.float32, device=device)
@@ -662,6 +679,14 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 wt_ptr = cw["Wt_pad"].data_ptr() + cw["bwd_pad_off"][wname] * es
             else:
                 wt_ptr = cw["Wt"].data_ptr() + e.offset * es
+            # BatchNorm-backward reduce of the producer of x_in folded into this data gradient (DYK_EPI_BNBWD): possible
+            # when this launch is the only writer of the gradient (sole reader of the tensor, nothing accumulated yet)
+            prod = producer_of.get(x_in.tid)
+            fuse = (first and prod is not None and prod is not rec and tcons.get(x_in.tid, 0) == 1
+                    and x_in.C % (16 // es) == 0 and not os.environ.get("DYK_DEBUG_PLAN")
+                    and os.environ.get("DYK_BNBWD_FUSE", "1") != "0")
+            if fuse:
+                prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
             classes = dgrad_classes(k, pad, stride, x_in.H, x_in.W)
             for (py, px, Hg, Wg, taps) in classes:
                 if not taps and not first:
@@ -681,6 +706,13 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 d.ldx, d.ldy = dy.ld, gx.ld
                 d.act, d.flags = 0, (0 if first else L.EPI_ACCUM)
                 later(lambda d=d, dy=dy, gx=gx: (setattr(d, "x", ptr_of(dy)), setattr(d, "y", ptr_of(gx))))
+                if fuse:
+                    pc, pv, pr = x_in.C, prod["vecs"], prod["red_fused"]
+                    d.act, d.flags, d.stats_slots, d.ldr = prod["act"], L.EPI_BNBWD, STAT_SLOTS, prod["y_raw"].ld
+                    later(lambda d=d, prod=prod, pc=pc, pv=pv, pr=pr: (
+                        setattr(d, "res", ptr_of(prod["y_raw"])), setattr(d, "scale", ws.ptr(pv)),
+                        setattr(d, "shift", ws.ptr(pv + 4 * pc)), setattr(d, "aux0", ws.ptr(pv + 8 * pc)),
+                        setattr(d, "aux1", ws.ptr(pv + 12 * pc)), setattr(d, "stats", ws.ptr(pr))))
                 plan.bwd.append((L.OP_CONV, d))
             ginit.add(x_in.tid)
 
@@ -692,18 +724,23 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             dz = gref(z)
             if rec["bn"]:
                 cout, vecs, bnpre = rec["cout"], rec["vecs"], rec["bnpre"]
-                red = new_red(STAT_SLOTS * 2 * cout * 8)
-                r = ew_desc(a=dz, b=rec["y_raw"], act=rec["act"])
-                r.slots = STAT_SLOTS
-                later(lambda r=r, vecs=vecs, red=red, cout=cout: (
-                    setattr(r, "p0", ws.ptr(vecs)), setattr(r, "p1", ws.ptr(vecs + 4 * cout)),
-                    setattr(r, "p2", ws.ptr(vecs + 8 * cout)), setattr(r, "p3", ws.ptr(vecs + 12 * cout)),
-                    setattr(r, "red", ws.ptr(red))))
-                plan.bwd.append((L.OP_BN_BWD_REDUCE, r))
+                fused_red = rec.get("red_fused")          # the producing dgrad already left da and the two sums
+                act_bwd = 0 if fused_red is not None else rec["act"]
+                if fused_red is not None:
+                    red = fused_red
+                else:
+                    red = new_red(STAT_SLOTS * 2 * cout * 8)
+                    r = ew_desc(a=dz, b=rec["y_raw"], act=rec["act"])
+                    r.slots = STAT_SLOTS
+                    later(lambda r=r, vecs=vecs, red=red, cout=cout: (
+                        setattr(r, "p0", ws.ptr(vecs)), setattr(r, "p1", ws.ptr(vecs + 4 * cout)),
+                        setattr(r, "p2", ws.ptr(vecs + 8 * cout)), setattr(r, "p3", ws.ptr(vecs + 12 * cout)),
+                        setattr(r, "red", ws.ptr(red))))
+                    plan.bwd.append((L.OP_BN_BWD_REDUCE, r))
                 dyr = dz
                 if os.environ.get("DYK_DEBUG_PLAN"):      # keep dz intact for per-layer gradient dumps
                     dyr = TRef("grad", grad_arena.alloc(dz.npix * dz.ld * es), dz.B, dz.H, dz.W, dz.C, dz.ld, es)
-                ap = ew_desc(a=dz, b=rec["y_raw"], out=dyr, act=rec["act"])     # in place: dz -> dy_raw
+                ap = ew_desc(a=dz, b=rec["y_raw"], out=dyr, act=act_bwd)        # in place: dz (or da) -> dy_raw
                 # the apply pass folds the replicas of the reduction itself and adds them to dgamma / dbeta
                 ap.slots = STAT_SLOTS
                 ap.aux, ap.aux2 = store.g_ptr(bnpre + "weight"), store.g_ptr(bnpre + "bias")
@@ -887,6 +924,14 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     for q in range(a0, len(plan.bwd)):
                         plan.bwd_lanes[q] = plan.bwd_lanes.get(q, 0) | 1
 
+    # the side stream finishes last (its launches contend with the chain for CUs): the weight gradients of the last
+    # sections differentiated stay on their own streams instead (measured on the per-stream timeline, tools/trace_timeline.py)
+    if training:
+        wg = [q for q, (op, _) in enumerate(plan.bwd) if op in (L.OP_WGRAD, L.OP_DW_WGRAD)]
+        ntail = int(os.environ.get("DYK_WGRAD_INPLACE_TAIL", "20"))
+        for q in wg[len(wg) - ntail:] if ntail > 0 else []:
+            plan.bwd_lanes[q] = plan.bwd_lanes.get(q, 0) | 8
+
     # ---------------------------------------------------------------- materialise
     for a in plan.arenas.values():
         a.materialize(device)
@@ -957,7 +1002,8 @@ def autotune(plan, cache=None):
     groups = {}
     for (op, d) in plan.fwd + plan.bwd:
         if op == L.OP_CONV:
-            key = ("c", d.dtype, d.B, d.Cin, d.Cout, d.Hg, d.Wg, d.ntaps, d.isy, d.osy, d.flags & (L.EPI_STATS | L.EPI_OUT_F32))
+            key = ("c", d.dtype, d.B, d.Cin, d.Cout, d.Hg, d.Wg, d.ntaps, d.isy, d.osy,
+                   d.flags & (L.EPI_STATS | L.EPI_OUT_F32 | L.EPI_BNBWD))
         elif op == L.OP_WGRAD:
             key = ("w", d.dtype, d.B, d.Cin, d.Cout, d.Ho, d.Wo, d.ntaps, d.isy)
         else:

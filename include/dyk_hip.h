@@ -77,7 +77,13 @@ enum {
                              stats[0..Cout) / stats[Cout..2Cout): replica (workgroup id % stats_slots), 2*Cout doubles each
                              (replication bounds the atomic contention per address; dyk_bn_finalize sums the replicas) */
     DYK_EPI_ACCUM = 8,    /* y = y_old + v (gradient accumulation) */
-    DYK_EPI_OUT_F32 = 16  /* y is float regardless of dtype */
+    DYK_EPI_OUT_F32 = 16, /* y is float regardless of dtype */
+    DYK_EPI_BNBWD = 32    /* data-gradient launches only: the tensor being produced is the gradient wrt the output z of a
+                             train-mode BatchNorm + activation whose raw conv output is `res` (same shape as y).  The
+                             epilogue stores  da = v * act'(res*scale + shift)  instead of v and adds sum(da),
+                             sum(da * (res - aux0) * aux1) per channel into a `stats` replica -- the reduce pass of that
+                             BatchNorm's backward, fused (`act` = its activation; scale/shift/aux0/aux1 = its
+                             scale, shift, saved mean, saved rstd).  Excludes AFFINE, RESIDUAL, STATS, ACCUM, OUT_F32. */
 };
 
 typedef struct DykConvDesc {
@@ -88,6 +94,8 @@ typedef struct DykConvDesc {
     const float* shift;   /* [Cout] or NULL */
     const void* res;      /* residual, dtype, or NULL */
     double* stats;        /* [2*Cout] or NULL */
+    const float* aux0;    /* DYK_EPI_BNBWD: saved mean [Cout] */
+    const float* aux1;    /* DYK_EPI_BNBWD: saved rstd [Cout] */
     int32_t dtype;
     int32_t ldx, ldy, ldr;          /* pixel strides in elements */
     int32_t B, Hi, Wi, Cin, Cout;
@@ -394,7 +402,8 @@ typedef struct DykCommand {
     int32_t lane;         /* scheduling hints for dyk_run_commands_overlap (ignored by dyk_run_commands):
                              bit 0 = belongs to the second, independent branch (the LWIR backbone of a dual-stream
                              net); bit 1 = fork point (the branch may start once everything before this command is
-                             done); bit 2 = join (this command needs both branches) */
+                             done); bit 2 = join (this command needs both branches); bit 3 = a weight-gradient command that
+                             stays on its own stream (the tail of a backward list: balances the side stream) */
     const void* desc;
 } DykCommand;
 

@@ -253,3 +253,64 @@ def test_conv_every_tile_configuration(case):
         z = ops.conv2d_fwd(xd, wp, k, s, pad, Cout, act="leaky", scale=scale.cuda(), shift=shift.cuda(), tune=tune)
         err = (ops.to_nchw(z).cpu() - z_ref).abs().max().item()
         assert err <= 1.5e-2 * max(1.0, z_ref.abs().max().item()), (hex(tune), err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["mish", "leaky", "linear", "relu6"])
+def test_dgrad_with_fused_batchnorm_backward_reduce(dtype, act):
+    """DYK_EPI_BNBWD: the data gradient that produces dz of a BatchNorm+activation output stores
+    da = dz * act'(y*scale + shift) and accumulates sum(da), sum(da * xhat) (the BN backward's reduce pass)."""
+    import ctypes
+    from dyk import lib as L
+    from dyk import ops
+    acts = {"mish": F.mish, "leaky": lambda t: F.leaky_relu(t, 0.1), "linear": lambda t: t, "relu6": F.relu6}
+    B, Cin, Cout, H, W, k = 2, 64, 96, 12, 20, 3          # the conv whose dgrad is launched: Cin -> Cout
+    g = torch.Generator().manual_seed(11)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * 9) ** 0.5)
+    dy = torch.randn(B, Cout, H, W, generator=g)          # gradient wrt the conv's raw output
+    y_prev = torch.randn(B, Cin, H, W, generator=g)       # raw output of the producer (the BN'd conv before)
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    if dtype == torch.bfloat16:
+        w, dy, y_prev = w.bfloat16().float(), dy.bfloat16().float(), y_prev.bfloat16().float()
+    mean = y_prev.mean((0, 2, 3))
+    var = y_prev.var((0, 2, 3), unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    scale, shift = gamma * rstd, beta - mean * gamma * rstd
+    dz = torch.nn.grad.conv2d_input((B, Cin, H, W), w, dy, padding=1)
+    if dtype == torch.bfloat16:
+        dz = dz.bfloat16().float()                         # the kernel rounds the gradient tile to the storage dtype first
+    u = (y_prev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).requires_grad_(True)
+    acts[act](u).backward(dz)
+    da_ref = u.grad
+    xhat = (y_prev - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1)
+    s1_ref, s2_ref = da_ref.double().sum((0, 2, 3)), (da_ref.double() * xhat.double()).sum((0, 2, 3))
+
+    cpad = (Cout + 31) // 32 * 32
+    dyd = ops.to_nhwc(dy.cuda(), dtype, cpad=cpad)
+    wpt = ops.pack_weight(w.cuda(), dtype, transposed=True, cout_pad=cpad)
+    yd = ops.to_nhwc(y_prev.cuda(), dtype)
+    out = torch.empty((B, H, W, Cin), dtype=dtype, device="cuda")
+    slots = 4
+    red = torch.zeros(slots, 2, Cin, dtype=torch.float64, device="cuda")
+    vec = [t.cuda().contiguous() for t in (scale, shift, mean, rstd)]
+    (py, px, Hg, Wg, taps), = ops.dgrad_classes(k, 1, 1, H, W)
+    d = ops.make_conv_desc(dyd, wpt, out, Hi=H, Wi=W, Cin=cpad, Cout=Cin, Hg=Hg, Wg=Wg, Ho=H, Wo=W, taps=taps, act=act)
+    d.flags = L.EPI_BNBWD
+    d.res, d.ldr = yd.data_ptr(), Cin
+    d.scale, d.shift, d.aux0, d.aux1 = (t.data_ptr() for t in vec)
+    d.stats, d.stats_slots = red.data_ptr(), slots
+    for tune in (0, 64 | (2 << 8) | (2 << 12), 64 | (2 << 8) | (4 << 12)):        # generic 128, 160-pixel tile, halo tile
+        red.zero_()
+        d.tune = tune
+        L.check(L.load().dyk_conv_igemm(ctypes.byref(d), None), "dyk_conv_igemm(BNBWD)")
+        tol = 3e-5 if dtype == torch.float32 else 1.5e-2
+        got = ops.to_nchw(out).cpu()
+        err = (got - da_ref).abs().max().item()
+        assert err <= tol * max(1.0, da_ref.abs().max().item()), (hex(tune), err)
+        st = red.sum(0).cpu()
+        n = B * H * W
+        assert torch.allclose(st[0], s1_ref, rtol=2e-3, atol=(5e-4 if dtype == torch.float32 else 5e-2) * n ** 0.5), hex(tune)
+        assert torch.allclose(st[1], s2_ref, rtol=2e-3, atol=(5e-4 if dtype == torch.float32 else 5e-2) * n ** 0.5), hex(tune)
+    # illegal flag combinations are rejected
+    d.flags = L.EPI_BNBWD | L.EPI_ACCUM
+    assert L.load().dyk_conv_igemm(ctypes.byref(d), None) != 0

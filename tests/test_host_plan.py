@@ -95,7 +95,9 @@ def test_plan_compiles_consistently(name, training):
         bops = [op for op, _ in plan.bwd]
         assert bops[0] == L.OP_MEMSET
         assert bops.count(L.OP_WGRAD) == n_conv
-        assert bops.count(L.OP_BN_BWD_REDUCE) == bops.count(L.OP_BN_BWD_APPLY) == n_bn and bops.count(L.OP_BN_BWD_PARAMS) == 0
+        n_fused = sum(1 for op, d in plan.bwd if op == L.OP_CONV and d.flags & L.EPI_BNBWD and d.ooy == 0 and d.oox == 0)
+        assert bops.count(L.OP_BN_BWD_APPLY) == n_bn and bops.count(L.OP_BN_BWD_REDUCE) + n_fused == n_bn and n_fused > 0
+        assert bops.count(L.OP_BN_BWD_PARAMS) == 0
         # every data-gradient launch either stores or accumulates; the first write into each buffer stores
         seen = set()
         for op, d in plan.bwd:
