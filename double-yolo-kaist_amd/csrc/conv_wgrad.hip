@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc
     const int gchunk = chunk / KG;
     const int p_begin = sp * chunk + grp * gchunk;
     const int p_end = min(Ntot, p_begin + gchunk);
-    if (KG == 1 && p_begin >= p_end) return;
+    if (KG == 1 && p_begin >= p_end && !a.part) return;      // (with `part` every launched split owns a plane and writes it)
     const int tdy = a.tdy[tap], tdx = a.tdx[tap];
     const T* __restrict__ dyg = (const T*)a.dy;
     const T* __restrict__ xg = (const T*)a.x;
@@ -349,6 +349,26 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc
         if (sum == 123.456f) dw[0] = sum;
         return;
     }
+    if (a.part) {
+        // atomic-free mode: this split's plane gets the tile with plain stores (16 lanes = one 64-byte row segment);
+        // dyk_grad_reduce folds the planes.  The fp32 atomics retire at ~1 lane per clock per L2 channel and were
+        // 37 % of this kernel's time; the stores run at HBM speed and the result is bit-reproducible.
+        float* pw = a.part + (long)sp * a.part_stride + (long)a.twt[tap] * a.Cout * lddw;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = m0 + wm * WTM + mi * 16 + (lane >> 4) * 4 + r;
+                if (co >= a.Cout) continue;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int ci = n0 + wn * WTN + ni * 16 + (lane & 15);
+                    if (ci < a.Cin) pw[(long)co * lddw + ci] = acc[mi][ni][r];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -373,8 +393,9 @@ inline bool wg_use_dma() {
     return v == 1;
 }
 
+// query != NULL: only report the split count this launch would use
 template <typename T, int BM, int BN, int PIPE, int KG>
-int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream) {
+int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream, int* query) {
     constexpr int ROWS = WgTraits<T>::ROWS;
     constexpr size_t ring = KG * (PIPE ? PIPE : 2) * (size_t)ROWS * (BM + BN) * sizeof(T);
     constexpr size_t park = KG > 1 ? (size_t)BM * BN * 4 : 0;
@@ -399,33 +420,66 @@ int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream) {
     }
     if (splits * KG > ksteps) splits = ksteps / KG > 0 ? ksteps / KG : 1;
     const int chunk = dyk_div_up(ksteps, splits * KG) * ROWS * KG;      // pixels per workgroup: KG slices of whole K steps
-    splits = dyk_div_up(Ntot, chunk);
+    if (!(d->part && d->splits > 0)) splits = dyk_div_up(Ntot, chunk);  // (plane mode with a given count: exactly that many
+                                                                         //  planes are written, trailing empty ones with zeros)
+    if (query) { *query = splits; return DYK_OK; }
     hipLaunchKernelGGL(kfn, dim3(tiles * splits), dim3(256 * KG), lds, stream, *d, splits, chunk);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
 
 template <typename T, int BM, int BN>
-int launch_wgrad(const DykWgradDesc* d, hipStream_t stream) {
-    if (!wg_use_dma()) return launch_wgrad_impl<T, BM, BN, 0, 1>(d, stream);
+int launch_wgrad(const DykWgradDesc* d, hipStream_t stream, int* query) {
+    if (!wg_use_dma()) return launch_wgrad_impl<T, BM, BN, 0, 1>(d, stream, query);
     // tune: low byte = LDS ring stages (2 | 3), bits 8..15 = K-groups per workgroup (1 | 2)
     const int kg = (d->tune >> 8) & 0xff;
-    if ((d->tune & 0xff) == 3) return launch_wgrad_impl<T, BM, BN, 3, 1>(d, stream);
-    if (kg == 2) return launch_wgrad_impl<T, BM, BN, 2, 2>(d, stream);
-    return launch_wgrad_impl<T, BM, BN, 2, 1>(d, stream);
+    if ((d->tune & 0xff) == 3) return launch_wgrad_impl<T, BM, BN, 3, 1>(d, stream, query);
+    if (kg == 2) return launch_wgrad_impl<T, BM, BN, 2, 2>(d, stream, query);
+    return launch_wgrad_impl<T, BM, BN, 2, 1>(d, stream, query);
 }
 
 template <typename T, int BM>
-int dispatch_wgrad_n(const DykWgradDesc* d, hipStream_t s) {
-    if (d->Cin > 64) return launch_wgrad<T, BM, 128>(d, s);
-    if (d->Cin > 32) return launch_wgrad<T, BM, 64>(d, s);
-    return launch_wgrad<T, BM, 32>(d, s);
+int dispatch_wgrad_n(const DykWgradDesc* d, hipStream_t s, int* query) {
+    if (d->Cin > 64) return launch_wgrad<T, BM, 128>(d, s, query);
+    if (d->Cin > 32) return launch_wgrad<T, BM, 64>(d, s, query);
+    return launch_wgrad<T, BM, 32>(d, s, query);
 }
 template <typename T>
-int dispatch_wgrad(const DykWgradDesc* d, hipStream_t s) {
-    if (d->Cout > 64) return dispatch_wgrad_n<T, 128>(d, s);
-    if (d->Cout > 32) return dispatch_wgrad_n<T, 64>(d, s);
-    return dispatch_wgrad_n<T, 32>(d, s);
+int dispatch_wgrad(const DykWgradDesc* d, hipStream_t s, int* query) {
+    if (d->Cout > 64) return dispatch_wgrad_n<T, 128>(d, s, query);
+    if (d->Cout > 32) return dispatch_wgrad_n<T, 64>(d, s, query);
+    return dispatch_wgrad_n<T, 32>(d, s, query);
+}
+
+// one block per 1024-element chunk of one table entry (binary search over chunk_begin, as dyk_transpose_taps)
+__global__ __launch_bounds__(256) void grad_reduce_kernel(float* __restrict__ G, const float* __restrict__ part,
+                                                          const DykGradReduceEntry* __restrict__ tab, int n_entries) {
+    const int cidx = blockIdx.x;
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].chunk_begin <= cidx) lo = mid; else hi = mid - 1;
+    }
+    const DykGradReduceEntry e = tab[lo];
+    const long i = ((long)(cidx - e.chunk_begin) * 256 + threadIdx.x) * 4;
+    if (i >= e.n) return;
+    const float* p = part + e.part_off + i;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 4 <= e.splits; s += 4) {                 // four planes in flight
+        const float4 v0 = *(const float4*)(p + (long)s * e.plane), v1 = *(const float4*)(p + (long)(s + 1) * e.plane);
+        const float4 v2 = *(const float4*)(p + (long)(s + 2) * e.plane), v3 = *(const float4*)(p + (long)(s + 3) * e.plane);
+        acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+        acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < e.splits; ++s) {
+        const float4 v = *(const float4*)(p + (long)s * e.plane);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4* g = (float4*)(G + e.g_off + i);
+    float4 o = *g;
+    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+    *g = o;
 }
 
 }  // namespace
@@ -440,8 +494,27 @@ extern "C" int dyk_conv_wgrad(const DykWgradDesc* d, void* stream) {
     if (d->ldx < (d->Cin + epv - 1) / epv * epv || d->lddy < (d->Cout + epv - 1) / epv * epv) return DYK_ERR_ARG;
     if (((uintptr_t)d->x % 16) || ((uintptr_t)d->dy % 16)) return DYK_ERR_ARG;
     if ((long)d->B * d->Ho * d->Wo >= (1L << 31)) return DYK_ERR_ARG;
+    if (d->part && (d->part_stride < (int64_t)d->Cout * (d->lddw > 0 ? d->lddw : d->Cin))) return DYK_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == DYK_BF16) return dispatch_wgrad<bf16_t>(d, s);
-    if (d->dtype == DYK_F32) return dispatch_wgrad<float>(d, s);
+    if (d->dtype == DYK_BF16) return dispatch_wgrad<bf16_t>(d, s, nullptr);
+    if (d->dtype == DYK_F32) return dispatch_wgrad<float>(d, s, nullptr);
     return DYK_ERR_ARG;
+}
+
+extern "C" int dyk_conv_wgrad_splits(const DykWgradDesc* d) {
+    if (!d || d->ntaps <= 0 || d->ntaps > DYK_MAX_TAPS || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0 || d->Cin <= 0)
+        return DYK_ERR_ARG;
+    int q = 0;
+    int rc = DYK_ERR_ARG;
+    if (d->dtype == DYK_BF16) rc = dispatch_wgrad<bf16_t>(d, nullptr, &q);
+    else if (d->dtype == DYK_F32) rc = dispatch_wgrad<float>(d, nullptr, &q);
+    return rc == DYK_OK ? q : rc;
+}
+
+extern "C" int dyk_grad_reduce(float* G, const float* part, const DykGradReduceEntry* tab, int32_t n_entries,
+                               int32_t total_chunks, void* stream) {
+    if (!G || !part || !tab || n_entries <= 0 || total_chunks <= 0) return DYK_ERR_ARG;
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(total_chunks), dim3(256), 0, (hipStream_t)stream, G, part, tab, n_entries);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
 }

@@ -206,6 +206,8 @@ extern "C" int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream,
             case DYK_OP_DW_FWD: rc = dyk_dwconv_fwd((const DykDwDesc*)dp, stream); break;
             case DYK_OP_DW_DGRAD: rc = dyk_dwconv_dgrad((const DykDwDesc*)dp, stream); break;
             case DYK_OP_DW_WGRAD: rc = dyk_dwconv_wgrad((const DykDwDesc*)dp, stream); break;
+            case DYK_OP_GRAD_REDUCE:
+                rc = dyk_grad_reduce((float*)m->p[0], (const float*)m->p[1], (const DykGradReduceEntry*)m->p[2], m->i[0], m->i[1], stream); break;
             case DYK_OP_BN_FWD_FUSED:
                 rc = dyk_bn_finalize_act_fwd((const DykBnFinalizeDesc*)m->p[0], (const DykEwDesc*)m->p[1], stream); break;
             case DYK_OP_CAST_PAD_ROWS:
@@ -257,7 +259,7 @@ extern "C" int dyk_run_commands_overlap(const DykCommand* cmds, int32_t n, void*
     };
     // issue one command on `target` (weight gradients: on the side stream behind an event of `target`)
     auto issue = [&](int32_t k, hipStream_t target) -> int {
-        if ((cmds[k].op == DYK_OP_WGRAD || cmds[k].op == DYK_OP_DW_WGRAD) && !(cmds[k].lane & 8)) {
+        if ((cmds[k].op == DYK_OP_WGRAD || cmds[k].op == DYK_OP_DW_WGRAD || cmds[k].op == DYK_OP_GRAD_REDUCE) && !(cmds[k].lane & 8)) {
             hipEvent_t e = ring[ev++ & 63];
             if (hipEventRecord(e, target) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return DYK_ERR_HIP;
             target = side;

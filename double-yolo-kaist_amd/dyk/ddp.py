@@ -39,6 +39,9 @@ class GradAllReduce:
             for k in range(1, len(marks)):
                 c_end, layer_done = marks[k][0], marks[k - 1][1]     # commands [.., c_end) finish layer `layer_done`
                 lo = min((o for l, o in first_off.items() if l >= layer_done), default=hi)
+                cut_ok = getattr(plan, "bwd_cut_ok", None)          # atomic-free wgrads: cut only where the planes are folded
+                if cut_ok is not None and c_end not in cut_ok and k != len(marks) - 1:
+                    continue
                 if (hi - lo >= target and c_end > c_prev) or k == len(marks) - 1:
                     lo = 0 if k == len(marks) - 1 else lo
                     segs.append((c_prev, c_end, lo, hi))

@@ -21,7 +21,7 @@ MAX_TAPS = 25
  OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_SE_POOL, OP_SE_FC_FWD, OP_SE_FC_BWD,
  OP_SE_SCALE, OP_BN_BWD_PARAMS, OP_BN_FOLD, OP_WFUSE_WEIGHTS, OP_WFUSE_BWD_PARAMS, OP_HEAD_PERMUTE_FWD,
  OP_HEAD_PERMUTE_BWD, OP_PATCH_GATHER, OP_MEMSET, OP_YOLO_DECODE, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD,
- OP_CAST_PAD_ROWS, OP_BN_FWD_FUSED) = range(1, 31)
+ OP_CAST_PAD_ROWS, OP_BN_FWD_FUSED, OP_GRAD_REDUCE) = range(1, 32)
 
 
 class DykLibraryError(RuntimeError):
@@ -51,7 +51,7 @@ class DykConvDesc(ctypes.Structure):
 
 class DykWgradDesc(ctypes.Structure):
     _fields_ = [
-        ("x", _vp), ("dy", _vp), ("dw", _vp),
+        ("x", _vp), ("dy", _vp), ("dw", _vp), ("part", _vp), ("part_stride", _i64),
         ("dtype", _i32), ("ldx", _i32), ("lddy", _i32),
         ("B", _i32), ("Hi", _i32), ("Wi", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32), ("Cout", _i32),
         ("isy", _i32), ("isx", _i32), ("ntaps", _i32),
@@ -96,6 +96,11 @@ class DykDwDesc(ctypes.Structure):
                 ("dtype", _i32), ("ldx", _i32), ("ldy", _i32),
                 ("B", _i32), ("Hi", _i32), ("Wi", _i32), ("Ho", _i32), ("Wo", _i32), ("C", _i32),
                 ("k", _i32), ("stride", _i32), ("pad", _i32), ("flags", _i32), ("stats_slots", _i32)]
+
+
+class DykGradReduceEntry(ctypes.Structure):
+    _fields_ = [("g_off", _i64), ("part_off", _i64), ("plane", _i64), ("n", _i32), ("splits", _i32),
+                ("chunk_begin", _i32), ("_pad", _i32)]
 
 
 class DykMiscDesc(ctypes.Structure):
@@ -146,6 +151,8 @@ SIGNATURES = {
     "dyk_error_string": (ctypes.c_char_p, [_i32]),
     "dyk_conv_igemm": (_i32, [_P(DykConvDesc), _vp]),
     "dyk_conv_wgrad": (_i32, [_P(DykWgradDesc), _vp]),
+    "dyk_conv_wgrad_splits": (_i32, [_P(DykWgradDesc)]),
+    "dyk_grad_reduce": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dyk_bn_finalize": (_i32, [_P(DykBnFinalizeDesc), _vp]),
     "dyk_bn_finalize_act_fwd": (_i32, [_P(DykBnFinalizeDesc), _P(DykEwDesc), _vp]),
     "dyk_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp]),

@@ -899,6 +899,30 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         memset_desc.n, memset_desc.i[0] = hi - lo, 0
         later(lambda ms=memset_desc, lo=lo: ms.p.__setitem__(0, ws.ptr(lo)))
 
+    # ---------------------------------------------------------------- materialise
+    for a in plan.arenas.values():
+        a.materialize(device)
+    if training:
+        stats_memset.p[0] = st_arena.ptr(0)
+        stats_memset.n, stats_memset.i[0] = max(st_arena.size, 256), 0
+    for fn in pending:
+        fn()
+    if not dry and os.environ.get("DYK_AUTOTUNE", "1") != "0":
+        autotune(plan, _TUNE_CACHE)
+    plan.part = None
+    plan.bwd_cut_ok = None
+    if training and not dry and os.environ.get("DYK_WGRAD_PARTIALS", "1") != "0":
+        # the two backbones of a dual-stream net are enqueued interleaved (dyk_run_commands_overlap): a reduction must
+        # not span the boundary between them, or it could run before weight gradients that precede it in the list
+        force = set()
+        if second is not None and 0 < second < len(defs):
+            force.add(second - 1)
+            for j in range(second, len(defs)):
+                if defs[j]["type"] in ("route", "shortcut") and any(q < second for q in mods[j].layers):
+                    force.add(j - 1)
+                    break
+        _setup_wgrad_partials(plan, store, device, force)
+
     # ---------------------------------------------------------------- branch lanes (dual-stream nets)
     # sections [second, F) -- the second backbone up to the first section that reads anything of the first one -- are
     # independent of sections [0, second): tag them for the branch stream of dyk_run_commands_overlap
@@ -928,21 +952,11 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     # sections differentiated stay on their own streams instead (measured on the per-stream timeline, tools/trace_timeline.py)
     if training:
         wg = [q for q, (op, _) in enumerate(plan.bwd) if op in (L.OP_WGRAD, L.OP_DW_WGRAD)]
-        ntail = int(os.environ.get("DYK_WGRAD_INPLACE_TAIL", "20"))
+        ntail = 0 if plan.part is not None else int(os.environ.get("DYK_WGRAD_INPLACE_TAIL", "20"))
         for q in wg[len(wg) - ntail:] if ntail > 0 else []:
             plan.bwd_lanes[q] = plan.bwd_lanes.get(q, 0) | 8
 
-    # ---------------------------------------------------------------- materialise
-    for a in plan.arenas.values():
-        a.materialize(device)
-    if training:
-        stats_memset.p[0] = st_arena.ptr(0)
-        stats_memset.n, stats_memset.i[0] = max(st_arena.size, 256), 0
-    for fn in pending:
-        fn()
     plan.finalize()
-    if not dry and os.environ.get("DYK_AUTOTUNE", "1") != "0":
-        autotune(plan, _TUNE_CACHE)
     plan.info = info
     plan.grads = grads if training else {}
     plan.outs = outs
@@ -953,6 +967,71 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
 
 
 # ======================================================================================
+def _setup_wgrad_partials(plan, store, device, force_layers=()):
+    """Atomic-free weight gradients: every K split of a weight-gradient launch gets its own plane of a partial buffer
+    (dyk_conv_wgrad_splits planes per layer), and a table-driven dyk_grad_reduce folds the planes into the flat gradient
+    buffer every ~1/16 of the parameters (at section boundaries, so that the data-parallel exchange can cut there).
+    Rewrites plan.bwd / plan.bwd_marks; stems (gathered-patch layout) and single-split launches keep the atomics."""
+    lib = L.load()
+    G0 = store.G.data_ptr()
+    items, total = {}, 0
+    for q, (op, d) in enumerate(plan.bwd):
+        if op != L.OP_WGRAD or d.lddw > 0:
+            continue
+        splits = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
+        if splits < 2:
+            continue
+        plane = d.ntaps * d.Cout * d.Cin
+        if plane % 4:
+            continue
+        items[q] = dict(d=d, splits=splits, plane=plane, part_off=total, g_off=(d.dw - G0) // 4)
+        total += splits * plane
+    if not items:
+        return
+    plan.part = torch.empty(total, dtype=torch.float32, device=device)
+    plan.part_bytes = total * 4
+    base = plan.part.data_ptr()
+    for it in items.values():
+        d = it["d"]
+        d.part, d.part_stride, d.splits = base + 4 * it["part_off"], it["plane"], it["splits"]
+    target = sum(it["plane"] for it in items.values()) // 16
+
+    def reduce_cmd(entries):
+        arr = (L.DykGradReduceEntry * len(entries))()
+        chunks = 0
+        for i, it in enumerate(entries):
+            arr[i].g_off, arr[i].part_off, arr[i].plane = it["g_off"], it["part_off"], it["plane"]
+            arr[i].n, arr[i].splits, arr[i].chunk_begin = it["plane"], it["splits"], chunks
+            chunks += (it["plane"] + 1023) // 1024
+        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        m = L.DykMiscDesc()
+        m.p[0], m.p[1], m.p[2] = G0, base, tab.data_ptr()
+        m.i[0], m.i[1] = len(entries), chunks
+        plan._keep += [tab, m]
+        return (L.OP_GRAD_REDUCE, m)
+
+    starts = {}
+    for cnt, layer in plan.bwd_marks:
+        starts.setdefault(cnt, []).append(layer)
+    new, marks, cut_ok, pend, acc = [], [], set(), [], 0
+    for idx in range(len(plan.bwd) + 1):
+        if idx in starts:
+            if pend and (acc >= target or idx == len(plan.bwd) or any(l in force_layers for l in starts[idx])):
+                new.append(reduce_cmd(pend))
+                pend, acc = [], 0
+            if not pend:
+                cut_ok.add(len(new))
+            for layer in starts[idx]:
+                marks.append((len(new), layer))
+        if idx < len(plan.bwd):
+            new.append(plan.bwd[idx])
+            if idx in items:
+                pend.append(items[idx])
+                acc += items[idx]["plane"]
+    assert not pend
+    plan.bwd, plan.bwd_marks, plan.bwd_cut_ok = new, marks, cut_ok
+
+
 _TUNE_CACHE = {}     # process-wide: the same problem always runs the same tile configuration (bit-reproducible
                      # results across plans / model instances within a process)
 def _conv_candidates(d):

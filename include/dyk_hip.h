@@ -130,6 +130,11 @@ typedef struct DykWgradDesc {
     const void* x;
     const void* dy;
     float* dw;
+    float* part;                    /* NULL: partial tiles are added to dw with fp32 atomics.  Else: K split s stores its
+                                       tiles (plain stores, same [tap][Cout][Cin] layout as dw) into the plane
+                                       part + s * part_stride; dyk_grad_reduce later adds the planes to dw --
+                                       no atomics, bit-reproducible.  Needs the split count of dyk_conv_wgrad_splits. */
+    int64_t part_stride;            /* floats between the planes of consecutive splits */
     int32_t dtype;
     int32_t ldx, lddy;
     int32_t B, Hi, Wi, Cin, Ho, Wo, Cout;
@@ -145,6 +150,19 @@ typedef struct DykWgradDesc {
 } DykWgradDesc;
 
 int dyk_conv_wgrad(const DykWgradDesc* desc, void* stream);
+/* Number of K splits (> 0) dyk_conv_wgrad will use for this descriptor (its `splits` and `tune` included): the
+ * number of planes a `part` buffer must hold.  Negative = error code. */
+int dyk_conv_wgrad_splits(const DykWgradDesc* desc);
+
+/* G[g_off + i] += sum_s part[part_off + s * plane + i], i < n, for every entry of a device table: folds the per-split
+ * planes written by dyk_conv_wgrad into the flat gradient buffer, one launch for many layers.  n is a multiple of 4;
+ * chunk_begin = exclusive prefix sum of ceil(n / 1024) over the entries, total_chunks its total. */
+typedef struct DykGradReduceEntry {
+    int64_t g_off, part_off, plane;
+    int32_t n, splits, chunk_begin, _pad;
+} DykGradReduceEntry;
+int dyk_grad_reduce(float* G, const float* part, const DykGradReduceEntry* table_dev, int32_t n_entries,
+                    int32_t total_chunks, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Channels-last elementwise / per-channel kernels share one descriptor; each entry point
@@ -394,6 +412,7 @@ enum {
     DYK_OP_DW_WGRAD = 28,       /* DykDwDesc -> dyk_dwconv_wgrad */
     DYK_OP_CAST_PAD_ROWS = 29,  /* Misc: p0=src p1=dst i0=R i1=C i2=Cpad i3=dtype */
     DYK_OP_BN_FWD_FUSED = 30,   /* Misc: p0=DykBnFinalizeDesc* p1=DykEwDesc* -> dyk_bn_finalize_act_fwd */
+    DYK_OP_GRAD_REDUCE = 31,    /* Misc: p0=G p1=part p2=table i0=n_entries i1=total_chunks -> dyk_grad_reduce */
     DYK_OP_COUNT_
 };
 
