@@ -314,3 +314,58 @@ def test_dgrad_with_fused_batchnorm_backward_reduce(dtype, act):
     # illegal flag combinations are rejected
     d.flags = L.EPI_BNBWD | L.EPI_ACCUM
     assert L.load().dyk_conv_igemm(ctypes.byref(d), None) != 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wgrad_plane_mode_and_grad_reduce(dtype):
+    """DykWgradDesc.part: every K split stores its tiles into its own plane, dyk_grad_reduce folds the planes into the
+    gradient buffer (accumulating).  Same values as the atomic mode, and bit-identical from run to run."""
+    import ctypes
+    from dyk import lib as L
+    from dyk import ops
+    B, Cin, Cout, H, W, k = 4, 64, 96, 24, 40, 3
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+    xd, dyd = ops.to_nhwc(x.cuda(), dtype), ops.to_nhwc(dy.cuda(), dtype)
+    dw_atomic = ops.conv2d_wgrad(xd, dyd, k, 1, 1)                       # [k*k][Cout][Cin], fp32 atomics
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, padding=1).permute(2, 3, 0, 1).reshape(k * k, Cout, Cin)
+    assert (dw_atomic.cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+
+    d = L.DykWgradDesc()
+    d.x, d.dy = xd.data_ptr(), dyd.data_ptr()
+    d.dtype = ops.dtype_code(dtype)
+    d.ldx, d.lddy = Cin, Cout
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, Cin, H, W, Cout
+    d.isy = d.isx = 1
+    taps = ops.fwd_taps(k, 1)
+    d.ntaps = len(taps)
+    for i, (ty, tx, wt) in enumerate(taps):
+        d.tdy[i], d.tdx[i], d.twt[i] = ty, tx, wt
+    lib = L.load()
+    plane = k * k * Cout * Cin
+    outs = []
+    for tune in (2, 2 | (2 << 8)):                                        # 4-wave and K-grouped workgroups
+        d.tune, d.splits, d.part = tune, 0, None
+        splits = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
+        assert splits >= 2
+        part = torch.full((splits * plane,), float("nan"), device="cuda")      # every plane must be fully written
+        G = torch.ones(plane + 64, device="cuda")                         # reduce accumulates onto existing values
+        d.dw, d.part, d.part_stride, d.splits = G.data_ptr() + 64 * 4, part.data_ptr(), plane, splits
+        e = (L.DykGradReduceEntry * 1)()
+        e[0].g_off, e[0].part_off, e[0].plane, e[0].n, e[0].splits, e[0].chunk_begin = 64, 0, plane, plane, splits, 0
+        tab = torch.frombuffer(bytearray(bytes(e)), dtype=torch.uint8).cuda()
+        runs = []
+        for _ in range(2):
+            G.fill_(1.0)
+            part.fill_(float("nan"))
+            L.check(lib.dyk_conv_wgrad(ctypes.byref(d), None), "dyk_conv_wgrad(part)")
+            L.check(lib.dyk_grad_reduce(G.data_ptr(), part.data_ptr(), tab.data_ptr(), 1, (plane + 1023) // 1024, None), "dyk_grad_reduce")
+            runs.append(G.clone())
+        assert torch.equal(runs[0], runs[1]), "plane mode must be bit-reproducible"
+        assert torch.all(runs[0][:64] == 1.0)
+        got = (runs[0][64:] - 1.0).view(k * k, Cout, Cin)
+        assert (got.cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item(), hex(tune)
+        outs.append(got)
