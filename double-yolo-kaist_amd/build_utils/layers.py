@@ -185,3 +185,65 @@ class Mish(nn.Module):
 
 MemoryEfficientSwish = Swish
 MemoryEfficientMish = Mish
+
+
+class ResBlock(nn.Module):
+    """n x (1x1 ConvBnActivation -> 3x3 ConvBnActivation [+ input]) (ref :125-145; no cfg section creates it).
+    Built from the same HIP-backed ConvBnActivation blocks; the skip add is one dyk_axpby."""
+
+    def __init__(self, in_channels, filter_1, out_channels, block_nums=1, activation="mish", shortcut=True):
+        super(ResBlock, self).__init__()
+        self.shortcut = shortcut
+        self.module_list = nn.ModuleList()
+        for _ in range(block_nums):
+            self.module_list.append(nn.ModuleList([
+                ConvBnActivation(in_channels, filter_1, kernel_size=1, stride=1, pad=1, activation=activation, bn=True),
+                ConvBnActivation(filter_1, out_channels, kernel_size=3, stride=1, pad=1, activation=activation, bn=True)]))
+
+    def forward(self, x):
+        for pair in self.module_list:
+            y = pair[1](pair[0](x))
+            x = _F().weighted_fusion(y, [x], None, 2) if self.shortcut else y
+        return x
+
+
+class SEInceptionFusion(nn.Module):
+    """FeatureConcat -> 1x1 ConvBnActivation [-> Inception] [-> SqueezeExcitation] (ref :193-215; no cfg section
+    creates it -- the `*_seinc` cfgs spell the same thing out as [route] / [convolutional] / [inception] / [se])."""
+
+    def __init__(self, in_channels, out_channels, layers, inception=False, icp_param_list=(), tmse=False, squeeze_factor=4):
+        super(SEInceptionFusion, self).__init__()
+        self.concat = FeatureConcat(layers)
+        self.enhance = nn.ModuleList([ConvBnActivation(in_channels, out_channels, kernel_size=1)])
+        if inception:
+            self.enhance.append(Inception(out_channels, *icp_param_list))
+        if tmse:
+            self.enhance.append(SqueezeExcitation(out_channels, squeeze_factor))
+
+    def forward(self, x, outputs):
+        y = self.concat(x, outputs)
+        for m in self.enhance:
+            y = m(y)
+        return y
+
+
+class MixConv2d(nn.Module):
+    """Mixed-kernel convolution (ref :237-268): output channels split over kernel sizes k, either evenly
+    ('equal_ch') or so that every group has about the same number of weights ('equal_params').  Parameters and
+    state_dict keys (`m.<g>.weight/bias`) as in the reference; used by none of its cfgs, so the forward is not built."""
+
+    def __init__(self, in_ch, out_ch, k=(3, 5, 7), stride=1, dilation=1, bias=True, method="equal_params"):
+        super(MixConv2d, self).__init__()
+        n = len(k)
+        if method == "equal_ch":
+            idx = torch.linspace(0, n - 1e-6, out_ch).floor()          # ref :246 (same group boundaries)
+            ch = [int((idx == g).sum()) for g in range(n)]
+        else:
+            # channels c_g with c_g * k_g^2 equal for all groups and sum(c_g) = out_ch: c_g = out_ch * k_g^-2 / sum_j k_j^-2
+            inv = [1.0 / (kk * kk) for kk in k]
+            ch = [int(round(out_ch * v / sum(inv))) for v in inv]
+            ch[0] += out_ch - sum(ch)
+        self.m = nn.ModuleList([nn.Conv2d(in_ch, ch[g], k[g], stride, k[g] // 2, dilation=dilation, bias=bias) for g in range(n)])
+
+    def forward(self, x):
+        raise NotImplementedError("MixConv2d is not created by any cfg section of the reference; its forward is not built")

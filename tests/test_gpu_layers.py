@@ -126,3 +126,35 @@ def test_depthwise_separable_block(stride):
     for j in (1, 4):
         _close(blk.conv[j].running_mean, ref_blk[j].running_mean, 1e-5)
         _close(blk.conv[j].running_var, ref_blk[j].running_var, 1e-5)
+
+
+def test_compat_blocks_resblock_and_seinception_fusion():
+    """ResBlock / SEInceptionFusion (reference layers.py:125-215; created by no cfg section) run on the HIP operator
+    surface and agree with the same blocks built from torch modules; MixConv2d keeps the reference's channel split."""
+    from build_utils.layers import MixConv2d, ResBlock, SEInceptionFusion
+    torch.manual_seed(9)
+    x = torch.randn(2, 32, 12, 20)
+
+    def ref_cba(cba, t):                       # ConvBnActivation on the CPU, eval mode
+        y = F.conv2d(t, cba.conv[0].weight, None, 1, cba.conv[0].padding)
+        y = F.batch_norm(y, cba.conv[1].running_mean, cba.conv[1].running_var, cba.conv[1].weight, cba.conv[1].bias, False, 0.1, 1e-5)
+        return F.mish(y) if cba.act_name == "mish" else F.leaky_relu(y, 0.1)
+
+    rb = ResBlock(32, 16, 32, block_nums=2).eval()
+    with torch.no_grad():
+        for m in rb.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+        ref = x
+        for pair in rb.module_list:
+            ref = ref + ref_cba(pair[1], ref_cba(pair[0], ref))
+        _close(rb.cuda()(x.cuda()), ref, 1e-4)
+    fus = SEInceptionFusion(64, 64, [0, 1], inception=True, icp_param_list=(16, 24, 24, 12, 12, 12), tmse=True).eval()
+    outs = [torch.randn(2, 32, 12, 20), torch.randn(2, 32, 12, 20)]
+    with torch.no_grad():
+        y = fus.cuda()(None, [o.cuda() for o in outs])
+    assert y.shape == (2, 64, 12, 20) and bool(torch.isfinite(y).all())
+    assert [c.out_channels for c in MixConv2d(32, 64).m] == [41, 15, 8]
+    assert [c.out_channels for c in MixConv2d(32, 64, method="equal_ch").m] == [22, 21, 21]
+    with pytest.raises(NotImplementedError):
+        MixConv2d(32, 64)(x)
