@@ -113,6 +113,116 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DykDwDesc d, int CVB) {
     }
 }
 
+// Stride-1 fast path of the kernel above: a thread produces XT = 4 neighbouring pixels of a row for its 8 channels and
+// keeps the (4 + K - 1) source vectors of each kernel row in registers: (K + 3) / 4 loads per output and row instead of
+// K (2 x fewer for 3x3, 2.5 x fewer for 5x5), weights of a kernel row read once per strip.
+template <typename T, int K, bool GRAD>
+__global__ __launch_bounds__(256) void dwconv_strip_kernel(DykDwDesc d, int CVB) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    constexpr int XT = 4, NS = XT + K - 1;
+    __shared__ float red[256 * 2 * 8];
+    const int PY = 256 / CVB;
+    const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
+    const int cv = blockIdx.x * CVB + tx;
+    const int c = cv * EPV;
+    const bool active = c < d.C;
+    const T* __restrict__ x = GRAD ? (const T*)d.y : (const T*)d.x;     // tensor read
+    T* __restrict__ y = GRAD ? (T*)d.x : (T*)d.y;                       // tensor written
+    const int ld_src = GRAD ? d.ldy : d.ldx, ld_dst = GRAD ? d.ldx : d.ldy;
+    const int pad = d.pad;
+    const int H = d.Hi, W = d.Wi;                  // stride 1: source and destination extents differ only by k - 1 - 2 pad
+    const int Hout = GRAD ? d.Hi : d.Ho, Wout = GRAD ? d.Wi : d.Wo;
+    const int Hsrc = GRAD ? d.Ho : d.Hi, Wsrc = GRAD ? d.Wo : d.Wi;
+    (void)H; (void)W;
+    const bool accum = d.flags & DYK_EW_ACCUM;
+    const bool stats = (!GRAD) && d.stats != nullptr;
+    float s1[EPV], s2[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) s1[j] = s2[j] = 0.f;
+    if (active) {
+        const int nrows = d.B * Hout;
+        for (int row = blockIdx.y; row < nrows; row += gridDim.y) {
+            const int b = row / Hout, yo = row - b * Hout;
+            for (int xo0 = ty * XT; xo0 < Wout; xo0 += PY * XT) {
+                float acc[XT][EPV];
+#pragma unroll
+                for (int o = 0; o < XT; ++o)
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) acc[o][j] = 0.f;
+                // source column of strip slot 0:  forward xs = xo + kw - pad ; gradient xs = xo + pad - kw
+                const int xbase = GRAD ? xo0 + pad - (K - 1) : xo0 - pad;
+#pragma unroll
+                for (int kh = 0; kh < K; ++kh) {
+                    const int ys = GRAD ? yo + pad - kh : yo + kh - pad;
+                    if (ys < 0 || ys >= Hsrc) continue;
+                    float wv[K][EPV];
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw) {
+                        const float* wp = d.w + (long)(kh * K + kw) * d.C + c;
+                        const float4 w0 = *(const float4*)wp;
+                        wv[kw][0] = w0.x; wv[kw][1] = w0.y; wv[kw][2] = w0.z; wv[kw][3] = w0.w;
+                        if (EPV == 8) {
+                            const float4 w1 = *(const float4*)(wp + 4);
+                            wv[kw][4] = w1.x; wv[kw][5] = w1.y; wv[kw][6] = w1.z; wv[kw][7] = w1.w;
+                        }
+                    }
+                    const T* srow = x + ((long)b * Hsrc + ys) * Wsrc * ld_src + c;
+#pragma unroll
+                    for (int sl = 0; sl < NS; ++sl) {
+                        const int xs = xbase + sl;
+                        if (xs < 0 || xs >= Wsrc) continue;
+                        float xv[EPV];
+                        vec_unpack<T>(*(const uint4*)(srow + (long)xs * ld_src), xv);
+#pragma unroll
+                        for (int o = 0; o < XT; ++o) {
+                            const int kw = GRAD ? o + (K - 1) - sl : sl - o;       // compile-time after unrolling
+                            if (kw < 0 || kw >= K) continue;
+#pragma unroll
+                            for (int j = 0; j < EPV; ++j) acc[o][j] += xv[j] * wv[kw][j];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < XT; ++o) {
+                    const int xo = xo0 + o;
+                    if (xo >= Wout) break;
+                    if (stats) {
+#pragma unroll
+                        for (int j = 0; j < EPV; ++j) { s1[j] += acc[o][j]; s2[j] += acc[o][j] * acc[o][j]; }
+                    }
+                    T* yp = y + ((long)row * Wout + xo) * ld_dst + c;
+                    if (accum) {
+                        float old[EPV];
+                        vec_unpack<T>(*(const uint4*)yp, old);
+#pragma unroll
+                        for (int j = 0; j < EPV; ++j) acc[o][j] += old[j];
+                    }
+                    *(uint4*)yp = vec_pack<T>(acc[o]);
+                }
+            }
+        }
+    }
+    if (stats) {
+        float* mine = red + threadIdx.x * 16;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) { mine[j] = s1[j]; mine[8 + j] = s2[j]; }
+        __syncthreads();
+        if (ty == 0 && active) {
+            for (int q = 1; q < PY; ++q) {
+                const float* o = red + (q * CVB + tx) * 16;
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) { s1[j] += o[j]; s2[j] += o[8 + j]; }
+            }
+            double* st = d.stats + (size_t)(blockIdx.y % (unsigned)(d.stats_slots > 0 ? d.stats_slots : 1)) * 2 * d.C;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                atomicAdd(st + c + j, (double)s1[j]);
+                atomicAdd(st + d.C + c + j, (double)s2[j]);
+            }
+        }
+    }
+}
+
 // dw[t][c] += sum_p dy[p][c] * x[src(p, t)][c].  grid.z = kernel row kh; a thread keeps the K taps of that row for its
 // 8 channels in registers (K*8 accumulators), reads the output-gradient vector of a pixel once and the K input vectors of
 // the row from L1 -- one pass over dy per kernel row instead of one per tap, K x fewer workgroup reductions and atomics.
@@ -140,11 +250,41 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DykDwDesc d, int CVB)
           const int b = row / d.Ho, yo = row - b * d.Ho;
             const int yi = yo * d.stride + kh - d.pad;
             if (yi < 0 || yi >= d.Hi) continue;
+            const T* xrow = x + ((long)b * d.Hi + yi) * d.Wi * d.ldx + c;
+            if (d.stride == 1) {
+                // strips of 4 output pixels: 4 gradient vectors + (4 + K - 1) input vectors per strip and kernel row
+                constexpr int XT = 4;
+                for (int xo0 = ty * XT; xo0 < d.Wo; xo0 += PY * XT) {
+                    float g[XT][EPV];
+#pragma unroll
+                    for (int o = 0; o < XT; ++o) {
+                        if (xo0 + o < d.Wo) vec_unpack<T>(*(const uint4*)(dy + ((long)row * d.Wo + xo0 + o) * d.ldy + c), g[o]);
+                        else {
+#pragma unroll
+                            for (int j = 0; j < EPV; ++j) g[o][j] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < XT + K - 1; ++sl) {
+                        const int xi = xo0 - d.pad + sl;
+                        if (xi < 0 || xi >= d.Wi) continue;
+                        float xv[EPV];
+                        vec_unpack<T>(*(const uint4*)(xrow + (long)xi * d.ldx), xv);
+#pragma unroll
+                        for (int o = 0; o < XT; ++o) {
+                            const int t = sl - o;                  // tap within the kernel row (compile-time after unrolling)
+                            if (t < 0 || t >= K) continue;
+#pragma unroll
+                            for (int j = 0; j < EPV; ++j) acc[t][j] += g[o][j] * xv[j];
+                        }
+                    }
+                }
+                continue;
+            }
           for (int xo = ty; xo < d.Wo; xo += PY) {
             const long p = (long)row * d.Wo + xo;
             float g[EPV];
             vec_unpack<T>(*(const uint4*)(dy + p * d.ldy + c), g);
-            const T* xrow = x + ((long)b * d.Hi + yi) * d.Wi * d.ldx + c;
             const int xi0 = xo * d.stride - d.pad;
 #pragma unroll
             for (int t = 0; t < K; ++t) {
@@ -212,7 +352,10 @@ extern "C" int dyk_dwconv_fwd(const DykDwDesc* d, void* stream) {
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     int gx, gy;
     const int CVB = grid2d(d->C / epv, (long)d->B * d->Ho, &gx, &gy, 4096);
-    if (d->dtype == DYK_BF16)
+    if (d->stride == 1 && (d->k == 3 || d->k == 5) && d->dtype == DYK_BF16) {
+        if (d->k == 3) hipLaunchKernelGGL((dwconv_strip_kernel<bf16_t, 3, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
+        else hipLaunchKernelGGL((dwconv_strip_kernel<bf16_t, 5, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
+    } else if (d->dtype == DYK_BF16)
         hipLaunchKernelGGL((dwconv_kernel<bf16_t, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
     else
         hipLaunchKernelGGL((dwconv_kernel<float, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
@@ -227,7 +370,10 @@ extern "C" int dyk_dwconv_dgrad(const DykDwDesc* d, void* stream) {
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     int gx, gy;
     const int CVB = grid2d(d->C / epv, (long)d->B * d->Hi, &gx, &gy, 4096);
-    if (d->dtype == DYK_BF16)
+    if (d->stride == 1 && (d->k == 3 || d->k == 5) && d->dtype == DYK_BF16) {
+        if (d->k == 3) hipLaunchKernelGGL((dwconv_strip_kernel<bf16_t, 3, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
+        else hipLaunchKernelGGL((dwconv_strip_kernel<bf16_t, 5, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
+    } else if (d->dtype == DYK_BF16)
         hipLaunchKernelGGL((dwconv_kernel<bf16_t, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
     else
         hipLaunchKernelGGL((dwconv_kernel<float, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
