@@ -211,3 +211,21 @@ def step_probe_names():
             "module_list.111.Conv2d.weight", "module_list.112.fc1.weight", "module_list.113.w",
             "module_list.223.Conv2d.weight", "module_list.258.Conv2d.weight", "module_list.258.Conv2d.bias",
             "module_list.280.Conv2d.bias", "module_list.279.BatchNorm2d.running_var"]
+
+
+# ------------------------------------------------------------------------------------------ decode (G7)
+def decode_cases():
+    """YOLOLayer eval decode (reference models.py:234-258) on fixed logits: (name, bf_type, stride, ny, nx, anchors, nc)"""
+    anchors = [[16.0, 32.0], [18.0, 42.0], [22.0, 44.0]]
+    out = []
+    for bf, strides in (("yolov3", (32, 16, 8)), ("yolov4", (8, 16, 32))):
+        for s in strides:
+            out.append(dict(name="%s_s%d" % (bf, s), bf=bf, stride=s, ny=512 // s, nx=640 // s, anchors=anchors, nc=1))
+    out.append(dict(name="yolov4_s16_nc2", bf="yolov4", stride=16, ny=8, nx=10, anchors=anchors, nc=2))
+    return out
+
+
+def decode_logits(case):
+    g = torch.Generator().manual_seed(900 + case["stride"] + (7 if case["bf"] == "yolov4" else 0) + case["nc"])
+    na, no = len(case["anchors"]), 5 + case["nc"]
+    return torch.randn(1, na * no, case["ny"], case["nx"], generator=g) * 1.5

@@ -1,7 +1,7 @@
 """Generate the golden fixtures under tests/golden/ by importing and RUNNING THE REFERENCE
 (/root/reference) in the build container.  Run from the repo root:
 
-    python tests/golden/make_golden.py [parse] [graph] [fwd] [targets] [loss] [nms] [ap] [step]
+    python tests/golden/make_golden.py [parse] [graph] [fwd] [targets] [loss] [decode] [nms] [ap] [step]
 
 The reference never travels to the GPU box; only these small data files do.  Inputs are produced
 by seeded torch CPU generators and parameters by oracle.model.OracleNet.synth_state (a pure

@@ -50,6 +50,18 @@ def run(what, ref_models, ref_utils, ref_parse, ref_metrics, OUT):
         np.savez_compressed(os.path.join(OUT, "targets.npz"), **rec)
         print("targets fixture written (%d arrays)" % len(rec))
 
+    if "decode" in what:
+        rec = {}
+        for case in cases.decode_cases():
+            lay = ref_models.YOLOLayer(np.array(case["anchors"]), case["nc"], (512, 640), case["stride"], case["bf"])
+            lay.eval()
+            with torch.no_grad():
+                io, p = lay(cases.decode_logits(case))
+            rec[case["name"] + "|io"] = io.numpy()
+            assert torch.equal(p, cases.decode_logits(case).view(1, lay.na, lay.no, case["ny"], case["nx"]).permute(0, 1, 3, 4, 2))
+        np.savez_compressed(os.path.join(OUT, "decode.npz"), **rec)
+        print("decode fixture written (%d arrays)" % len(rec))
+
     if "loss" in what:
         rec = {}
         for case in cases.loss_cases():

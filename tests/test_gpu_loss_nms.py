@@ -136,3 +136,17 @@ def test_nms_full_size_properties():
         assert iou.max().item() <= 0.6
         # the top-scoring candidate of the image is always kept first
         assert r[0].item() == int(torch.argmax(p[b, :, 4] * p[b, :, 5]))
+
+
+@pytest.mark.parametrize("case", cases.decode_cases(), ids=lambda c: c["name"])
+def test_yolo_decode_matches_reference_fixture(case):
+    """dyk_yolo_decode through models.YOLOLayer (eval) against the reference's own output on the same logits:
+    row order exact (anchor-major, then y, then x), values to fp32 rounding of exp / sigmoid"""
+    from models import YOLOLayer
+    gold = np.load(os.path.join(GOLDEN, "decode.npz"))
+    lay = YOLOLayer(np.array(case["anchors"]), case["nc"], (512, 640), case["stride"], case["bf"]).cuda().eval()
+    io, p = lay(cases.decode_logits(case).cuda())
+    ref = torch.from_numpy(gold[case["name"] + "|io"])
+    assert io.shape == ref.shape
+    err = ((io.cpu() - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
+    assert err < 3e-6, err

@@ -107,3 +107,17 @@ def test_box_helpers():
     c = torch.tensor([[80., 40., 160., 120.]])
     onms.scale_coords((416, 512), c, (512, 640))
     assert torch.allclose(c, torch.tensor([[100., 46., 200., 146.]]))
+
+
+@pytest.mark.parametrize("case", cases.decode_cases(), ids=lambda c: c["name"])
+def test_yolo_decode_matches_reference(case):
+    """oracle YOLO head decode (models.py:234-258) against the reference YOLOLayer's eval output (fixture decode.npz)"""
+    from oracle.model import OracleNet
+    gold = np.load(os.path.join(GOLDEN, "decode.npz"))
+    net = OracleNet.__new__(OracleNet)
+    net.v4 = case["bf"] == "yolov4"
+    L = dict(na=3, nc=case["nc"], stride=case["stride"], anchors=torch.tensor(case["anchors"]))
+    io, p = net._yolo(L, cases.decode_logits(case), training=False)
+    ref = gold[case["name"] + "|io"]
+    assert io.shape == ref.shape
+    assert np.allclose(io.numpy(), ref, rtol=1e-6, atol=1e-6)
