@@ -3,6 +3,8 @@
 The checker here is plain torch.nn.functional on the CPU (same arithmetic the oracle uses for
 models.py:34-62); the thing under test is reached only through the C ABI.
 """
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -369,3 +371,36 @@ def test_wgrad_plane_mode_and_grad_reduce(dtype):
         got = (runs[0][64:] - 1.0).view(k * k, Cout, Cin)
         assert (got.cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item(), hex(tune)
         outs.append(got)
+
+
+@pytest.mark.parametrize("case", [(16, 128, 128, 64, 80, 3), (16, 1024, 512, 16, 20, 1), (16, 256, 256, 32, 40, 3)])
+def test_conv_at_baseline_size(case):
+    """forward, data gradient and weight gradient of three layers of the target cfg at BASELINE size (batch 16, 512x640
+    input), bf16 operands, against torch CPU fp32 on the same rounded operands; plus linearity in the input
+    (conv(2x) == 2 conv(x) bit for bit: scaling by a power of two commutes with every rounding)."""
+    from dyk import ops
+    B, Cin, Cout, H, W, k = case
+    pad = k // 2
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    dy = torch.randn(B, Cout, H, W, generator=g).bfloat16().float()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    y_ref = F.conv2d(x, w, padding=pad)
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, w, dy, padding=pad)
+    dw_ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=pad)
+    xd, dyd = ops.to_nhwc(x.cuda(), torch.bfloat16), ops.to_nhwc(dy.cuda(), torch.bfloat16)
+    wp = ops.pack_weight(w.cuda(), torch.bfloat16)
+    wpt = ops.pack_weight(w.cuda(), torch.bfloat16, transposed=True)
+    y = ops.conv2d_fwd(xd, wp, k, 1, pad, Cout)
+    err = (ops.to_nchw(y).cpu() - y_ref).abs().max().item()
+    assert err <= 1.2e-2 * max(1.0, y_ref.abs().max().item()), err
+    y2 = ops.conv2d_fwd(ops.to_nhwc((2 * x).cuda(), torch.bfloat16), wp, k, 1, pad, Cout)
+    assert torch.equal(y2.float(), 2 * y.float())
+    dx = ops.conv2d_dgrad(dyd, wpt, k, 1, pad, H, W, Cin)
+    err = (ops.to_nchw(dx).cpu() - dx_ref).abs().max().item()
+    assert err <= 1.2e-2 * max(1.0, dx_ref.abs().max().item()), err
+    dw = ops.conv2d_wgrad(xd, dyd, k, 1, pad)
+    ref = dw_ref.permute(2, 3, 0, 1).reshape(k * k, Cout, Cin)
+    err = (dw.cpu() - ref).abs().max().item()
+    assert err <= 2e-3 * ref.abs().max().item(), err
