@@ -85,7 +85,7 @@ template <int BM, int BN> struct WaveGrid {
     static constexpr int WN = 4 / WM;
     static_assert(BM / WM >= 16 && (BN / WN) % 16 == 0, "unsupported tile");
 };
-template <int BN> constexpr int table_bytes() { return BN * (3 * 4 + 2 * 2) + 1024 + 4 * 32 * 4 + 2 * 128 * 4; }
+template <int BN> constexpr int table_bytes() { return BN * (3 * 4 + 2 * 2) + 1024 + 4 * 32 * 4 + 4 * 2 * 128 * 4; }
 
 // Shared epilogue of the convolution kernels: BN statistics, affine / activation / residual / accumulate, staged
 // coalesced stores.  Called by every thread after the K loop's last barrier (the operand ring is free: sC overlays it).
@@ -111,9 +111,9 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
     const int mlane = (lane >> 4) * 4;
     if (flags & DYK_EPI_STATS) {
         // per-channel sum / sum of squares of the raw accumulators: in-lane over ni, DPP row rotate-adds over the
-        // 16 pixel lanes, LDS atomics across the waves of the workgroup, then ONE fp64 atomic per channel
-        // and workgroup into a replica of the statistics buffer.
-        for (int i = tid; i < 2 * BM; i += 256) s_stat[i] = 0.f;
+        // 16 pixel lanes, one LDS slot per wave (summed in wave order: the forward pass is reproducible -- with LDS
+        // float atomics the order of the adds, and through the chaotic random-weight nets the outputs, changed from
+        // run to run), then ONE fp64 atomic per channel and workgroup into a replica of the statistics buffer.
         __syncthreads();
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -129,8 +129,8 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
                 s2 = row16_sum(s2);
                 if ((lane & 15) == 0) {
                     const int ml = wm * WTM + mi * 16 + mlane + r;
-                    atomicAdd(s_stat + ml, s1);
-                    atomicAdd(s_stat + BM + ml, s2);
+                    s_stat[(wn * 2 + 0) * BM + ml] = s1;
+                    s_stat[(wn * 2 + 1) * BM + ml] = s2;
                 }
             }
         }
@@ -138,8 +138,11 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
         if (tid < 2 * BM) {
             const int ml = tid % BM, which = tid / BM;
             if (m0 + ml < a.Cout) {
+                float tot = 0.f;
+#pragma unroll
+                for (int q = 0; q < WN; ++q) tot += s_stat[(q * 2 + which) * BM + ml];
                 double* st = a.stats + (size_t)(blockIdx.x % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
-                atomicAdd(st + which * a.Cout + m0 + ml, (double)s_stat[tid]);
+                atomicAdd(st + which * a.Cout + m0 + ml, (double)tot);
             }
         }
     }
@@ -288,7 +291,6 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
                     }
                 }
             }
-            for (int i = tid; i < 2 * BM; i += 256) s_stat[i] = 0.f;
             __syncthreads();
             constexpr int EPVT = 16 / eso;                        // elements per 16-byte chunk
             constexpr int cpr = BM / EPVT;                        // chunks per tile row (divides 256: one chunk column per thread)
@@ -329,19 +331,21 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
                     s2[j] += __shfl_xor(s2[j], o, 64);
                 }
             }
-            if (lane < cpr && live) {
+            if (lane < cpr) {                                     // one slot per wave, summed in wave order below
 #pragma unroll
                 for (int j = 0; j < EPVT; ++j) {
-                    atomicAdd(s_stat + cc * EPVT + j, s1[j]);
-                    atomicAdd(s_stat + BM + cc * EPVT + j, s2[j]);
+                    s_stat[(wid * 2 + 0) * BM + cc * EPVT + j] = live ? s1[j] : 0.f;
+                    s_stat[(wid * 2 + 1) * BM + cc * EPVT + j] = live ? s2[j] : 0.f;
                 }
             }
             __syncthreads();
             if (tid < 2 * BM) {
                 const int ml = tid % BM, which = tid / BM;
                 if (m0 + ml < a.Cout) {
+                    const float tot = (s_stat[(0 * 2 + which) * BM + ml] + s_stat[(1 * 2 + which) * BM + ml]) +
+                                      (s_stat[(2 * 2 + which) * BM + ml] + s_stat[(3 * 2 + which) * BM + ml]);
                     double* st = a.stats + (size_t)(blockIdx.x % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
-                    atomicAdd(st + which * a.Cout + m0 + ml, (double)s_stat[tid]);
+                    atomicAdd(st + which * a.Cout + m0 + ml, (double)tot);
                 }
             }
         };
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     int* tap_w = tap_x + 32;                  // [32] weight element offset of a tap: twt*Cout*Cin
     int* tap_dy = tap_w + 32;                 // [32]
     int* tap_dx = tap_dy + 32;                // [32]
-    float* s_stat = (float*)(tap_dx + 32);    // [2][BM] per-workgroup channel sums (STATS epilogue)
+    float* s_stat = (float*)(tap_dx + 32);    // [4][2][BM] per-wave channel sums (STATS / BNBWD epilogues)
     char* sA = smem + TABLE_BYTES;                 // [NSTAGE][A_BYTES]
     char* sB = sA + NSTAGE * A_BYTES;              // [NSTAGE][B_BYTES]
     char* sC = sA;                                 // epilogue staging tile (overlays the ring)
@@ -652,7 +656,7 @@ template <int TH> struct HaloGeom {
     static constexpr int TW = 20, HW = TW + 2, BN = TH * TW, HR = (TH + 2) * HW;
 };
 template <int BM, int TH> constexpr int halo_table_bytes() {
-    return HaloGeom<TH>::BN * 8 + 1024 + 2 * 32 * 4 + 2 * 128 * 4;
+    return HaloGeom<TH>::BN * 8 + 1024 + 2 * 32 * 4 + 4 * 2 * 128 * 4;
 }
 
 template <typename T, int BM, int TH, int BKB>
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     char* sink = (char*)(t_res + BN);         // [1024]
     int* tap_w = (int*)(sink + 1024);         // [32] weight element offset of a tap
     int* tap_h = tap_w + 32;                  // [32] halo-row offset of a tap: dy*HW + dx
-    float* s_stat = (float*)(tap_h + 32);     // [2][BM]
+    float* s_stat = (float*)(tap_h + 32);     // [4][2][BM]
     char* sA = smem + TABLE_BYTES;            // [NA][A_BYTES]
     char* sH = sA + NA * A_BYTES;             // [2][HB_BYTES]
     int* t_hsrc = (int*)(sH + 2 * HB_BYTES);  // [NB*64] per (instruction, lane): source element offset or -1 (zero page)

@@ -337,8 +337,7 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(DykSeFcDesc d) {
         if (l16 == 0) {
             const float t2 = acc + d.b2[c];
             const float g = (t2 > -3.f && t2 < 3.f) ? d.dscale[(long)b * d.C + c] * (1.f / 6.f) : 0.f;
-            dt2[c] = g;
-            if (g != 0.f) unsafeAtomicAdd(d.db2 + c, g);
+            dt2[c] = g;                                   // (db2 = sum over the batch: se_fc_wgrad_kernel, in image order)
         }
     }
     __syncthreads();
@@ -357,7 +356,6 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(DykSeFcDesc d) {
     for (int j = threadIdx.x; j < d.Cs; j += blockDim.x) {
         const float g = t1[j] > 0.f ? dt1[j] : 0.f;
         dt1[j] = g;
-        if (g != 0.f) unsafeAtomicAdd(d.db1 + j, g);
     }
     __syncthreads();
     // park what the weight-gradient kernel needs: h | dt1 | dt2
@@ -379,9 +377,18 @@ __global__ __launch_bounds__(256) void se_fc_wgrad_kernel(DykSeFcDesc d) {
     const float* h = d.ws;
     const float* dt1 = d.ws + (long)d.B * d.Cs;
     const float* dt2 = d.ws + 2L * d.B * d.Cs;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < 2 * n; i += (long)gridDim.x * blockDim.x) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < 2 * n + d.C + d.Cs; i += (long)gridDim.x * blockDim.x) {
         float acc = 0.f;
-        if (i < n) {
+        if (i >= 2 * n) {                       // bias gradients: plain sums over the batch in image order (reproducible)
+            const long k = i - 2 * n;
+            if (k < d.C) {
+                for (int b = 0; b < d.B; ++b) acc += dt2[(long)b * d.C + k];
+                d.db2[k] += acc;
+            } else {
+                for (int b = 0; b < d.B; ++b) acc += dt1[(long)b * d.Cs + (k - d.C)];
+                d.db1[k - d.C] += acc;
+            }
+        } else if (i < n) {
             const int c = (int)(i / d.Cs), j = (int)(i - (long)c * d.Cs);
             for (int b = 0; b < d.B; ++b) acc += dt2[(long)b * d.C + c] * h[(long)b * d.Cs + j];
             d.dw2[i] += acc;
@@ -626,7 +633,7 @@ extern "C" int dyk_se_fc_bwd(const DykSeFcDesc* d, void* stream) {
         return DYK_ERR_ARG;
     const size_t lds = (size_t)(2 * d->C + 3 * d->Cs) * sizeof(float);
     hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(d->B), dim3(1024), lds, (hipStream_t)stream, *d);
-    const long n2 = 2L * d->C * d->Cs;
+    const long n2 = 2L * d->C * d->Cs + d->C + d->Cs;
     hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3((unsigned)((n2 + 255) / 256 < 4096 ? (n2 + 255) / 256 : 4096)), dim3(256), 0,
                        (hipStream_t)stream, *d);
     DYK_LAUNCH_CHECK();

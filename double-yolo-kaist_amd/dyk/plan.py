@@ -971,17 +971,17 @@ def _setup_wgrad_partials(plan, store, device, force_layers=()):
     """Atomic-free weight gradients: every K split of a weight-gradient launch gets its own plane of a partial buffer
     (dyk_conv_wgrad_splits planes per layer), and a table-driven dyk_grad_reduce folds the planes into the flat gradient
     buffer every ~1/16 of the parameters (at section boundaries, so that the data-parallel exchange can cut there).
-    Rewrites plan.bwd / plan.bwd_marks; stems (gathered-patch layout) and single-split launches keep the atomics."""
+    Rewrites plan.bwd / plan.bwd_marks; single-split launches keep their (uncontended, order-free) atomics."""
     lib = L.load()
     G0 = store.G.data_ptr()
     items, total = {}, 0
     for q, (op, d) in enumerate(plan.bwd):
-        if op != L.OP_WGRAD or d.lddw > 0:
+        if op != L.OP_WGRAD:
             continue
         splits = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
         if splits < 2:
             continue
-        plane = d.ntaps * d.Cout * d.Cin
+        plane = d.ntaps * d.Cout * (d.lddw if d.lddw > 0 else d.Cin)       # stems: [Cout][k*k*3] rows of lddw floats
         if plane % 4:
             continue
         items[q] = dict(d=d, splits=splits, plane=plane, part_off=total, g_off=(d.dw - G0) // 4)
