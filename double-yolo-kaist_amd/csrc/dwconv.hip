@@ -314,8 +314,14 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DykDwDesc d, int CVB)
 #pragma unroll
                 for (int j = 0; j < EPV; ++j) s[j] += o[j];
             }
+            if (d.part) {          // plane mode: this workgroup row's own plane, plain stores
+                float* pp = d.part + ((long)blockIdx.y * K * K + (kh * K + t)) * d.C + c;
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) unsafeAtomicAdd(d.dw + (long)(kh * K + t) * d.C + c + j, s[j]);
+                for (int j = 0; j < EPV; ++j) pp[j] = s[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) unsafeAtomicAdd(d.dw + (long)(kh * K + t) * d.C + c + j, s[j]);
+            }
         }
         __syncthreads();
     }
@@ -393,6 +399,15 @@ int launch_dw_wgrad(const DykDwDesc* d, hipStream_t s, int gx, int gy, int CVB) 
     }
     DYK_LAUNCH_CHECK();
     return DYK_OK;
+}
+
+extern "C" int dyk_dwconv_wgrad_rows(const DykDwDesc* d) {
+    const int rc = check_dw(d);
+    if (rc) return rc;
+    const int epv = d->dtype == DYK_BF16 ? 8 : 4;
+    int gx, gy;
+    grid2d(d->C / epv, (long)d->B * d->Ho, &gx, &gy, 768 / d->k);
+    return gy;
 }
 
 extern "C" int dyk_dwconv_wgrad(const DykDwDesc* d, void* stream) {

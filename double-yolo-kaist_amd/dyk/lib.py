@@ -92,7 +92,7 @@ class DykTransposeEntry(ctypes.Structure):
 
 
 class DykDwDesc(ctypes.Structure):
-    _fields_ = [("x", _vp), ("y", _vp), ("w", _vp), ("dw", _vp), ("stats", _vp),
+    _fields_ = [("x", _vp), ("y", _vp), ("w", _vp), ("dw", _vp), ("stats", _vp), ("part", _vp),
                 ("dtype", _i32), ("ldx", _i32), ("ldy", _i32),
                 ("B", _i32), ("Hi", _i32), ("Wi", _i32), ("Ho", _i32), ("Wo", _i32), ("C", _i32),
                 ("k", _i32), ("stride", _i32), ("pad", _i32), ("flags", _i32), ("stats_slots", _i32)]
@@ -184,6 +184,7 @@ SIGNATURES = {
     "dyk_dwconv_fwd": (_i32, [_P(DykDwDesc), _vp]),
     "dyk_dwconv_dgrad": (_i32, [_P(DykDwDesc), _vp]),
     "dyk_dwconv_wgrad": (_i32, [_P(DykDwDesc), _vp]),
+    "dyk_dwconv_wgrad_rows": (_i32, [_P(DykDwDesc)]),
     "dyk_run_commands": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
     "dyk_run_commands_overlap": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
     "dyk_yolo_decode": (_i32, [_P(DykDecodeDesc), _vp]),

@@ -976,6 +976,14 @@ def _setup_wgrad_partials(plan, store, device, force_layers=()):
     G0 = store.G.data_ptr()
     items, total = {}, 0
     for q, (op, d) in enumerate(plan.bwd):
+        if op == L.OP_DW_WGRAD:                  # depthwise: one plane [k*k][C] per workgroup row
+            splits = lib.dyk_dwconv_wgrad_rows(ctypes.byref(d))
+            plane = d.k * d.k * d.C
+            if splits < 2 or plane % 4:
+                continue
+            items[q] = dict(d=d, splits=splits, plane=plane, part_off=total, g_off=(d.dw - G0) // 4, dw=True)
+            total += splits * plane
+            continue
         if op != L.OP_WGRAD:
             continue
         splits = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
@@ -993,7 +1001,10 @@ def _setup_wgrad_partials(plan, store, device, force_layers=()):
     base = plan.part.data_ptr()
     for it in items.values():
         d = it["d"]
-        d.part, d.part_stride, d.splits = base + 4 * it["part_off"], it["plane"], it["splits"]
+        if it.get("dw"):
+            d.part = base + 4 * it["part_off"]
+        else:
+            d.part, d.part_stride, d.splits = base + 4 * it["part_off"], it["plane"], it["splits"]
     target = sum(it["plane"] for it in items.values()) // 16
 
     def reduce_cmd(entries):

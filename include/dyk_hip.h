@@ -336,6 +336,9 @@ typedef struct DykDwDesc {
     const float* w;
     float* dw;
     double* stats;
+    float* part;                    /* dyk_dwconv_wgrad only.  NULL: workgroups add their sums to dw with fp32 atomics.  Else
+                                       workgroup row r (of dyk_dwconv_wgrad_rows) stores them into the plane
+                                       part + r * k*k*C; dyk_grad_reduce folds the planes (reproducible). */
     int32_t dtype, ldx, ldy;
     int32_t B, Hi, Wi, Ho, Wo, C;
     int32_t k, stride, pad;
@@ -344,6 +347,8 @@ typedef struct DykDwDesc {
 int dyk_dwconv_fwd(const DykDwDesc* desc, void* stream);
 int dyk_dwconv_dgrad(const DykDwDesc* desc, void* stream);
 int dyk_dwconv_wgrad(const DykDwDesc* desc, void* stream);
+/* number of workgroup rows (= planes of `part`) dyk_dwconv_wgrad uses for this descriptor; negative = error code */
+int dyk_dwconv_wgrad_rows(const DykDwDesc* desc);
 
 /* ------------------------------------------------------------------------------------
  * Parameter staging.  Master parameters and gradients are fp32, conv weights stored
