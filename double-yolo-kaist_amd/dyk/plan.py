@@ -22,7 +22,7 @@ from .ops import conv_out_size, dgrad_classes, fwd_taps
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 HEAD_LD = 32            # head conv outputs / their gradients live in 32-channel rows
-STAT_SLOTS = 32         # replicas of every per-channel fp64 reduction buffer (bounds atomic contention)
+STAT_SLOTS = int(os.environ.get("DYK_STAT_SLOTS", "32"))   # replicas of every per-channel fp64 reduction buffer (bounds atomic contention)
 
 
 def _ru(n, a):
