@@ -63,7 +63,7 @@ template <typename T, int C> __device__ inline int wg_logical_ch(int row, int ps
     return (wg_off<T, C>(row, ps * EPV) - row * C * (int)sizeof(T)) / (int)sizeof(T);
 }
 
-// PIPE: 0 = register-staged double buffer, 2 / 3 = LDS-DMA ring stages
+// PIPE: LDS-DMA ring stages (2 | 3)
 // KG:   K-groups per workgroup.  The fp32 atomics of the epilogue run at ~1 element/clk/L2 channel, so their
 //       count (= workgroups x tile area) bounds the kernel; with KG = 2 a 512-thread workgroup holds two 4-wave
 //       groups that walk the two halves of its pixel range with private LDS rings, group 1 hands its
@@ -78,8 +78,7 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int MI = WTM / 16, NI = WTN / 16;
     constexpr int A_BYTES = ROWS * BM * (int)sizeof(T), B_BYTES = ROWS * BN * (int)sizeof(T);
-    constexpr bool DMA = PIPE != 0;
-    constexpr int NSTAGE = DMA ? PIPE : 2;
+    constexpr int NSTAGE = PIPE;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
@@ -169,8 +168,8 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc
     // bits 16.. of `tune`: ablation switches for kernel analysis (tools/gpu_probe.py wgablate), never set by the plan
     const bool abl_noatomic = (a.tune >> 16) & 1, abl_noloop = (a.tune >> 17) & 1;
     const int S = abl_noloop ? 0 : (KG > 1 ? gchunk / ROWS : (p_end - p_begin + ROWS - 1) / ROWS);   // uniform over the K-groups
-    if constexpr (DMA) {
-        // ---- 3-stage LDS-DMA ring; each wave instruction fills RPI consecutive pixel rows of a tile
+    {
+        // ---- LDS-DMA ring; each wave instruction fills RPI consecutive pixel rows of a tile
         constexpr int RPI_A = 64 / VPR_A, RPI_B = 64 / VPR_B;
         constexpr int NI_A = A_BYTES / 1024, NI_B = B_BYTES / 1024;         // both multiples of 4
         constexpr int NIA_W = NI_A / 4, NIB_W = NI_B / 4;
@@ -248,68 +247,6 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc
                 __builtin_amdgcn_s_barrier();
             }
         }
-    } else {
-        // ---- register-staged double buffer
-        constexpr int NPA = (NV_A + 255) / 256, NPB = (NV_B + 255) / 256;
-        int a_row[NPA], a_ch[NPA];
-        int b_row[NPB], b_ch[NPB];
-        int b_img[NPB], b_yo[NPB], b_xo[NPB];
-#pragma unroll
-        for (int i = 0; i < NPA; ++i) {
-            const int v = i * 256 + tid;
-            a_row[i] = v / VPR_A; a_ch[i] = (v % VPR_A) * EPV;
-        }
-#pragma unroll
-        for (int i = 0; i < NPB; ++i) {
-            const int v = i * 256 + tid;
-            b_row[i] = v / VPR_B; b_ch[i] = (v % VPR_B) * EPV;
-            const int n = p_begin + b_row[i];
-            const int b = n / HWo, r = n - b * HWo;
-            b_img[i] = b; b_yo[i] = r / a.Wo; b_xo[i] = r - b_yo[i] * a.Wo;
-        }
-        uint4 ra[NPA], rb[NPB];
-        const uint4 zero4 = make_uint4(0, 0, 0, 0);
-        auto gload = [&](int p0) {
-#pragma unroll
-            for (int i = 0; i < NPA; ++i) {
-                const int n = p0 + a_row[i];
-                const int c = m0 + a_ch[i];
-                const bool ok = (NV_A % 256 == 0 || i * 256 + tid < NV_A) && n < p_end && c < a.Cout;
-                ra[i] = ok ? *(const uint4*)(dyg + (long)n * a.lddy + c) : zero4;
-            }
-#pragma unroll
-            for (int i = 0; i < NPB; ++i) {
-                const int n = p0 + b_row[i];
-                const int c = n0 + b_ch[i];
-                const int yi = b_yo[i] * a.isy + tdy, xi = b_xo[i] * a.isx + tdx;
-                const bool ok = (NV_B % 256 == 0 || i * 256 + tid < NV_B) && n < p_end && c < a.Cin &&
-                                ((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi);
-                rb[i] = ok ? *(const uint4*)(xg + ((long)(b_img[i] * a.Hi + yi) * a.Wi + xi) * a.ldx + c) : zero4;
-                int xo = b_xo[i] + ROWS, yo = b_yo[i], bb = b_img[i];
-                while (xo >= a.Wo) { xo -= a.Wo; ++yo; }
-                while (yo >= a.Ho) { yo -= a.Ho; ++bb; }
-                b_xo[i] = xo; b_yo[i] = yo; b_img[i] = bb;
-            }
-        };
-        auto lstore = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < NPA; ++i)
-                if (NV_A % 256 == 0 || i * 256 + tid < NV_A)
-                    *(uint4*)(sA + buf * A_BYTES + wg_off<T, BM>(a_row[i], a_ch[i])) = ra[i];
-#pragma unroll
-            for (int i = 0; i < NPB; ++i)
-                if (NV_B % 256 == 0 || i * 256 + tid < NV_B)
-                    *(uint4*)(sB + buf * B_BYTES + wg_off<T, BN>(b_row[i], b_ch[i])) = rb[i];
-        };
-        if (S > 0) { gload(p_begin); lstore(0); }
-        __syncthreads();
-        for (int s = 0; s < S; ++s) {
-            const bool more = (s + 1 < S);
-            if (more) gload(p_begin + (s + 1) * ROWS);
-            compute(sA + (s & 1) * A_BYTES, sB + (s & 1) * B_BYTES);
-            if (more) lstore((s + 1) & 1);
-            __syncthreads();
-        }
     }
 
     if constexpr (KG > 1) {
@@ -384,20 +321,11 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc
     }
 }
 
-inline bool wg_use_dma() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("DYK_CONV_PIPE");
-        v = (e && e[0] == 'r') ? 0 : 1;
-    }
-    return v == 1;
-}
-
 // query != NULL: only report the split count this launch would use
 template <typename T, int BM, int BN, int PIPE, int KG>
 int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream, int* query) {
     constexpr int ROWS = WgTraits<T>::ROWS;
-    constexpr size_t ring = KG * (PIPE ? PIPE : 2) * (size_t)ROWS * (BM + BN) * sizeof(T);
+    constexpr size_t ring = KG * PIPE * (size_t)ROWS * (BM + BN) * sizeof(T);
     constexpr size_t park = KG > 1 ? (size_t)BM * BN * 4 : 0;
     constexpr size_t lds = ring > park ? ring : park;
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -430,7 +358,6 @@ int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream, int* query) {
 
 template <typename T, int BM, int BN>
 int launch_wgrad(const DykWgradDesc* d, hipStream_t stream, int* query) {
-    if (!wg_use_dma()) return launch_wgrad_impl<T, BM, BN, 0, 1>(d, stream, query);
     // tune: low byte = LDS ring stages (2 | 3), bits 8..15 = K-groups per workgroup (1 | 2)
     const int kg = (d->tune >> 8) & 0xff;
     if ((d->tune & 0xff) == 3) return launch_wgrad_impl<T, BM, BN, 3, 1>(d, stream, query);
