@@ -62,13 +62,31 @@ class Engine:
 
     def get_plan(self, B, H, W, dtype, training, device):
         key = (B, H, W, dtype, bool(training))
-        plan = self.plans.get(key)
+        plan = self.plans.pop(key, None)
         if plan is None:
             if H % 32 or W % 32:
                 raise ValueError("input height/width must be multiples of 32 (reference train.py:49), got %dx%d" % (H, W))
             plan = compile_plan(self.model, self.store, B, H, W, dtype, training, device)
-            self.plans[key] = plan
+        self.plans[key] = plan                     # (re)insert as most recently used
+        self._evict(device)
         return plan
+
+    def _evict(self, device):
+        """Plans own their arenas (the target cfg at batch 16: ~20 GB for a training plan).  Multi-scale training
+        (reference kaist_train_eval_utils.py:59-71 draws a new image size every few batches) would otherwise keep one
+        per size: least-recently-used plans are dropped once the total passes DYK_PLAN_MEM_GB (default: half of the
+        device memory).  A plan still referenced by a pending backward stays alive until that backward is done."""
+        budget = float(os.environ.get("DYK_PLAN_MEM_GB", "0")) * 1e9
+        if budget <= 0:
+            budget = 0.5 * torch.cuda.get_device_properties(device).total_memory if device.type == "cuda" else float("inf")
+
+        def nbytes(p):
+            return sum(a.size for a in p.arenas.values()) + (getattr(p, "part_bytes", 0) or 0)
+        keys = list(self.plans)
+        total = sum(nbytes(self.plans[k]) for k in keys)
+        while total > budget and len(keys) > 1:
+            k = keys.pop(0)
+            total -= nbytes(self.plans.pop(k))
 
     # ------------------------------------------------------------------ execution
     def _run_forward(self, plan, x, y):

@@ -310,3 +310,18 @@ def test_baseline_size_train_step_is_bit_reproducible():
     assert all(bool(torch.isfinite(gv).all()) and float(gv.abs().max()) > 0 for gv in grads[0].values())
     differing = [k for k in grads[0] if not torch.equal(grads[0][k], grads[1][k])]
     assert not differing, differing[:8]
+
+
+def test_plan_cache_is_bounded(monkeypatch):
+    """multi-scale use: every (batch, size, dtype, mode) gets its own plan; least-recently-used plans are dropped once
+    their arenas exceed the budget, and results do not depend on eviction"""
+    monkeypatch.setenv("DYK_PLAN_MEM_GB", "0.03")
+    m = _model(C1).eval()
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.rand(1, 3, s, s + 32, generator=g).cuda() for s in (64, 96, 128, 160, 192)]
+    with torch.no_grad():
+        first = [m(x)[0].clone() for x in xs]
+        n_after_sweep = len(m.engine.plans)
+        again = [m(x)[0].clone() for x in xs]
+    assert 1 <= n_after_sweep < len(xs)
+    assert all(torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)) for a, b in zip(first, again))
