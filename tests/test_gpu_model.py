@@ -325,3 +325,69 @@ def test_plan_cache_is_bounded(monkeypatch):
         again = [m(x)[0].clone() for x in xs]
     assert 1 <= n_after_sweep < len(xs)
     assert all(torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)) for a, b in zip(first, again))
+
+
+def test_reference_harness_step_with_autocast_and_gradscaler():
+    """the unchanged reference training step (kaist_train_eval_utils.py:74-108): autocast forward, compute_loss,
+    scaler.scale(loss).backward(), scaler.step(torch.optim.SGD), scaler.update(), optimizer.zero_grad() -- runs on the
+    HIP path (bf16 under autocast) and gives the same parameter update as the unscaled step."""
+    from build_utils.utils import compute_loss
+    x, y, tg = cases.step_batch(0)
+    updates = []
+    for use_scaler in (True, False):
+        m = _model(C3, dtype=None).train()
+        m.nc, m.hyp, m.gr = 1, hyp(), 1.0
+        opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, nesterov=True)
+        scaler = torch.amp.GradScaler("cuda", enabled=use_scaler, init_scale=1024.0)
+        before = {k: p.detach().clone() for k, p in m.named_parameters()}
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = m(x.cuda(), y.cuda())
+            ld = compute_loss(pred, tg.cuda(), m)
+            losses = ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]
+        scaler.scale(losses).backward()
+        scaler.step(opt)
+        scaler.update()
+        opt.zero_grad()
+        assert bool(torch.isfinite(losses).all())
+        updates.append({k: (p.detach() - before[k]) for k, p in m.named_parameters()})
+    num = sum(float(((updates[0][k] - updates[1][k]) ** 2).sum()) for k in updates[0])
+    den = sum(float((updates[1][k] ** 2).sum()) for k in updates[0])
+    assert den > 0 and (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+
+
+def test_eval_pipeline_forward_nms_scale_ap():
+    """evaluate.py-style flow through the product API only: eval forward -> non_max_suppression -> scale_coords ->
+    other_utils.metrics.compute_ap_lamr.  Labels are built from the two best detections of every image, so the first
+    detections are true positives and AP is the known value for that construction."""
+    from build_utils.utils import non_max_suppression, scale_coords
+    from other_utils.metrics import compute_ap_lamr
+    m = _model(C3).eval()
+    g = torch.Generator().manual_seed(8)
+    v, l = torch.rand(4, 3, 128, 160, generator=g).cuda(), torch.rand(4, 3, 128, 160, generator=g).cuda()
+    with torch.no_grad():
+        io, _ = m(v, l)
+    conf = float(io[..., 4].sort(dim=1).values[:, -60].min()) * 0.999          # >= 60 candidates in every image
+    dets = non_max_suppression(io, conf_thres=conf * float(io[..., 5].min()), iou_thres=0.3, multi_label=False)
+    assert all(d is not None and d.shape[1] == 6 for d in dets)
+    preds, labels, shapes = [], [], []
+    H0, W0 = 512, 640                                         # "original" image size: boxes are scaled 128x160 -> 512x640
+    for i, d in enumerate(dets):
+        d = d.clone()
+        d[:, :4] = scale_coords((128, 160), d[:, :4], (H0, W0)).round()
+        boxes = d[:, :4].cpu().numpy().astype(np.float32)
+        keep = [j for j in range(len(boxes)) if boxes[j, 2] - boxes[j, 0] >= 4 and boxes[j, 3] - boxes[j, 1] >= 4][:2]
+        assert keep
+        gts = []
+        for j in keep:
+            x1, y1, x2, y2 = boxes[j]
+            gts.append([0.0, (x1 + x2) / 2 / W0, (y1 + y2) / 2 / H0, (x2 - x1) / W0, (y2 - y1) / H0])
+        labels.append(np.array(gts, dtype=np.float32))
+        shapes.append((float(W0), float(H0)))
+        for j in range(len(boxes)):
+            preds.append(dict(img_id=i, conf=float(d[j, 4]), bbox=boxes[j]))
+    preds.sort(key=lambda r: -r["conf"])
+    out = compute_ap_lamr(preds, labels, np.array(shapes))
+    nt = sum(len(x) for x in labels)
+    assert out["recall"][-1] == 1.0 and len(out["recall"]) == len(preds)
+    assert 0.0 < out["ap"] <= 1.0 and 0.0 <= out["lamr"] <= 1.0
+    assert int(round(out["recall"][-1] * nt)) == nt
