@@ -487,36 +487,40 @@ __global__ __launch_bounds__(256) void head_bias_grad_kernel(const float* __rest
 
 // ------------------------------------------------------------------ first-layer patch gather
 // in NCHW fp32 [B,Cin,H,W] -> out [B,Ho,Wo,ld] T with out[.., (kh*k+kw)*Cin + c] = in[b,c,yo*s+kh-pad,xo*s+kw-pad]*mul
+// One thread per output pixel: the k*k*Cin gathered values (consecutive threads read consecutive x: coalesced NCHW
+// reads) are packed in registers and the whole zero-padded row of `ld` channels leaves as contiguous 16-byte stores.
 template <typename T>
 __global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ in, T* __restrict__ out, int B,
                                                            int Cin, int H, int W, int k, int stride, int pad, int Ho,
                                                            int Wo, int ld, float mul) {
     constexpr int EPV = ElemTraits<T>::EPV;
-    const int CV = ld / EPV;
-    const long npix = (long)B * Ho * Wo;
-    const long total = npix * CV;
+    const int npix = B * Ho * Wo;
     const int K = k * k * Cin;
-    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
-        const long p = v % npix;               // pixel fastest: coalesced NCHW reads
-        const int j0 = (int)(v / npix) * EPV;
-        const int xo = (int)(p % Wo);
-        const long q = p / Wo;
-        const int yo = (int)(q % Ho);
-        const int b = (int)(q / Ho);
-        float val[EPV];
+    const int CV = ld / EPV;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const int xo = p % Wo;
+        const int q = p / Wo;
+        const int yo = q % Ho;
+        const int b = q / Ho;
+        const float* img = in + (long)b * Cin * H * W;
+        T* row = out + (long)p * ld;
+        int j = 0, tap = 0, c = 0;                 // j = tap * Cin + c walks the gathered row
+        for (int v = 0; v < CV; ++v) {
+            float val[EPV];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            const int j = j0 + e;
-            float t = 0.f;
-            if (j < K) {
-                const int c = j % Cin, tap = j / Cin;
-                const int kh = tap / k, kw = tap - kh * k;
-                const int yy = yo * stride + kh - pad, xx = xo * stride + kw - pad;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W) t = in[(((long)b * Cin + c) * H + yy) * W + xx] * mul;
+            for (int e = 0; e < EPV; ++e) {
+                float t = 0.f;
+                if (j < K) {
+                    const int kh = tap / k, kw = tap - kh * k;
+                    const int yy = yo * stride + kh - pad, xx = xo * stride + kw - pad;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) t = img[((long)c * H + yy) * W + xx] * mul;
+                    if (++c == Cin) { c = 0; ++tap; }
+                    ++j;
+                }
+                val[e] = t;
             }
-            val[e] = t;
+            *(uint4*)(row + v * EPV) = vec_pack<T>(val);
         }
-        *(uint4*)(out + p * ld + j0) = vec_pack<T>(val);
     }
 }
 
@@ -682,7 +686,8 @@ extern "C" int dyk_patch_gather(const float* in, void* out, int32_t B, int32_t C
     const int epv = epv_of(dtype);
     if (ld % epv || ld < k * k * Cin) return DYK_ERR_ARG;
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
-    const int grid = ew_grid((long)B * Ho * Wo * (ld / epv));
+    if ((long)B * Ho * Wo >= (1L << 31)) return DYK_ERR_ARG;
+    const int grid = ew_grid((long)B * Ho * Wo);
     if (dtype == DYK_BF16)
         hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, B, Cin, H, W, k, stride, pad, Ho, Wo, ld, mul);
     else if (dtype == DYK_F32)
