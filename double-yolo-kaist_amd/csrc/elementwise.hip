@@ -680,6 +680,52 @@ extern "C" int dyk_head_permute_bwd(const float* dp, void* dy, float* dbias, int
     return DYK_OK;
 }
 
+// Input path of the training harness: `imgs.float() / 255.0` (+ bilinear resize, align_corners=False) in one pass.
+// Index arithmetic follows ATen's area_pixel_compute_source_index / guard_index_and_lambda so that the four taps and
+// both lambdas are the ones F.interpolate uses; one thread per output pixel, x fastest (coalesced stores).
+template <typename S>
+__global__ __launch_bounds__(256) void image_prep_kernel(const S* __restrict__ src, float* __restrict__ dst, int planes,
+                                                         int Hi, int Wi, int Ho, int Wo, float div) {
+    const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+    const long total = (long)planes * Ho * Wo;
+    const bool same = Hi == Ho && Wi == Wo;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (same) {
+            dst[i] = (float)src[i] / div;
+            continue;
+        }
+        const int xo = (int)(i % Wo);
+        const long q = i / Wo;
+        const int yo = (int)(q % Ho);
+        const S* pl = src + (q / Ho) * (long)Hi * Wi;
+        float fy = fmaf(sh, (float)yo + 0.5f, -0.5f), fx = fmaf(sw, (float)xo + 0.5f, -0.5f);   // fused like torch's build
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = min((int)fy, Hi - 1), x0 = min((int)fx, Wi - 1);
+        const int y1 = y0 + (y0 < Hi - 1), x1 = x0 + (x0 < Wi - 1);
+        const float ly = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+        const float v00 = (float)pl[(long)y0 * Wi + x0] / div, v01 = (float)pl[(long)y0 * Wi + x1] / div;
+        const float v10 = (float)pl[(long)y1 * Wi + x0] / div, v11 = (float)pl[(long)y1 * Wi + x1] / div;
+        const float top = __fadd_rn(__fmul_rn(1.f - lx, v00), __fmul_rn(lx, v01));
+        const float bot = __fadd_rn(__fmul_rn(1.f - lx, v10), __fmul_rn(lx, v11));
+        dst[i] = __fadd_rn(__fmul_rn(1.f - ly, top), __fmul_rn(ly, bot));
+    }
+}
+
+extern "C" int dyk_image_prep(const void* src, float* dst, int32_t planes, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                              int32_t src_dtype, float div, void* stream) {
+    if (!src || !dst || planes <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || !(div > 0.f)) return DYK_ERR_ARG;
+    const int grid = ew_grid((long)planes * Ho * Wo);
+    if (src_dtype == DYK_U8)
+        hipLaunchKernelGGL(image_prep_kernel<uint8_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, dst, planes, Hi, Wi, Ho, Wo, div);
+    else if (src_dtype == DYK_F32)
+        hipLaunchKernelGGL(image_prep_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, planes, Hi, Wi, Ho, Wo, div);
+    else
+        return DYK_ERR_ARG;
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
 extern "C" int dyk_patch_gather(const float* in, void* out, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t k,
                                 int32_t stride, int32_t pad, int32_t ld, float mul, int32_t dtype, void* stream) {
     if (!in || !out || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0) return DYK_ERR_ARG;

@@ -96,7 +96,11 @@ class Engine:
         keep = []
         for desc, which in plan.dyn_in:
             t = xs[which]
-            if t.dtype != torch.float32 or not t.is_contiguous():
+            if t.dtype == torch.uint8:
+                # the loader's uint8 batch handed over as is: `.float() / 255.0` in one HIP pass
+                from .functional import prepare_images
+                t = prepare_images(t)
+            elif t.dtype != torch.float32 or not t.is_contiguous():
                 t = t.float().contiguous()
             keep.append(t)
             desc.p[0] = t.data_ptr()

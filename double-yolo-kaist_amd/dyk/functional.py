@@ -166,3 +166,37 @@ def yolo_layer(p, layer):
         d.anchor_vec[i] = v
     ops.call("dyk_yolo_decode", d)
     return io, out
+
+
+def prepare_images(imgs, size=None, div=255.0):
+    """Harness input path (reference train_utils/kaist_train_eval_utils.py:54-55, 59-71): the loader's uint8 batch
+    [B,3,H,W] -> float32 in 0..1, optionally resized like F.interpolate(size=size, mode='bilinear',
+    align_corners=False), in one HIP pass.  float32 input is taken as already divided (div forced to 1)."""
+    ops._require_cuda(imgs)
+    if imgs.dim() != 4:
+        raise ValueError("prepare_images expects [B,C,H,W], got %s" % (tuple(imgs.shape),))
+    if imgs.dtype == torch.uint8:
+        sdt = L.DYK_U8
+    elif imgs.dtype == torch.float32:
+        sdt, div = L.DYK_F32, 1.0
+    else:
+        raise TypeError("prepare_images: uint8 or float32 images, got %s" % imgs.dtype)
+    imgs = imgs.contiguous()
+    B, C, H, W = imgs.shape
+    Ho, Wo = (H, W) if size is None else (int(size[0]), int(size[1]))
+    out = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=imgs.device)
+    check(load().dyk_image_prep(imgs.data_ptr(), out.data_ptr(), B * C, H, W, Ho, Wo, sdt, float(div), _stream()),
+          "dyk_image_prep")
+    return out
+
+
+def multi_scale_pair(v_imgs, l_imgs, img_size, gs=32):
+    """The multi-scale step of the reference training loop (kaist_train_eval_utils.py:59-71): scale factor
+    sf = img_size / max(H, W), new size ceil(x*sf/gs)*gs per axis, both streams resized alike."""
+    import math
+    assert v_imgs.shape[:2] == l_imgs.shape[:2]
+    sf = img_size / max(v_imgs.shape[2:])
+    ns = None
+    if sf != 1:
+        ns = [math.ceil(x * sf / gs) * gs for x in v_imgs.shape[2:]]
+    return prepare_images(v_imgs, ns), prepare_images(l_imgs, ns)

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(os.path.dirname(_HERE), "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libdyk_hip.so")
 
-DYK_F32, DYK_BF16 = 0, 1
+DYK_F32, DYK_BF16, DYK_U8 = 0, 1, 2
 ACT_CODES = {"linear": 0, "leaky": 1, "mish": 2, "relu": 3, "relu6": 4, "hard-sigmoid": 5, "hard-swish": 6}
 EPI_AFFINE, EPI_RESIDUAL, EPI_STATS, EPI_ACCUM, EPI_OUT_F32, EPI_BNBWD = 1, 2, 4, 8, 16, 32
 EW_ACCUM = 1
@@ -175,6 +175,7 @@ SIGNATURES = {
     "dyk_head_permute_fwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dyk_head_permute_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dyk_patch_gather": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "dyk_image_prep": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "dyk_pack_conv_weight": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dyk_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "dyk_nhwc_to_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -40,7 +40,7 @@ enum {
     DYK_ERR_STATE = -4     /* plan used before bind, etc. */
 };
 
-enum { DYK_F32 = 0, DYK_BF16 = 1 };
+enum { DYK_F32 = 0, DYK_BF16 = 1, DYK_U8 = 2 /* image input of dyk_image_prep only */ };
 
 /* activation codes; the strings are the cfg `activation=` values (models.py:51-64) */
 enum {
@@ -296,6 +296,14 @@ int dyk_head_permute_fwd(const float* y, float* p, int32_t B, int32_t ny, int32_
                          int32_t no, int32_t ld, void* stream);
 int dyk_head_permute_bwd(const float* dp, void* dy, float* dbias, int32_t B, int32_t ny, int32_t nx,
                          int32_t na, int32_t no, int32_t ld, int32_t dtype, void* stream);
+
+/* Input path of the harness (train_utils/kaist_train_eval_utils.py:54-55 `imgs.to(device).float() / 255.0`, and under
+ * multi-scale training :59-71 `F.interpolate(imgs, size=ns, mode='bilinear', align_corners=False)`) as one pass:
+ * src [planes = B*C][Hi][Wi] of src_dtype (DYK_U8 loader output, kaist_dataset.py:385-386, or DYK_F32)
+ *   -> dst f32 [planes][Ho][Wo] = bilinear(src / div).  Hi == Ho && Wi == Wo is the plain conversion.
+ * Source index / lambda arithmetic is ATen's (scale = in/out, src = scale*(dst+0.5)-0.5 clamped at 0). */
+int dyk_image_prep(const void* src, float* dst, int32_t planes, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                   int32_t src_dtype, float div, void* stream);
 
 /* First-layer patch gather: torch NCHW fp32 image batch -> channels-last patches
  * out[b,yo,xo,(kh*k+kw)*Cin + c] = in[b,c,yo*stride+kh-pad,xo*stride+kw-pad]*mul (zero padded up
