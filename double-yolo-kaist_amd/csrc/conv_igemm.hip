@@ -13,6 +13,7 @@ extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
     if (d->B <= 0 || d->Hg <= 0 || d->Wg <= 0 || d->Cout <= 0 || d->Cin <= 0) return DYK_ERR_ARG;
     if ((d->flags & DYK_EPI_STATS) && !d->stats) return DYK_ERR_ARG;
     if ((d->flags & DYK_EPI_RESIDUAL) && !d->res) return DYK_ERR_ARG;
+    if ((d->flags & DYK_EPI_ADDEND) && (!(d->flags & DYK_EPI_BNBWD) || !d->add || ((uintptr_t)d->add % 16))) return DYK_ERR_ARG;
     if (d->flags & DYK_EPI_BNBWD) {
         if (d->flags & (DYK_EPI_AFFINE | DYK_EPI_RESIDUAL | DYK_EPI_STATS | DYK_EPI_ACCUM | DYK_EPI_OUT_F32)) return DYK_ERR_ARG;
         if (!d->res || !d->stats || !d->scale || !d->shift || !d->aux0 || !d->aux1) return DYK_ERR_ARG;

@@ -305,6 +305,7 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
                 mu[j] = live ? a.aux0[mc + j] : 0.f; rs[j] = live ? a.aux1[mc + j] : 0.f;
                 s1[j] = s2[j] = 0.f;
             }
+            const bool chain = (flags & DYK_EPI_ADDEND) != 0;     // residual chain: store dz itself, reduce da
             if (live) {
                 for (int q = tid; q < nchunk; q += 256) {
                     const int row = q / cpr;
@@ -313,6 +314,15 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
                     float g[EPVT], yv[EPVT];
                     vec_unpack<T>(*(const uint4*)(sC + row * rstride + cc * 16), g);
                     vec_unpack<T>(*(const uint4*)((const T*)a.res + (long)t_res[row] + mc), yv);
+                    if (chain) {
+                        float ad[EPVT];
+                        vec_unpack<T>(*(const uint4*)((const T*)a.add + (long)po + mc), ad);
+#pragma unroll
+                        for (int j = 0; j < EPVT; ++j) g[j] += ad[j];
+                        const uint4 pk = vec_pack<T>(g);
+                        *(uint4*)((T*)a.y + (long)po + mc) = pk;
+                        vec_unpack<T>(pk, g);              // the apply pass will see the rounded dz: reduce the same values
+                    }
 #pragma unroll
                     for (int j = 0; j < EPVT; ++j) {
                         const float da = g[j] * act_bwd_c<ACTB>(yv[j] * sc[j] + sh[j], a.act);
@@ -320,7 +330,7 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
                         s2[j] += da * ((yv[j] - mu[j]) * rs[j]);
                         g[j] = da;
                     }
-                    *(uint4*)((T*)a.y + (long)po + mc) = vec_pack<T>(g);
+                    if (!chain) *(uint4*)((T*)a.y + (long)po + mc) = vec_pack<T>(g);
                 }
             }
 #pragma unroll

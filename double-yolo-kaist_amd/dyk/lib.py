@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(CSRC_DIR, "libdyk_hip.so")
 
 DYK_F32, DYK_BF16, DYK_U8 = 0, 1, 2
 ACT_CODES = {"linear": 0, "leaky": 1, "mish": 2, "relu": 3, "relu6": 4, "hard-sigmoid": 5, "hard-swish": 6}
-EPI_AFFINE, EPI_RESIDUAL, EPI_STATS, EPI_ACCUM, EPI_OUT_F32, EPI_BNBWD = 1, 2, 4, 8, 16, 32
+EPI_AFFINE, EPI_RESIDUAL, EPI_STATS, EPI_ACCUM, EPI_OUT_F32, EPI_BNBWD, EPI_ADDEND = 1, 2, 4, 8, 16, 32, 64
 EW_ACCUM = 1
 MAX_TAPS = 25
 
@@ -38,7 +38,7 @@ _i8, _i32, _i64, _f32, _vp = ctypes.c_int8, ctypes.c_int32, ctypes.c_int64, ctyp
 class DykConvDesc(ctypes.Structure):
     _fields_ = [
         ("x", _vp), ("w", _vp), ("y", _vp), ("scale", _vp), ("shift", _vp), ("res", _vp), ("stats", _vp),
-        ("aux0", _vp), ("aux1", _vp),
+        ("aux0", _vp), ("aux1", _vp), ("add", _vp),
         ("dtype", _i32), ("ldx", _i32), ("ldy", _i32), ("ldr", _i32),
         ("B", _i32), ("Hi", _i32), ("Wi", _i32), ("Cin", _i32), ("Cout", _i32),
         ("Hg", _i32), ("Wg", _i32), ("Ho", _i32), ("Wo", _i32),

@@ -493,6 +493,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     cd.flags |= L.EPI_RESIDUAL
                     cd.ldr = a.ld
                     later(lambda cd=cd, a=a: setattr(cd, "res", ptr_of(a)))
+                prev["fused_shortcut"] = True
                 rec.update(weighted=False, fused=True, x=x_in, a=a, z=x_in)
                 cur = x_in
                 outs.append(cur)
@@ -628,6 +629,33 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             red_offs.append((off, nbytes))
             return off
 
+        pending_add = {}     # tid of a skip tensor -> gradient that reaches it over a fused plain [shortcut], not yet added
+
+        def chain_consumer(a, before):
+            """the conv whose data gradient can take the [shortcut] gradient of `a` as an addend and reduce the
+            BatchNorm backward of a's producer in its epilogue (DYK_EPI_BNBWD | DYK_EPI_ADDEND): `a` is read by that
+            conv and the [shortcut] only, the conv comes earlier than layer `before` and covers a in one launch"""
+            if (os.environ.get("DYK_BNBWD_FUSE", "1") == "0" or os.environ.get("DYK_CHAIN_FUSE", "1") == "0"
+                    or os.environ.get("DYK_DEBUG_PLAN")):
+                return None
+            prod = producer_of.get(a.tid)
+            if prod is None or not prod.get("bn"):
+                return None
+            # readers: the conv, this [shortcut] and, when a is itself the output of a fused [shortcut], that section
+            if tcons.get(a.tid, 0) != (3 if prod.get("fused_shortcut") else 2) or a.tid in ginit or a.tid in grads \
+                    or a.C % (16 // es):
+                return None
+            readers = [r for r in info[:before] if r.get("kind") == "conv" and r.get("x") is not None
+                       and r["x"].tid == a.tid]
+            if len(readers) != 1:
+                return None
+            r = readers[0]
+            if r is prod or r.get("dw") or r.get("stem") or r["stride"] != 1 or r["i"] <= prod["i"]:
+                return None
+            if len(dgrad_classes(r["k"], r["pad"], 1, a.H, a.W)) != 1:
+                return None
+            return r
+
         def emit_conv_backward(rec, dy):
             """dy: gradient w.r.t. the conv's raw output (dtype), rows zero padded to a multiple of 32 channels"""
             k, stride, pad, cout, wname = rec["k"], rec["stride"], rec["pad"], rec["cout"], rec["wname"]
@@ -682,11 +710,16 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             # BatchNorm-backward reduce of the producer of x_in folded into this data gradient (DYK_EPI_BNBWD): possible
             # when this launch is the only writer of the gradient (sole reader of the tensor, nothing accumulated yet)
             prod = producer_of.get(x_in.tid)
-            fuse = (first and prod is not None and prod is not rec and tcons.get(x_in.tid, 0) == 1
-                    and x_in.C % (16 // es) == 0 and not os.environ.get("DYK_DEBUG_PLAN")
-                    and os.environ.get("DYK_BNBWD_FUSE", "1") != "0")
+            addend = pending_add.pop(x_in.tid, None)
+            if addend is not None and (not first or addend[1] is not rec or addend[0].ld != gx.ld):
+                raise RuntimeError("residual-chain addend of layer %d lost its consumer" % rec["i"])
+            fuse = addend is not None or (
+                first and prod is not None and prod is not rec and tcons.get(x_in.tid, 0) == 1
+                and x_in.C % (16 // es) == 0 and not os.environ.get("DYK_DEBUG_PLAN")
+                and os.environ.get("DYK_BNBWD_FUSE", "1") != "0")
             if fuse:
                 prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
+                prod["keep_dz"] = addend is not None
             classes = dgrad_classes(k, pad, stride, x_in.H, x_in.W)
             for (py, px, Hg, Wg, taps) in classes:
                 if not taps and not first:
@@ -709,6 +742,9 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 if fuse:
                     pc, pv, pr = x_in.C, prod["vecs"], prod["red_fused"]
                     d.act, d.flags, d.stats_slots, d.ldr = prod["act"], L.EPI_BNBWD, STAT_SLOTS, prod["y_raw"].ld
+                    if addend is not None:
+                        d.flags |= L.EPI_ADDEND
+                        later(lambda d=d, ad=addend[0]: setattr(d, "add", ptr_of(ad)))
                     later(lambda d=d, prod=prod, pc=pc, pv=pv, pr=pr: (
                         setattr(d, "res", ptr_of(prod["y_raw"])), setattr(d, "scale", ws.ptr(pv)),
                         setattr(d, "shift", ws.ptr(pv + 4 * pc)), setattr(d, "aux0", ws.ptr(pv + 8 * pc)),
@@ -725,7 +761,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             if rec["bn"]:
                 cout, vecs, bnpre = rec["cout"], rec["vecs"], rec["bnpre"]
                 fused_red = rec.get("red_fused")          # the producing dgrad already left da and the two sums
-                act_bwd = 0 if fused_red is not None else rec["act"]
+                keep_dz = bool(rec.get("keep_dz"))        # ... or, in a residual chain, dz itself (act' still to apply)
+                act_bwd = 0 if (fused_red is not None and not keep_dz) else rec["act"]
                 if fused_red is not None:
                     red = fused_red
                 else:
@@ -738,7 +775,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                         setattr(r, "red", ws.ptr(red))))
                     plan.bwd.append((L.OP_BN_BWD_REDUCE, r))
                 dyr = dz
-                if os.environ.get("DYK_DEBUG_PLAN"):      # keep dz intact for per-layer gradient dumps
+                if os.environ.get("DYK_DEBUG_PLAN") or rec.get("dz_is_addend"):
+                    # keep dz intact: per-layer gradient dumps / it is still to be added to the skip tensor's gradient
                     dyr = TRef("grad", grad_arena.alloc(dz.npix * dz.ld * es), dz.B, dz.H, dz.W, dz.C, dz.ld, es)
                 ap = ew_desc(a=dz, b=rec["y_raw"], out=dyr, act=act_bwd)        # in place: dz (or da) -> dy_raw
                 # the apply pass folds the replicas of the reduction itself and adds them to dgamma / dbeta
@@ -818,7 +856,13 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 dz = gref(z)
                 x_in, a = rec["x"], rec["a"]
                 if rec.get("fused"):
-                    # z is the conv's own output: its gradient stays where it is, the skip branch gets a copy
+                    # z is the conv's own output: its gradient stays where it is, the skip branch gets a copy --
+                    # or, in a residual chain, the data gradient of the skip tensor's other reader adds it on the fly
+                    r = chain_consumer(a, i)
+                    if r is not None and dz.ld == a.ld:
+                        pending_add[a.tid] = (dz, r)
+                        info[i - 1]["dz_is_addend"] = True
+                        continue
                     plan.bwd.append((L.OP_AXPBY, ew_desc(a=dz, out=gref(a), flags=acc_flag(a))))
                     continue
                 if rec["weighted"]:

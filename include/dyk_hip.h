@@ -78,12 +78,18 @@ enum {
                              (replication bounds the atomic contention per address; dyk_bn_finalize sums the replicas) */
     DYK_EPI_ACCUM = 8,    /* y = y_old + v (gradient accumulation) */
     DYK_EPI_OUT_F32 = 16, /* y is float regardless of dtype */
-    DYK_EPI_BNBWD = 32    /* data-gradient launches only: the tensor being produced is the gradient wrt the output z of a
+    DYK_EPI_BNBWD = 32,   /* data-gradient launches only: the tensor being produced is the gradient wrt the output z of a
                              train-mode BatchNorm + activation whose raw conv output is `res` (same shape as y).  The
                              epilogue stores  da = v * act'(res*scale + shift)  instead of v and adds sum(da),
                              sum(da * (res - aux0) * aux1) per channel into a `stats` replica -- the reduce pass of that
                              BatchNorm's backward, fused (`act` = its activation; scale/shift/aux0/aux1 = its
                              scale, shift, saved mean, saved rstd).  Excludes AFFINE, RESIDUAL, STATS, ACCUM, OUT_F32. */
+    DYK_EPI_ADDEND = 64   /* with DYK_EPI_BNBWD only: dz = v + add[b, y, x, co] (`add`: the gradient arriving over a plain
+                             [shortcut], same geometry and pixel stride as y).  The epilogue stores dz ITSELF (the next
+                             link of the residual chain needs it), rounded to dtype, and reduces the sums of
+                             da = dz * act'(...) computed from the rounded value; the BatchNorm-backward apply pass
+                             then applies act' itself.  Removes the gradient copy of the [shortcut] and the separate
+                             reduce pass for residual blocks. */
 };
 
 typedef struct DykConvDesc {
@@ -96,6 +102,7 @@ typedef struct DykConvDesc {
     double* stats;        /* [2*Cout] or NULL */
     const float* aux0;    /* DYK_EPI_BNBWD: saved mean [Cout] */
     const float* aux1;    /* DYK_EPI_BNBWD: saved rstd [Cout] */
+    const void* add;      /* DYK_EPI_ADDEND: gradient addend, dtype, laid out like y */
     int32_t dtype;
     int32_t ldx, ldy, ldr;          /* pixel strides in elements */
     int32_t B, Hi, Wi, Cin, Cout;

@@ -313,8 +313,35 @@ def test_dgrad_with_fused_batchnorm_backward_reduce(dtype, act):
         n = B * H * W
         assert torch.allclose(st[0], s1_ref, rtol=2e-3, atol=(5e-4 if dtype == torch.float32 else 5e-2) * n ** 0.5), hex(tune)
         assert torch.allclose(st[1], s2_ref, rtol=2e-3, atol=(5e-4 if dtype == torch.float32 else 5e-2) * n ** 0.5), hex(tune)
+    # residual chain (DYK_EPI_ADDEND): dz = dgrad + gradient over the plain [shortcut]; dz itself is stored (rounded to
+    # the storage dtype), the sums are those of da = dz * act'(u) taken from the rounded value
+    gadd = torch.randn(B, Cin, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        gadd = gadd.bfloat16().float()
+    dzt = dz + gadd
+    if dtype == torch.bfloat16:
+        dzt = dzt.bfloat16().float()
+    u2 = u.detach().clone().requires_grad_(True)
+    acts[act](u2).backward(dzt)
+    s1c, s2c = u2.grad.double().sum((0, 2, 3)), (u2.grad.double() * xhat.double()).sum((0, 2, 3))
+    addd = ops.to_nhwc(gadd.cuda(), dtype)
+    d.flags = L.EPI_BNBWD | L.EPI_ADDEND
+    d.add = addd.data_ptr()
+    for tune in (0, 64 | (2 << 8) | (1 << 12), 64 | (2 << 8) | (4 << 12)):
+        red.zero_()
+        out.zero_()
+        d.tune = tune
+        L.check(L.load().dyk_conv_igemm(ctypes.byref(d), None), "dyk_conv_igemm(BNBWD|ADDEND)")
+        got = ops.to_nchw(out).cpu()
+        err = (got - dzt).abs().max().item()
+        assert err <= tol * max(1.0, dzt.abs().max().item()), (hex(tune), err)
+        st = red.sum(0).cpu()
+        assert torch.allclose(st[0], s1c, rtol=2e-3, atol=(5e-4 if dtype == torch.float32 else 5e-2) * n ** 0.5), hex(tune)
+        assert torch.allclose(st[1], s2c, rtol=2e-3, atol=(5e-4 if dtype == torch.float32 else 5e-2) * n ** 0.5), hex(tune)
     # illegal flag combinations are rejected
     d.flags = L.EPI_BNBWD | L.EPI_ACCUM
+    assert L.load().dyk_conv_igemm(ctypes.byref(d), None) != 0
+    d.flags = L.EPI_ADDEND
     assert L.load().dyk_conv_igemm(ctypes.byref(d), None) != 0
 
 

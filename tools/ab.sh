@@ -1,0 +1,8 @@
+run() { env "$@" python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['ms_per_step'],2), round(d['value'],1))"; }
+run A=1
+run DYK_BNBWD_FUSE=0
+run DYK_CHAIN_FUSE=0
+run A=1
+run DYK_BNBWD_FUSE=0
