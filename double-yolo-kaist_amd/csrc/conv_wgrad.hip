@@ -367,13 +367,16 @@ int launch_wgrad(const DykWgradDesc* d, hipStream_t stream, int* query) {
 
 template <typename T, int BM>
 int dispatch_wgrad_n(const DykWgradDesc* d, hipStream_t s, int* query) {
-    if (d->Cin > 64) return launch_wgrad<T, BM, 128>(d, s, query);
+    const bool cap64 = ((d->tune >> 16) & 0xf) == 1;        // bits 16..19 = 1: tiles capped at 64 x 64 (small GEMMs: more
+                                                            // tiles, so fewer K splits -- partial planes -- fill the chip)
+    if (d->Cin > 64 && !cap64) return launch_wgrad<T, BM, 128>(d, s, query);
     if (d->Cin > 32) return launch_wgrad<T, BM, 64>(d, s, query);
     return launch_wgrad<T, BM, 32>(d, s, query);
 }
 template <typename T>
 int dispatch_wgrad(const DykWgradDesc* d, hipStream_t s, int* query) {
-    if (d->Cout > 64) return dispatch_wgrad_n<T, 128>(d, s, query);
+    const bool cap64 = ((d->tune >> 16) & 0xf) == 1;
+    if (d->Cout > 64 && !cap64) return dispatch_wgrad_n<T, 128>(d, s, query);
     if (d->Cout > 32) return dispatch_wgrad_n<T, 64>(d, s, query);
     return dispatch_wgrad_n<T, 32>(d, s, query);
 }

@@ -352,7 +352,7 @@ def test_wgrad_plane_mode_and_grad_reduce(dtype):
     import ctypes
     from dyk import lib as L
     from dyk import ops
-    B, Cin, Cout, H, W, k = 4, 64, 96, 24, 40, 3
+    B, Cin, Cout, H, W, k = 4, 96, 160, 24, 40, 3
     g = torch.Generator().manual_seed(21)
     x = torch.randn(B, Cin, H, W, generator=g)
     dy = torch.randn(B, Cout, H, W, generator=g)
@@ -376,7 +376,7 @@ def test_wgrad_plane_mode_and_grad_reduce(dtype):
     lib = L.load()
     plane = k * k * Cout * Cin
     outs = []
-    for tune in (2, 2 | (2 << 8)):                                        # 4-wave and K-grouped workgroups
+    for tune in (2, 2 | (2 << 8), 2 | (1 << 16), 2 | (2 << 8) | (1 << 16)):   # 4-wave / K-grouped workgroups, 64x64 tile cap
         d.tune, d.splits, d.part = tune, 0, None
         splits = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
         assert splits >= 2
