@@ -367,7 +367,7 @@ int launch_wgrad(const DykWgradDesc* d, hipStream_t stream, int* query) {
 
 template <typename T, int BM>
 int dispatch_wgrad_n(const DykWgradDesc* d, hipStream_t s, int* query) {
-    const bool cap64 = ((d->tune >> 16) & 0xf) == 1;        // bits 16..19 = 1: tiles capped at 64 x 64 (small GEMMs: more
+    const bool cap64 = ((d->tune >> 24) & 0xf) == 1;        // bits 24..27 = 1: tiles capped at 64 x 64 (small GEMMs: more
                                                             // tiles, so fewer K splits -- partial planes -- fill the chip)
     if (d->Cin > 64 && !cap64) return launch_wgrad<T, BM, 128>(d, s, query);
     if (d->Cin > 32) return launch_wgrad<T, BM, 64>(d, s, query);
@@ -375,7 +375,7 @@ int dispatch_wgrad_n(const DykWgradDesc* d, hipStream_t s, int* query) {
 }
 template <typename T>
 int dispatch_wgrad(const DykWgradDesc* d, hipStream_t s, int* query) {
-    const bool cap64 = ((d->tune >> 16) & 0xf) == 1;
+    const bool cap64 = ((d->tune >> 24) & 0xf) == 1;
     if (d->Cout > 64 && !cap64) return dispatch_wgrad_n<T, 128>(d, s, query);
     if (d->Cout > 32) return dispatch_wgrad_n<T, 64>(d, s, query);
     return dispatch_wgrad_n<T, 32>(d, s, query);

@@ -153,7 +153,7 @@ typedef struct DykWgradDesc {
     int8_t _pad;
     int32_t splits;                 /* K splits; <= 0 selects automatically */
     int32_t lddw;                   /* row stride of dw in floats; <= 0 means Cin */
-    int32_t tune;                   /* 0 = default; else LDS ring stages (2 | 3) | K-groups per workgroup (1 | 2) << 8 | tile cap << 16
+    int32_t tune;                   /* 0 = default; else LDS ring stages (2 | 3) | K-groups per workgroup (1 | 2) << 8 | tile cap << 24
                                        (1 = tiles of at most 64 x 64: more tiles, fewer K splits for small GEMMs) */
 } DykWgradDesc;
 

@@ -2,6 +2,7 @@ run() { env "$@" python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-ro
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['ms_per_step'],2), round(d['value'],1))"; }
 run A=1
-run DYK_WGRAD_CANDS=2,3,0x202,0x10002,0x10003,0x10202
+run DYK_WGRAD_CANDS=2,3,0x202
 run A=1
-run DYK_WGRAD_CANDS=2,3,0x202,0x10002,0x10003,0x10202
+run DYK_WGRAD_CANDS=2,3,0x202
+python -m pytest tests/test_gpu_conv.py tests/test_gpu_model.py -x -q 2>&1 | tail -3
