@@ -11,6 +11,11 @@ extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
     if (!d || !d->x || !d->w || !d->y) return DYK_ERR_ARG;
     if (d->ntaps < 0 || d->ntaps > DYK_MAX_TAPS) return DYK_ERR_ARG;
     if (d->B <= 0 || d->Hg <= 0 || d->Wg <= 0 || d->Cout <= 0 || d->Cin <= 0) return DYK_ERR_ARG;
+    if (d->ncls < 0 || d->ncls > 4) return DYK_ERR_ARG;
+    for (int c = 0; c < (d->ncls > 1 ? d->ncls : 0); ++c)
+        if (d->cls_first[c] < 0 || d->cls_ntaps[c] < 0 || d->cls_first[c] + d->cls_ntaps[c] > d->ntaps || d->cls_ooy[c] < 0 ||
+            d->cls_ooy[c] >= d->osy || d->cls_oox[c] < 0 || d->cls_oox[c] >= d->osx)
+            return DYK_ERR_ARG;
     if ((d->flags & DYK_EPI_STATS) && !d->stats) return DYK_ERR_ARG;
     if ((d->flags & DYK_EPI_RESIDUAL) && !d->res) return DYK_ERR_ARG;
     if ((d->flags & DYK_EPI_ADDEND) && (!(d->flags & DYK_EPI_BNBWD) || !d->add || ((uintptr_t)d->add % 16))) return DYK_ERR_ARG;

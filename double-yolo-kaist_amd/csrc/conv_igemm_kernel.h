@@ -478,7 +478,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const int HWg = a.Hg * a.Wg;
     const int Ntot = a.B * HWg;
     const int tiles_n = (Ntot + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // output-parity classes of a strided data gradient in one launch: class fastest, so the classes of a pixel tile
+    // run side by side on one XCD (shared gradient tile, interleaved output lines merge in its L2)
+    int ntaps = a.ntaps, tap0 = 0, ooy = a.ooy, oox = a.oox;
+    if (a.ncls > 1) {
+        const int c = bid % a.ncls;
+        bid /= a.ncls;
+        tap0 = a.cls_first[c]; ntaps = a.cls_ntaps[c]; ooy = a.cls_ooy[c]; oox = a.cls_oox[c];
+    }
     const int m0 = (bid / tiles_n) * BM;
     const int n0 = (bid % tiles_n) * BN;
 
@@ -493,19 +501,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             t_in[tid] = ((b * a.Hi + yi) * a.Wi + xi) * a.ldx;
             t_y[tid] = (short)yi;
             t_x[tid] = (short)xi;
-            const int py = yo * a.osy + a.ooy, px = xo * a.osx + a.oox;
+            const int py = yo * a.osy + ooy, px = xo * a.osx + oox;
             t_out[tid] = ((b * a.Ho + py) * a.Wo + px) * a.ldy;
             t_res[tid] = ((b * a.Ho + py) * a.Wo + px) * a.ldr;
         } else {
             t_in[tid] = 0; t_y[tid] = -20000; t_x[tid] = -20000; t_out[tid] = -1; t_res[tid] = 0;
         }
     }
-    if (tid >= 256 - 32 && tid < 256 - 32 + a.ntaps) {   // tap tables in LDS: no vector-memory loads inside the K loop
+    if (tid >= 256 - 32 && tid < 256 - 32 + ntaps) {   // tap tables in LDS: no vector-memory loads inside the K loop
         const int q = tid - (256 - 32);
-        const int dy = a.tdy[q], dx = a.tdx[q];
+        const int dy = a.tdy[tap0 + q], dx = a.tdx[tap0 + q];
         tap_dy[q] = dy; tap_dx[q] = dx;
         tap_x[q] = (dy * a.Wi + dx) * a.ldx;
-        tap_w[q] = a.twt[q] * a.Cout * a.Cin;
+        tap_w[q] = a.twt[tap0 + q] * a.Cout * a.Cin;
     }
     __syncthreads();
     if ((a.tune >> 19) & 1) return;            // ablation: tables only
@@ -520,7 +528,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const T* __restrict__ wg = (const T*)a.w;
     // bits 16.. of `tune` are ablation switches for kernel analysis (tools/gpu_probe.py ablate): never set by the plan
     const bool abl_nostore = (a.tune >> 16) & 1, abl_noloop = (a.tune >> 17) & 1;
-    const int S = abl_noloop ? 0 : (a.Cin / BK) * a.ntaps;
+    const int S = abl_noloop ? 0 : (a.Cin / BK) * ntaps;
     const int frow = lane & 15, fslot = lane >> 4;
 
     // `mid` (the DMA issue of a later step) runs between the first fragment reads and their MFMAs: the ~100 cycles per
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             b_off[j] = live ? t_in[row] + ls * EPV : 0;
             const int y0 = live ? t_y[row] : -20000, x0 = live ? t_x[row] : -20000;
             unsigned m = 0;
-            for (int q = 0; q < a.ntaps; ++q) {
+            for (int q = 0; q < ntaps; ++q) {
                 const int yi = y0 + tap_dy[q], xi = x0 + tap_dx[q];
                 if (((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi)) m |= 1u << q;
             }
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         int sc0 = 0, st = 0;
         auto stage_next = [&](int buf) {
             stage(buf, sc0, st);
-            if (++st == a.ntaps) { st = 0; sc0 += BK; }
+            if (++st == ntaps) { st = 0; sc0 += BK; }
         };
         if constexpr (PIPE >= 3) {
             // N-stage ring: AHEAD = N-1 steps are in flight while one is computed.  Workgroups that sit alone on a
@@ -933,7 +941,7 @@ int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     if (force_scatter) vec = false;
     if (vec) args.d.flags |= EPI_INTERNAL_VEC;
     else args.d.flags &= ~EPI_INTERNAL_VEC;
-    hipLaunchKernelGGL(kfn, dim3(tiles_n * tiles_m), dim3(256), lds, stream, args);
+    hipLaunchKernelGGL(kfn, dim3(tiles_n * tiles_m * (d->ncls > 1 ? d->ncls : 1)), dim3(256), lds, stream, args);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

@@ -45,6 +45,8 @@ class DykConvDesc(ctypes.Structure):
         ("isy", _i32), ("isx", _i32), ("osy", _i32), ("osx", _i32), ("ooy", _i32), ("oox", _i32),
         ("ntaps", _i32),
         ("tdy", _i8 * MAX_TAPS), ("tdx", _i8 * MAX_TAPS), ("twt", _i8 * MAX_TAPS), ("_pad", _i8),
+        ("ncls", _i8), ("cls_first", _i8 * 4), ("cls_ntaps", _i8 * 4), ("cls_ooy", _i8 * 4), ("cls_oox", _i8 * 4),
+        ("_pad2", _i8 * 3),
         ("act", _i32), ("flags", _i32), ("stats_slots", _i32), ("tune", _i32),
     ]
 

@@ -176,13 +176,26 @@ def conv2d_fwd(x, wp, k, stride, pad, Cout, *, act="linear", scale=None, shift=N
     return out
 
 
-def conv2d_dgrad(dy, wpt, k, stride, pad, Hi, Wi, Cin, *, out=None, accumulate=False):
-    """dx = conv_transpose(dy, w); dy [B,Ho,Wo,Cout], wpt = pack_weight(w, transposed=True)."""
+def conv2d_dgrad(dy, wpt, k, stride, pad, Hi, Wi, Cin, *, out=None, accumulate=False, merge=False):
+    """dx = conv_transpose(dy, w); dy [B,Ho,Wo,Cout], wpt = pack_weight(w, transposed=True).
+    merge: the parity classes of a strided conv in ONE launch (DykConvDesc.ncls) when they share the launch grid."""
     _require_cuda(dy, wpt)
     B, Ho, Wo, Cout = dy.shape
     if out is None:
         out = torch.empty((B, Hi, Wi, Cin), dtype=dy.dtype, device=dy.device)
-    for (py, px, Hg, Wg, taps) in dgrad_classes(k, pad, stride, Hi, Wi):
+    classes = dgrad_classes(k, pad, stride, Hi, Wi)
+    if merge and len(classes) > 1:
+        if not (all(c[4] for c in classes) and len({(c[2], c[3]) for c in classes}) == 1 and len(classes) <= 4):
+            raise ValueError("parity classes of this data gradient cannot share a launch")
+        d = make_conv_desc(dy, wpt, out, Hi=Ho, Wi=Wo, Cin=Cout, Cout=Cin, Hg=classes[0][2], Wg=classes[0][3], Ho=Hi, Wo=Wi,
+                           taps=[t for c in classes for t in c[4]], osy=stride, osx=stride, accumulate=accumulate)
+        d.ncls, q0 = len(classes), 0
+        for c, (py, px, _, _, taps) in enumerate(classes):
+            d.cls_first[c], d.cls_ntaps[c], d.cls_ooy[c], d.cls_oox[c] = q0, len(taps), py, px
+            q0 += len(taps)
+        check(load().dyk_conv_igemm(ctypes.byref(d), _stream()), "dyk_conv_igemm(dgrad, merged classes)")
+        return out
+    for (py, px, Hg, Wg, taps) in classes:
         d = make_conv_desc(dy, wpt, out, Hi=Ho, Wi=Wo, Cin=Cout, Cout=Cin, Hg=Hg, Wg=Wg, Ho=Hi, Wo=Wi,
                            taps=taps, osy=stride, osx=stride, ooy=py, oox=px, accumulate=accumulate)
         check(load().dyk_conv_igemm(ctypes.byref(d), _stream()), "dyk_conv_igemm(dgrad)")

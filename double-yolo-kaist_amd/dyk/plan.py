@@ -721,7 +721,16 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
                 prod["keep_dz"] = addend is not None
             classes = dgrad_classes(k, pad, stride, x_in.H, x_in.W)
-            for (py, px, Hg, Wg, taps) in classes:
+            # the parity classes of a strided conv's data gradient in one launch (DykConvDesc.ncls) when they all have
+            # taps, share the launch grid and fit the tap table
+            merged = (len(classes) in (2, 4) and all(c[4] for c in classes)
+                      and len({(c[2], c[3]) for c in classes}) == 1
+                      and sum(len(c[4]) for c in classes) <= L.MAX_TAPS
+                      and os.environ.get("DYK_DGRAD_MERGE", "1") != "0")
+            if merged:
+                classes = [(0, 0, classes[0][2], classes[0][3], [t for c in classes for t in c[4]], classes)]
+            for cls in classes:
+                (py, px, Hg, Wg, taps) = cls[:5]
                 if not taps and not first:
                     continue                      # nothing to accumulate for this parity class
                 d = L.DykConvDesc()
@@ -736,6 +745,11 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 d.ntaps = len(taps)
                 for q, (ty, tx, wt) in enumerate(taps):
                     d.tdy[q], d.tdx[q], d.twt[q] = ty, tx, wt
+                if merged:
+                    d.ncls, q0 = len(cls[5]), 0
+                    for c, (cpy, cpx, _, _, ctaps) in enumerate(cls[5]):
+                        d.cls_first[c], d.cls_ntaps[c], d.cls_ooy[c], d.cls_oox[c] = q0, len(ctaps), cpy, cpx
+                        q0 += len(ctaps)
                 d.ldx, d.ldy = dy.ld, gx.ld
                 d.act, d.flags = 0, (0 if first else L.EPI_ACCUM)
                 later(lambda d=d, dy=dy, gx=gx: (setattr(d, "x", ptr_of(dy)), setattr(d, "y", ptr_of(gx))))
@@ -1138,7 +1152,7 @@ def autotune(plan, cache=None):
     for (op, d) in plan.fwd + plan.bwd:
         if op == L.OP_CONV:
             key = ("c", d.dtype, d.B, d.Cin, d.Cout, d.Hg, d.Wg, d.ntaps, d.isy, d.osy,
-                   d.flags & (L.EPI_STATS | L.EPI_OUT_F32 | L.EPI_BNBWD))
+                   d.flags & (L.EPI_STATS | L.EPI_OUT_F32 | L.EPI_BNBWD), d.ncls)
         elif op == L.OP_WGRAD:
             key = ("w", d.dtype, d.B, d.Cin, d.Cout, d.Ho, d.Wo, d.ntaps, d.isy)
         else:

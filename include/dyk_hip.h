@@ -114,6 +114,14 @@ typedef struct DykConvDesc {
     int8_t tdx[DYK_MAX_TAPS];
     int8_t twt[DYK_MAX_TAPS];
     int8_t _pad;
+    /* Output-parity classes in ONE launch (data gradient of a stride-s conv): ncls > 1 splits the tap table into
+     * ncls runs, class c = taps [cls_first[c], +cls_ntaps[c]) written at output offset (cls_ooy[c], cls_oox[c]);
+     * ntaps is the total, ooy/oox are ignored, every class walks the same Hg x Wg grid.  Workgroups of the classes of
+     * one pixel tile get consecutive ids (one XCD): the gradient tile is fetched once and the interleaved output
+     * lines meet in that L2.  ncls <= 1: a single class (ntaps, ooy, oox). */
+    int8_t ncls;
+    int8_t cls_first[4], cls_ntaps[4], cls_ooy[4], cls_oox[4];
+    int8_t _pad2[3];
     int32_t act;                    /* DYK_ACT_* applied after the affine */
     int32_t flags;                  /* DYK_EPI_* */
     int32_t stats_slots;            /* number of stats replicas (>= 1; 0 is read as 1) */

@@ -64,6 +64,10 @@ def test_conv_fwd_and_dgrad(case, dtype):
     dx_nchw = ops.to_nchw(dx).cpu()
     err = (dx_nchw - dx_ref).abs().max().item()
     assert err <= tol * max(1.0, dx_ref.abs().max().item()), "dgrad max err %g" % err
+    # stride > 1, even maps: the parity classes in one launch (DykConvDesc.ncls) -- same arithmetic per class, same bits
+    if s > 1 and H % s == 0 and W % s == 0 and k >= s:
+        dx1 = ops.conv2d_dgrad(dyd, wpt, k, s, pad, H, W, Cin, merge=True)
+        assert torch.equal(dx1, dx), "merged parity classes differ from the per-class launches"
     # accumulate flag: second pass adds onto the first
     ops.conv2d_dgrad(dyd, wpt, k, s, pad, H, W, Cin, out=dx, accumulate=True)
     err = (ops.to_nchw(dx).cpu() - 2 * dx_ref).abs().max().item()
