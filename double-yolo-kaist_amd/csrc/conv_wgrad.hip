@@ -381,6 +381,217 @@ int dispatch_wgrad(const DykWgradDesc* d, hipStream_t s, int* query) {
     return dispatch_wgrad_n<T, 32>(d, s, query);
 }
 
+// ======================================================================================
+// Multi-tap weight gradient for 3x3 convs with few channels (the early layers: 32..128 channels on 256x320 / 128x160
+// maps).  The per-tap kernel above re-stages dy and x for each of the nine taps, which makes those layers L2-bandwidth
+// bound (9 x 250 MB per launch through L2 at 256x320).  Here one K step is a segment of KW consecutive output pixels
+// of one output row: its dy tile [KW][64 co] and the x tile WITH HALO [3 input rows][(KW-1)*SI + 3 pixels][BN ci] are
+// staged once, and the nine taps are row-shifted (stride-SI) views of the halo tile -- each lane of the transposing
+// LDS read supplies its own address, so a shifted / strided pixel run costs nothing extra.  The dy fragments are read
+// once per step and feed all nine taps; a workgroup holds the nine [64 x BN] accumulator tiles (72 / 144 VGPRs).
+// bf16 only; taps must be the standard 3x3 / pad 1 table (tdy = t/3 - 1, tdx = t%3 - 1); Wo % KW == 0.
+template <int BN, int SI, int KW>
+__global__ __launch_bounds__(256) void conv_wgrad_mt_kernel(const DykWgradDesc a, const int splits, const int chunk) {
+    using T = bf16_t;
+    constexpr int BM = 64;
+    constexpr int XW = (KW - 1) * SI + 3;                      // halo pixels per input row
+    constexpr int HROWS = 3 * XW;
+    constexpr int VPR_A = BM / 8, VPR_B = BN / 8;              // 16-byte vectors per tile row
+    constexpr int RPI_A = 64 / VPR_A, RPI_B = 64 / VPR_B;      // tile rows per DMA wave instruction
+    constexpr int NI_A = KW / RPI_A;                           // 8 (KW 64) | 4 (KW 32): multiples of 4
+    constexpr int NI_B = ((HROWS + RPI_B - 1) / RPI_B + 3) / 4 * 4;
+    constexpr int NIA_W = NI_A / 4, NIB_W = NI_B / 4;
+    constexpr int A_BYTES = NI_A * 1024, B_BYTES = NI_B * 1024;
+    constexpr int WTN = BN / 2;                                // 2 x 2 waves over (64 co, BN ci)
+    constexpr int MI = 2, NI = WTN / 16;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                                           // [2][A_BYTES]  dy tile  [KW][64]
+    char* sB = smem + 2 * A_BYTES;                             // [2][B_BYTES]  x halo tile [3 * XW (+pad)][BN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tiles_m = (a.Cout + BM - 1) / BM;
+    const int tiles_n = (a.Cin + BN - 1) / BN;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid % tiles_m; bid /= tiles_m;
+    const int tn = bid % tiles_n;
+    const int sp = bid / tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int SPR = a.Wo / KW;                                 // segments per output row
+    const int nseg = a.B * a.Ho * SPR;
+    const int g_begin = sp * chunk;
+    const int g_end = min(nseg, g_begin + chunk);
+    const int S = g_end > g_begin ? g_end - g_begin : 0;
+    const T* __restrict__ dyg = (const T*)a.dy;
+    const T* __restrict__ xg = (const T*)a.x;
+
+    f32x4_t acc[9][MI][NI];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[t][mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    auto tr_read = [&](const char* p0, const char* p1) -> uint4 {
+        v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS v4i16_t*)(LDS_AS char*)p0);
+        v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS v4i16_t*)(LDS_AS char*)p1);
+        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        return make_uint4(l2.x, l2.y, h2.x, h2.y);
+    };
+    auto compute = [&](const char* pa, const char* pb) {
+        const int i16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < KW / 32; ++kk) {
+            const int r0 = kk * 32 + kq * 8 + (i16 >> 2);     // this lane's K pixel (and r0 + 4)
+            uint4 fa[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int ch = wm * 32 + mi * 16 + 4 * (i16 & 3);
+                fa[mi] = tr_read(pa + wg_off<T, BM>(r0, ch), pa + wg_off<T, BM>(r0 + 4, ch));
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int h0 = (t / 3) * XW + r0 * SI + (t % 3);      // halo row of K pixel r0 under tap t
+                uint4 fb[NI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int ch = wn * WTN + ni * 16 + 4 * (i16 & 3);
+                    fb[ni] = tr_read(pb + wg_off<T, BN>(h0, ch), pb + wg_off<T, BN>(h0 + 4 * SI, ch));
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, fa[mi]), __builtin_bit_cast(bf16x8_t, fb[ni]), acc[t][mi][ni], 0, 0, 0);
+            }
+        }
+    };
+
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(wid);
+        const T* zero = (const T*)dyk_wg_zero_page;
+        int a_row[NIA_W], a_ch[NIA_W];
+#pragma unroll
+        for (int j = 0; j < NIA_W; ++j) {
+            a_row[j] = (j * 4 + wv) * RPI_A + lane / VPR_A;
+            a_ch[j] = m0 + wg_logical_ch<T, BM>(a_row[j], lane % VPR_A);
+        }
+        int b_rr[NIB_W], b_jj[NIB_W], b_ch[NIB_W];
+#pragma unroll
+        for (int j = 0; j < NIB_W; ++j) {
+            const int h = (j * 4 + wv) * RPI_B + lane / VPR_B;
+            b_rr[j] = h < HROWS ? h / XW : -100000;            // beyond the halo tile: always out of bounds -> zero page
+            b_jj[j] = h % XW;
+            b_ch[j] = n0 + wg_logical_ch<T, BN>(h, lane % VPR_B);
+        }
+        int seg = g_begin;
+        auto stage_next = [&](int buf) {
+            const int b = seg / (a.Ho * SPR);
+            const int r = seg - b * (a.Ho * SPR);
+            const int yo = r / SPR, xo0 = (r - yo * SPR) * KW;
+            char* da = sA + buf * A_BYTES;
+            char* db = sB + buf * B_BYTES;
+            const long nbase = ((long)b * a.Ho + yo) * a.Wo + xo0;
+#pragma unroll
+            for (int j = 0; j < NIA_W; ++j) {
+                const T* src = a_ch[j] < a.Cout ? dyg + (nbase + a_row[j]) * a.lddy + a_ch[j] : zero;
+                wg_glds16(src, wg_lds_addr(da + (j * 4 + wv) * 1024));
+            }
+#pragma unroll
+            for (int j = 0; j < NIB_W; ++j) {
+                const int yi = yo * SI + b_rr[j] - 1, xi = xo0 * SI + b_jj[j] - 1;
+                const bool ok = b_ch[j] < a.Cin && ((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi);
+                const T* src = ok ? xg + ((long)(b * a.Hi + yi) * a.Wi + xi) * a.ldx + b_ch[j] : zero;
+                wg_glds16(src, wg_lds_addr(db + (j * 4 + wv) * 1024));
+            }
+            ++seg;
+        };
+        if (S > 0) stage_next(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < S; ++s) {
+            if (s + 1 < S) stage_next((s + 1) & 1);
+            compute(sA + (s & 1) * A_BYTES, sB + (s & 1) * B_BYTES);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // ---- epilogue: acc[t][mi][ni][r] = D_t[co = m0 + wm*32 + mi*16 + (lane>>4)*4 + r][ci = n0 + wn*WTN + ni*16 + (lane&15)]
+    const int lddw = a.Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const long toff = (long)a.twt[t] * a.Cout * lddw;
+        float* dw = a.part ? a.part + (long)sp * a.part_stride + toff : a.dw + toff;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = m0 + wm * 32 + mi * 16 + (lane >> 4) * 4 + r;
+                if (co >= a.Cout) continue;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int ci = n0 + wn * WTN + ni * 16 + (lane & 15);
+                    if (ci >= a.Cin) continue;
+                    if (a.part) dw[(long)co * lddw + ci] = acc[t][mi][ni][r];
+                    else unsafeAtomicAdd(dw + (long)co * lddw + ci, acc[t][mi][ni][r]);
+                }
+            }
+        }
+    }
+}
+
+// the multi-tap kernel covers: bf16, the standard 3x3 / pad 1 tap table, stride 1 | 2, Wo a multiple of 32, whole 8-channel
+// vectors, plain [tap][Cout][Cin] gradient rows
+bool mt_eligible(const DykWgradDesc* d) {
+    if (d->dtype != DYK_BF16 || d->ntaps != 9 || d->isy != d->isx || (d->isy != 1 && d->isy != 2)) return false;
+    if (d->Wo % 32 || d->Cin % 8 || d->Cout % 8 || (d->lddw > 0 && d->lddw != d->Cin)) return false;
+    for (int t = 0; t < 9; ++t)
+        if (d->tdy[t] != t / 3 - 1 || d->tdx[t] != t % 3 - 1) return false;
+    return true;
+}
+
+template <int BN, int SI, int KW>
+int launch_wgrad_mt(const DykWgradDesc* d, hipStream_t stream, int* query) {
+    constexpr int XW = (KW - 1) * SI + 3, HROWS = 3 * XW, RPI_B = 64 / (BN / 8);
+    constexpr int NI_B = ((HROWS + RPI_B - 1) / RPI_B + 3) / 4 * 4;
+    constexpr size_t lds = 2 * ((size_t)(KW / 8) * 1024 + (size_t)NI_B * 1024);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    auto kfn = conv_wgrad_mt_kernel<BN, SI, KW>;
+    if (!attr_set) {
+        DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int tiles = dyk_div_up(d->Cout, 64) * dyk_div_up(d->Cin, BN);
+    const int nseg = d->B * d->Ho * (d->Wo / KW);
+    int splits = d->splits;
+    if (splits <= 0) {
+        splits = dyk_div_up(512, tiles);
+        const int max_splits = nseg / 16 > 0 ? nseg / 16 : 1;          // at least 16 segments per workgroup
+        if (splits > max_splits) splits = max_splits;
+    }
+    if (splits > nseg) splits = nseg;
+    const int chunk = dyk_div_up(nseg, splits);
+    if (!(d->part && d->splits > 0)) splits = dyk_div_up(nseg, chunk);
+    if (query) { *query = splits; return DYK_OK; }
+    hipLaunchKernelGGL(kfn, dim3(tiles * splits), dim3(256), lds, stream, *d, splits, chunk);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+int dispatch_wgrad_mt(const DykWgradDesc* d, hipStream_t s, int* query) {
+    const bool wide = d->Cin > 32;
+    if (d->Wo % 64 == 0 && d->isy == 1) return wide ? launch_wgrad_mt<64, 1, 64>(d, s, query) : launch_wgrad_mt<32, 1, 64>(d, s, query);
+    if (d->isy == 1) return wide ? launch_wgrad_mt<64, 1, 32>(d, s, query) : launch_wgrad_mt<32, 1, 32>(d, s, query);
+    if (d->Wo % 64 == 0 && !wide) return launch_wgrad_mt<32, 2, 64>(d, s, query);
+    return wide ? launch_wgrad_mt<64, 2, 32>(d, s, query) : launch_wgrad_mt<32, 2, 32>(d, s, query);
+}
+
 // one block per 1024-element chunk of one table entry (binary search over chunk_begin, as dyk_transpose_taps)
 __global__ __launch_bounds__(256) void grad_reduce_kernel(float* __restrict__ G, const float* __restrict__ part,
                                                           const DykGradReduceEntry* __restrict__ tab, int n_entries) {
@@ -426,6 +637,7 @@ extern "C" int dyk_conv_wgrad(const DykWgradDesc* d, void* stream) {
     if ((long)d->B * d->Ho * d->Wo >= (1L << 31)) return DYK_ERR_ARG;
     if (d->part && (d->part_stride < (int64_t)d->Cout * (d->lddw > 0 ? d->lddw : d->Cin))) return DYK_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (((d->tune >> 28) & 7) == 1 && mt_eligible(d)) return dispatch_wgrad_mt(d, s, nullptr);    // multi-tap 3x3 variant
     if (d->dtype == DYK_BF16) return dispatch_wgrad<bf16_t>(d, s, nullptr);
     if (d->dtype == DYK_F32) return dispatch_wgrad<float>(d, s, nullptr);
     return DYK_ERR_ARG;
@@ -436,7 +648,8 @@ extern "C" int dyk_conv_wgrad_splits(const DykWgradDesc* d) {
         return DYK_ERR_ARG;
     int q = 0;
     int rc = DYK_ERR_ARG;
-    if (d->dtype == DYK_BF16) rc = dispatch_wgrad<bf16_t>(d, nullptr, &q);
+    if (((d->tune >> 28) & 7) == 1 && mt_eligible(d)) rc = dispatch_wgrad_mt(d, nullptr, &q);
+    else if (d->dtype == DYK_BF16) rc = dispatch_wgrad<bf16_t>(d, nullptr, &q);
     else if (d->dtype == DYK_F32) rc = dispatch_wgrad<float>(d, nullptr, &q);
     return rc == DYK_OK ? q : rc;
 }

@@ -202,7 +202,7 @@ def conv2d_dgrad(dy, wpt, k, stride, pad, Hi, Wi, Cin, *, out=None, accumulate=F
     return out
 
 
-def conv2d_wgrad(x, dy, k, stride, pad, *, dw=None, splits=0, Cin=None, Cout=None):
+def conv2d_wgrad(x, dy, k, stride, pad, *, dw=None, splits=0, Cin=None, Cout=None, tune=0):
     """dw[t][co][ci] += sum_n dy[n][co] x[src(n,t)][ci]  (fp32, packed tap-major order)."""
     _require_cuda(x, dy)
     B, Hi, Wi, Cx = x.shape
@@ -223,6 +223,7 @@ def conv2d_wgrad(x, dy, k, stride, pad, *, dw=None, splits=0, Cin=None, Cout=Non
         d.tdy[i], d.tdx[i], d.twt[i] = ty, tx, wt
     d.splits = splits
     d.lddw = 0
+    d.tune = tune
     check(load().dyk_conv_wgrad(ctypes.byref(d), _stream()), "dyk_conv_wgrad")
     return dw
 

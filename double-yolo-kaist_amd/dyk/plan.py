@@ -1126,8 +1126,8 @@ def _conv_candidates(d):
     return out
 
 
-_WGRAD_CANDIDATES = [2, 3, 2 | (2 << 8), 2 | (1 << 24), 3 | (1 << 24), 2 | (2 << 8) | (1 << 24)]
-# LDS ring stages | K-groups per workgroup << 8 | tile cap << 24 (1 = 64 x 64)
+_WGRAD_CANDIDATES = [2, 3, 2 | (2 << 8), 2 | (1 << 24), 3 | (1 << 24), 2 | (2 << 8) | (1 << 24), 2 | (1 << 28)]
+# LDS ring stages | K-groups per workgroup << 8 | tile cap << 24 (1 = 64 x 64) | 1 << 28 = multi-tap 3x3 kernel
 
 
 def _time_launch(fn, desc, stream, reps=3):

@@ -162,7 +162,9 @@ typedef struct DykWgradDesc {
     int32_t splits;                 /* K splits; <= 0 selects automatically */
     int32_t lddw;                   /* row stride of dw in floats; <= 0 means Cin */
     int32_t tune;                   /* 0 = default; else LDS ring stages (2 | 3) | K-groups per workgroup (1 | 2) << 8 | tile cap << 24
-                                       (1 = tiles of at most 64 x 64: more tiles, fewer K splits for small GEMMs) */
+                                       (1 = tiles of at most 64 x 64: more tiles, fewer K splits for small GEMMs) | 1 << 28: multi-tap
+                                       kernel (3x3 / pad 1, bf16, Wo % 32 == 0: dy and the x halo tile staged once for all nine
+                                       taps; ignored where it does not apply) */
 } DykWgradDesc;
 
 int dyk_conv_wgrad(const DykWgradDesc* desc, void* stream);

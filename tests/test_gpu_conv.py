@@ -435,3 +435,58 @@ def test_conv_at_baseline_size(case):
     ref = dw_ref.permute(2, 3, 0, 1).reshape(k * k, Cout, Cin)
     err = (dw.cpu() - ref).abs().max().item()
     assert err <= 2e-3 * ref.abs().max().item(), err
+
+
+@pytest.mark.parametrize("case", [
+    # (B, Cin, Cout, H, W, stride): H, W = input size; Wo must be a multiple of 32
+    (2, 32, 64, 12, 64, 1),       # KW 64, BN 32
+    (2, 64, 64, 10, 32, 1),       # KW 32, BN 64
+    (1, 64, 128, 9, 96, 1),       # KW 32 (96 % 64 != 0), two Cout tiles
+    (2, 32, 64, 16, 128, 2),      # stride 2, KW 64
+    (2, 64, 128, 12, 64, 2),      # stride 2, KW 32, BN 64
+    (1, 24, 40, 7, 64, 1),        # channel counts off the tiles
+    (1, 96, 64, 6, 64, 1),        # two Cin tiles, the second ragged
+])
+def test_wgrad_multi_tap_kernel(case):
+    """tune bit 28: dy and the x halo tile staged once for all nine taps (bf16, 3x3 / pad 1) -- atomic mode and plane
+    mode against torch's conv2d_weight on the same rounded operands."""
+    import ctypes
+    from dyk import lib as L
+    from dyk import ops
+    B, Cin, Cout, H, W, s = case
+    k, dtype = 3, torch.bfloat16
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    assert Wo % 32 == 0
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g).bfloat16().float()
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, stride=s, padding=1).permute(2, 3, 0, 1).reshape(9, Cout, Cin)
+    xd, dyd = ops.to_nhwc(x.cuda(), dtype), ops.to_nhwc(dy.cuda(), dtype)
+    tol = 2e-4 * ref.abs().max().item()
+    base = ops.conv2d_wgrad(xd, dyd, k, s, 1)
+    mt = ops.conv2d_wgrad(xd, dyd, k, s, 1, tune=2 | (1 << 28))
+    assert (base.cpu() - ref).abs().max().item() <= tol
+    assert (mt.cpu() - ref).abs().max().item() <= tol, (mt.cpu() - ref).abs().max().item()
+    # plane mode
+    d = L.DykWgradDesc()
+    d.x, d.dy = xd.data_ptr(), dyd.data_ptr()
+    d.dtype = ops.dtype_code(dtype)
+    d.ldx, d.lddy = ops.nhwc_ld(xd), ops.nhwc_ld(dyd)
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, Cin, Ho, Wo, Cout
+    d.isy = d.isx = s
+    taps = ops.fwd_taps(k, 1)
+    d.ntaps = len(taps)
+    for i, (ty, tx, wt) in enumerate(taps):
+        d.tdy[i], d.tdx[i], d.twt[i] = ty, tx, wt
+    d.tune = 2 | (1 << 28)
+    lib = L.load()
+    splits = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
+    assert splits >= 1
+    plane = 9 * Cout * Cin
+    part = torch.full((splits * plane,), float("nan"), device="cuda")
+    G = torch.zeros(plane, device="cuda")
+    d.dw, d.part, d.part_stride, d.splits = G.data_ptr(), part.data_ptr(), plane, splits
+    L.check(lib.dyk_conv_wgrad(ctypes.byref(d), None), "dyk_conv_wgrad(multi-tap, planes)")
+    got = part.view(splits, 9, Cout, Cin).sum(0)
+    assert bool(torch.isfinite(got).all())
+    assert (got.cpu() - ref).abs().max().item() <= tol
