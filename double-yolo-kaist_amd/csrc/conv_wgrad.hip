@@ -192,6 +192,8 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc
             b_img[j] = b; b_yo[j] = r / a.Wo; b_xo[j] = r - b_yo[j] * a.Wo;
         }
         int sp0 = p_begin;                       // first pixel of the next step to stage
+        const int adv_q = ROWS / a.Wo, adv_r = ROWS - adv_q * a.Wo;
+        const bool adv_fast = adv_q + 1 <= 2 * a.Ho;
         auto stage_next = [&](int buf) {
             char* da = sA + buf * A_BYTES;
             char* db = sB + buf * B_BYTES;
@@ -210,10 +212,30 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc
                 const bool ok = n < p_end && c < a.Cin && ((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi);
                 const T* src = ok ? xg + ((long)(b_img[j] * a.Hi + yi) * a.Wi + xi) * a.ldx + c : zero;
                 wg_glds16(src, wg_lds_addr(db + (j * 4 + wv) * 1024));
-                int xo = b_xo[j] + ROWS, yo = b_yo[j], bb = b_img[j];
-                while (xo >= a.Wo) { xo -= a.Wo; ++yo; }
-                while (yo >= a.Ho) { yo -= a.Ho; ++bb; }
-                b_xo[j] = xo; b_yo[j] = yo; b_img[j] = bb;
+            }
+            // advance the per-lane (image, row, column) by ROWS pixels.  Straight-line code on every real map (two
+            // conditional subtractions cover adv_q + 1 <= 2 * Ho); per-lane wrap loops -- exec-mask branches that cost
+            // more than the MFMA block of a K step -- only on maps of a few pixels
+            if (adv_fast) {
+#pragma unroll
+                for (int j = 0; j < NIB_W; ++j) {
+                    int xo = b_xo[j] + adv_r, yo = b_yo[j] + adv_q, bb = b_img[j];
+                    const bool cx = xo >= a.Wo;
+                    xo -= cx ? a.Wo : 0; yo += cx ? 1 : 0;
+                    const bool c1 = yo >= a.Ho;
+                    yo -= c1 ? a.Ho : 0; bb += c1 ? 1 : 0;
+                    const bool c2 = yo >= a.Ho;
+                    yo -= c2 ? a.Ho : 0; bb += c2 ? 1 : 0;
+                    b_xo[j] = xo; b_yo[j] = yo; b_img[j] = bb;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NIB_W; ++j) {
+                    int xo = b_xo[j] + ROWS, yo = b_yo[j], bb = b_img[j];
+                    while (xo >= a.Wo) { xo -= a.Wo; ++yo; }
+                    while (yo >= a.Ho) { yo -= a.Ho; ++bb; }
+                    b_xo[j] = xo; b_yo[j] = yo; b_img[j] = bb;
+                }
             }
             sp0 += ROWS;
         };
