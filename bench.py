@@ -233,20 +233,31 @@ def main():
     # images a cold start at lr0 drives box sizes to 0 within a few steps, where the CIoU term atan(w/h) has
     # a 0*inf gradient in the reference's own math (and here) -- the warm-up is what the reference trains with.
     it = [0]
+    host_tl = bool(os.environ.get("DYK_HOST_TIMELINE"))     # analysis: when does the host return from each phase
 
     def step():
         alpha = min(it[0] / 1000.0, 1.0)
         opt.param_groups[0]["lr"] = hyp["lr0"] * (0.001 * (1 - alpha) + alpha)
         it[0] += 1
+        tl = [time.perf_counter()] if host_tl else None
         v = v8.float() / 255.0                       # kaist_train_eval_utils.py:54-55
         l = l8.float() / 255.0
         pred = model(v, l)
+        if host_tl: tl.append(time.perf_counter())
         ld = compute_loss(pred, targets, model)
         loss = ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]
+        if host_tl: tl.append(time.perf_counter())
         loss.backward()
+        if host_tl: tl.append(time.perf_counter())
         if reducer is not None:
             reducer.all_reduce()
         opt.step()
+        if host_tl:
+            tl.append(time.perf_counter())
+            torch.cuda.synchronize()
+            tl.append(time.perf_counter())
+            print("host timeline ms: fwd %.2f loss %.2f bwd %.2f opt %.2f | gpu drained at %.2f" % tuple(
+                (b - tl[0]) * 1e3 for b in tl[1:]), file=sys.stderr)
         return loss
 
     for _ in range(args.warmup):
