@@ -92,14 +92,17 @@ if "ablate" in what:
     import ctypes as C
     from dyk import lib as L
     rows = []
-    for (ci, co, H, W, k) in [(128, 128, 64, 80, 1), (64, 64, 256, 320, 1), (256, 256, 32, 40, 1), (128, 128, 64, 80, 3)]:
+    shapes = [(128, 128, 64, 80, 1), (64, 64, 256, 320, 1), (256, 256, 32, 40, 1), (128, 128, 64, 80, 3)]
+    if os.environ.get("PROBE_EARLY"):
+        shapes = [(32, 64, 256, 320, 3), (64, 32, 256, 320, 3), (64, 64, 256, 320, 1), (64, 32, 256, 320, 1)]
+    for (ci, co, H, W, k) in shapes:
         B, dt = 16, torch.bfloat16
         x = torch.randn(B, H, W, ci, device="cuda").to(dt)
         w = torch.randn(co, ci, k, k, device="cuda") * 0.05
         wp = ops.pack_weight(w, dt)
         out = torch.empty(B, H, W, co, device="cuda", dtype=dt)
         stats = torch.zeros(64 * co, dtype=torch.float64, device="cuda")
-        for name, tune, st in [("default", 0, None), ("stats", 0, stats), ("nostore", 1 << 16, None), ("noloop", 1 << 17, None),
+        for name, tune, st in [("t160", 64 | (2 << 8) | (2 << 12), None), ("t160 stats", 64 | (2 << 8) | (2 << 12), stats), ("t160 noloop", 64 | (2 << 8) | (2 << 12) | (1 << 17), None), ("t160 tables", 64 | (2 << 8) | (2 << 12) | (1 << 19), None), ("t160 noepi", 64 | (2 << 8) | (2 << 12) | (1 << 20), None),("default", 0, None), ("stats", 0, stats), ("nostore", 1 << 16, None), ("noloop", 1 << 17, None),
                                ("noloop+nostore", 3 << 16, None), ("bkb128", 128 | (2 << 8), None), ("bkb64p3", 64 | (3 << 8), None),
                                ("empty", 1 << 18, None), ("tables", 1 << 19, None), ("noepi", 1 << 20, None), ("noloop+noepi", (1 << 20) | (1 << 17), None)]:
             d = ops.make_conv_desc(x, wp, out, Hi=H, Wi=W, Cin=ci, Cout=co, Hg=H, Wg=W, Ho=H, Wo=W, taps=ops.fwd_taps(k, k // 2), stats=st)
