@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             a_ok[j] = (inst < NI_A) && (co < a.Cout);
             a_off[j] = co * a.Cin + ls * EPV;
         }
-        int b_off[NIB_W]; unsigned b_mask[NIB_W];
+        int b_off[NIB_W];
         int b_y0[NIB_W], b_x0[NIB_W];
 #pragma unroll
         for (int j = 0; j < NIB_W; ++j) {
@@ -584,27 +584,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             const bool live = (NI_B % 4 == 0) || inst < NI_B;
             b_off[j] = live ? t_in[row] + ls * EPV : 0;
             b_y0[j] = live ? t_y[row] : -20000; b_x0[j] = live ? t_x[row] : -20000;
-            b_mask[j] = 0;
-        }
-        // which taps of each staged row fall inside the image.  Taps outermost, four per 16-byte LDS read of the tap
-        // tables: a per-row loop over single taps was a chain of dependent LDS round trips (NIB_W x ntaps x ~150 cycles,
-        // 1.9 us per workgroup on a 3x3 conv -- 15 % of the early layers' launch time)
-        for (int q0 = 0; q0 < ntaps; q0 += 4) {
-            const int4 dy4 = *(const int4*)(tap_dy + q0), dx4 = *(const int4*)(tap_dx + q0);
-            const int dys[4] = {dy4.x, dy4.y, dy4.z, dy4.w}, dxs[4] = {dx4.x, dx4.y, dx4.z, dx4.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool qv = q0 + i < ntaps;                 // entries past ntaps are stale LDS
-#pragma unroll
-                for (int j = 0; j < NIB_W; ++j) {
-                    const int yi = b_y0[j] + dys[i], xi = b_x0[j] + dxs[i];
-                    if (qv && ((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi)) b_mask[j] |= 1u << (q0 + i);
-                }
-            }
         }
         const T* zero = (const T*)dyk_zero_page;
         auto stage = [&](int buf, int c0, int t) {
             const int toff = tap_x[t] + c0;
+            const int tdy_t = tap_dy[t], tdx_t = tap_dx[t];
             const long wbase = (long)tap_w[t] + c0;
             char* da = sA + buf * A_BYTES;
             char* db = sB + buf * B_BYTES;
@@ -622,7 +606,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
             for (int j = 0; j < NIB_W; ++j) {
                 const int inst = j * 4 + wv;
-                const T* src = ((b_mask[j] >> t) & 1u) ? xg + (long)b_off[j] + toff : zero;
+                // in-image test of this row under tap t: five VALU ops in the shadow of the step's MFMAs (a per-row tap
+                // bitmask built in the prologue cost ~400 exposed instructions per workgroup on a 3x3 conv)
+                const bool ok = ((unsigned)(b_y0[j] + tdy_t) < (unsigned)a.Hi) && ((unsigned)(b_x0[j] + tdx_t) < (unsigned)a.Wi);
+                const T* src = ok ? xg + (long)b_off[j] + toff : zero;
                 glds16(src, lds_addr_of((NI_B % 4 == 0 || inst < NI_B) ? db + inst * 1024 : sink));
             }
         };
