@@ -1,9 +1,9 @@
-run() { env "$@" python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "
+#!/bin/bash
+# In-call A/B of bench.py variants on ONE GPU box (boxes differ by a few tenths of a ms: never compare across calls).
+#   gpurun -- 'bash tools/ab.sh "A=1" "DYK_BNBWD_FUSE=0" "DYK_LIB=double-yolo-kaist_amd/csrc/libdyk_var_x.so"'
+# Each argument is an environment assignment list for one variant; every variant runs twice, interleaved.
+run() { env $1 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['ms_per_step'],2), round(d['value'],1))"; }
-D=double-yolo-kaist_amd/csrc
-python -m pytest tests/test_gpu_conv.py -x -q 2>&1 | tail -2
-for i in 1 2; do
-run DYK_LIB=$D/libdyk_var_head.so
-run DYK_LIB=$D/libdyk_var_inloop.so
-done
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['ms_per_step'],2), 'ms', round(d['value'],1), 'pairs/s')"; }
+[ $# -eq 0 ] && set -- "A=1"
+for rep in 1 2; do for v in "$@"; do run "$v"; done; done
