@@ -6,6 +6,7 @@ int dyk_conv_launch_n128(const DykConvDesc* d, hipStream_t s);
 int dyk_conv_launch_n80(const DykConvDesc* d, hipStream_t s);
 int dyk_conv_launch_n160(const DykConvDesc* d, hipStream_t s);
 int dyk_conv_launch_halo(const DykConvDesc* d, hipStream_t s, int th);
+int dyk_conv_launch_kg(const DykConvDesc* d, hipStream_t s);
 
 extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
     if (!d || !d->x || !d->w || !d->y) return DYK_ERR_ARG;
@@ -37,6 +38,10 @@ extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
     if (d->Hi > 16000 || d->Wi > 16000) return DYK_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int tile = d->dtype == DYK_BF16 ? (d->tune >> 12) & 0xf : 0;      // 80 / 160 pixel tiles are built for bf16 only
+    if (((d->tune >> 28) & 7) == 1) {      // K-grouped workgroups (conv_igemm_kg.hip); generic tiles where they do not apply
+        const int rc = dyk_conv_launch_kg(d, s);
+        if (rc != DYK_ERR_UNSUPPORTED) return rc;
+    }
     if (tile == 3 || tile == 4) {          // 3x3 halo kernel; falls back to the generic tiles when the problem does not fit it
         const int rc = dyk_conv_launch_halo(d, s, tile == 3 ? 4 : 8);
         if (rc != DYK_ERR_UNSUPPORTED) return rc;

@@ -434,9 +434,15 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
     }
 }
 
-// PIPE: LDS-DMA ring stages (2 | 3)
-template <typename T, int BM, int BN, int BKB, int PIPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_kernel(const ConvArgs args) {
+// PIPE: LDS-DMA ring stages (2 | 3 | 4 | 6)
+// KG:   K-groups per workgroup (1 | 2).  The deep layers (16x20 / 32x40 maps) have ~256 tiles of a long K loop: one
+//       4-wave workgroup per CU, every step's barrier / LDS / DMA latency exposed.  With KG = 2 a 512-thread workgroup
+//       holds two 4-wave groups that walk the two halves of the input channels with private LDS rings (same barriers);
+//       group 1 hands its accumulators to group 0 through LDS before the epilogue -- twice the waves per CU without a
+//       split-K pass through memory.  2-stage ring only.
+template <typename T, int BM, int BN, int BKB, int PIPE, int KG = 1>
+__global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_kernel(const ConvArgs args) {
+    static_assert(KG == 1 || PIPE == 2, "K-groups use the 2-stage ring");
     const DykConvDesc& a = args.d;
     constexpr int TABLE_BYTES = table_bytes<BN>();
     constexpr int EPV = 16 / (int)sizeof(T);
@@ -464,11 +470,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     int* tap_dy = tap_w + 32;                 // [32]
     int* tap_dx = tap_dy + 32;                // [32]
     float* s_stat = (float*)(tap_dx + 32);    // [4][2][BM] per-wave channel sums (STATS / BNBWD epilogues)
-    char* sA = smem + TABLE_BYTES;                 // [NSTAGE][A_BYTES]
+    const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+    char* sA = smem + TABLE_BYTES + grp * (NSTAGE * (A_BYTES + B_BYTES));   // [NSTAGE][A_BYTES]  (per K-group)
     char* sB = sA + NSTAGE * A_BYTES;              // [NSTAGE][B_BYTES]
-    char* sC = sA;                                 // epilogue staging tile (overlays the ring)
+    char* sC = smem + TABLE_BYTES;                 // epilogue staging tile (overlays the rings)
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid_all = threadIdx.x;               // tables are built by the first 256 threads
+    const int tid = tid_all & 255, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     if ((a.tune >> 18) & 1) return;            // ablation: empty kernel
 
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const int m0 = (bid / tiles_n) * BM;
     const int n0 = (bid % tiles_n) * BN;
 
-    if (tid < BN) {
+    if (tid_all < BN) {
         const int n = n0 + tid;
         if (n < Ntot) {
             const int b = n / HWg;
@@ -508,7 +516,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             t_in[tid] = 0; t_y[tid] = -20000; t_x[tid] = -20000; t_out[tid] = -1; t_res[tid] = 0;
         }
     }
-    if (tid >= 256 - 32 && tid < 256 - 32 + ntaps) {   // tap tables in LDS: no vector-memory loads inside the K loop
+    if (tid_all >= 256 - 32 && tid_all < 256 - 32 + ntaps) {   // tap tables in LDS: no vector-memory loads inside the K loop
         const int q = tid - (256 - 32);
         const int dy = a.tdy[tap0 + q], dx = a.tdx[tap0 + q];
         tap_dy[q] = dy; tap_dx[q] = dx;
@@ -528,7 +536,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const T* __restrict__ wg = (const T*)a.w;
     // bits 16.. of `tune` are ablation switches for kernel analysis (tools/gpu_probe.py ablate): never set by the plan
     const bool abl_nostore = (a.tune >> 16) & 1, abl_noloop = (a.tune >> 17) & 1;
-    const int S = abl_noloop ? 0 : (a.Cin / BK) * ntaps;
+    // K-groups split the input-channel chunks; the step count of group 0 (the larger half) drives the common barriers
+    const int nchunks = a.Cin / BK;
+    const int c_begin = (KG > 1 && grp) ? (nchunks + 1) / 2 : 0;
+    const int c_end = (KG > 1 && !grp) ? (nchunks + 1) / 2 : nchunks;
+    const int S = abl_noloop ? 0 : (c_end - c_begin) * ntaps;
+    const int Smax = abl_noloop ? 0 : (KG > 1 ? ((nchunks + 1) / 2) * ntaps : S);
     const int frow = lane & 15, fslot = lane >> 4;
 
     // `mid` (the DMA issue of a later step) runs between the first fragment reads and their MFMAs: the ~100 cycles per
@@ -614,7 +627,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             }
         };
         // staging iterator (runs two steps ahead of the compute iterator)
-        int sc0 = 0, st = 0;
+        int sc0 = c_begin * BK, st = 0;
         auto stage_next = [&](int buf) {
             stage(buf, sc0, st);
             if (++st == ntaps) { st = 0; sc0 += BK; }
@@ -648,13 +661,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             if (S > 0) stage_next(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            for (int s = 0; s < S; ++s) {
-                compute(sA + (s & 1) * A_BYTES, sB + (s & 1) * B_BYTES, [&]() { if (s + 1 < S) stage_next((s + 1) & 1); });
+            for (int s = 0; s < Smax; ++s) {
+                if (KG == 1 || s < S)
+                    compute(sA + (s & 1) * A_BYTES, sB + (s & 1) * B_BYTES, [&]() { if (s + 1 < S) stage_next((s + 1) & 1); });
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
         }
+    }
+
+    if constexpr (KG > 1) {
+        // fold the K-groups: group 1 parks its accumulators in LDS (lane-linear float4, conflict free), group 0 adds them
+        float4* park = (float4*)(smem + TABLE_BYTES);      // overlays the rings: every wave is behind the loop's last barrier
+        if (grp == 1) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    park[((mi * NI + ni) * 4 + wid) * 64 + lane] = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+        }
+        __syncthreads();
+        if (grp != 0) return;                              // (ended waves no longer count at the barriers below)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const float4 v = park[((mi * NI + ni) * 4 + wid) * 64 + lane];
+                acc[mi][ni][0] += v.x; acc[mi][ni][1] += v.y; acc[mi][ni][2] += v.z; acc[mi][ni][3] += v.w;
+            }
+        __syncthreads();                                   // the epilogue's staging tile overlays the park area
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -912,15 +948,17 @@ int dispatch_conv_halo(const DykConvDesc* d, hipStream_t stream) {
     return bm == 128 ? launch_conv_halo<T, 128, TH, 64>(d, stream) : launch_conv_halo<T, 64, TH, 64>(d, stream);
 }
 
-template <typename T, int BM, int BN, int BKB, int PIPE>
+template <typename T, int BM, int BN, int BKB, int PIPE, int KG = 1>
 int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     constexpr int TABLE_BYTES = table_bytes<BN>();
-    constexpr size_t ring = PIPE * (size_t)(BM + BN) * BKB;
+    constexpr size_t ring = KG > 1 ? (size_t)KG * PIPE * (BM + BN) * BKB + 0 : PIPE * (size_t)(BM + BN) * BKB;   // K-groups: private rings; the 16 KiB-per-wave park area (BM*BN*4) fits inside
+    static_assert(KG == 1 || ring >= (size_t)BM * BN * 4, "park area");
+    static_assert(table_bytes<BN>() + ring <= 160 * 1024 || KG == 1, "LDS budget");
     const bool of32 = (d->flags & DYK_EPI_OUT_F32) || sizeof(T) == 4;
     const size_t stage_c = (size_t)BN * (BM * (of32 ? 4 : 2) + 16);
     const size_t lds = TABLE_BYTES + (ring > stage_c ? ring : stage_c);
     static bool attr_set = false;
-    auto kfn = conv_igemm_kernel<T, BM, BN, BKB, PIPE>;
+    auto kfn = conv_igemm_kernel<T, BM, BN, BKB, PIPE, KG>;
     if (!attr_set) {
         constexpr size_t lds_max = TABLE_BYTES + (ring > (size_t)BN * (BM * 4 + 16) ? ring : (size_t)BN * (BM * 4 + 16));
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -940,7 +978,7 @@ int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     if (force_scatter) vec = false;
     if (vec) args.d.flags |= EPI_INTERNAL_VEC;
     else args.d.flags &= ~EPI_INTERNAL_VEC;
-    hipLaunchKernelGGL(kfn, dim3(tiles_n * tiles_m * (d->ncls > 1 ? d->ncls : 1)), dim3(256), lds, stream, args);
+    hipLaunchKernelGGL(kfn, dim3(tiles_n * tiles_m * (d->ncls > 1 ? d->ncls : 1)), dim3(256 * KG), lds, stream, args);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

@@ -1105,7 +1105,8 @@ _TUNE_CACHE = {}     # process-wide: the same problem always runs the same tile 
                      # results across plans / model instances within a process)
 def _conv_candidates(d):
     """tile configurations of dyk_conv_igemm for one problem: K-step bytes | ring stages << 8 | pixel tile << 12
-    (0 = 128, 1 = 80, 2 = 160 pixels, 3 / 4 = halo kernel 4x20 / 8x20; bf16 only) | channel tile << 24 (0 = by Cout, 2 = 64, 1 = 32)"""
+    (0 = 128, 1 = 80, 2 = 160 pixels, 3 / 4 = halo kernel 4x20 / 8x20; bf16 only) | channel tile << 24 (0 = by Cout, 2 = 64, 1 = 32)
+    | 1 << 28 = K-grouped workgroups"""
     es = 2 if d.dtype == L.DYK_BF16 else 4
     bkbs = [64] + ([128] if (d.Cin * es) % 128 == 0 else [])
     tiles = [0, 1, 2] if d.dtype == L.DYK_BF16 else [0]
@@ -1123,6 +1124,12 @@ def _conv_candidates(d):
                     if t in (3, 4) and pipe != 2:
                         continue                      # the halo kernel has a fixed pipeline
                     out.append(bkb | (pipe << 8) | (t << 12) | (bm << 24))
+    if d.dtype == L.DYK_BF16 and (d.Cin * es) % 128 == 0 and d.Cin >= 128 and os.environ.get("DYK_CONV_KG", "1") != "0":
+        # K-grouped workgroups (two 4-wave groups over the two halves of Cin): for tiles that leave a CU one workgroup
+        for t in (1, 2):
+            for bm in bms:
+                if bm != 1:
+                    out.append(128 | (2 << 8) | (t << 12) | (bm << 24) | (1 << 28))
     return out
 
 

@@ -128,7 +128,8 @@ typedef struct DykConvDesc {
     int32_t tune;                   /* 0 = built-in heuristic; else tile configuration chosen by the plan compiler's
                                        per-shape measurement: bits 0..7 K-step bytes (64|128), 8..11 LDS ring stages
                                        (2|3|4|6), 12..15 pixel tile (0 = 128, 1 = 80, 2 = 160; bf16), 24..27 channel
-                                       tile (0 = by Cout, 1 = 32, 2 = 64, 3 = 128); bits 16..23 analysis switches */
+                                       tile (0 = by Cout, 1 = 32, 2 = 64, 3 = 128); bits 16..23 analysis switches; 1 << 28 = two K-groups per
+                                       workgroup (512 threads, halves of Cin, bf16 / 128-byte K step / 80|160-pixel tiles) */
 } DykConvDesc;
 
 int dyk_conv_igemm(const DykConvDesc* desc, void* stream);

@@ -227,7 +227,7 @@ def test_depthwise_conv_fwd_dgrad_wgrad(case, dtype):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 128, 16, 20, 3, 1), (1, 128, 96, 17, 23, 3, 1), (3, 64, 64, 9, 13, 1, 1),
-                                  (2, 32, 32, 20, 24, 3, 2)])
+                                  (2, 32, 32, 20, 24, 3, 2), (1, 192, 128, 12, 20, 3, 1), (2, 256, 64, 8, 10, 1, 1)])
 def test_conv_every_tile_configuration(case):
     """every instantiation the autotuner may pick (K step x ring depth x pixel tile 80/128/160 x channel tile) gives
     the same result, with the statistics + affine/activation epilogues"""

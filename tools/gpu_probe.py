@@ -95,6 +95,8 @@ if "ablate" in what:
     shapes = [(128, 128, 64, 80, 1), (64, 64, 256, 320, 1), (256, 256, 32, 40, 1), (128, 128, 64, 80, 3)]
     if os.environ.get("PROBE_EARLY"):
         shapes = [(32, 64, 256, 320, 3), (64, 32, 256, 320, 3), (64, 64, 256, 320, 1), (64, 32, 256, 320, 1)]
+    if os.environ.get("PROBE_MID"):
+        shapes = [(256, 256, 32, 40, 3), (128, 128, 64, 80, 3), (512, 512, 16, 20, 3), (256, 256, 32, 40, 1)]
     for (ci, co, H, W, k) in shapes:
         B, dt = 16, torch.bfloat16
         x = torch.randn(B, H, W, ci, device="cuda").to(dt)
