@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc
             for (int j = 0; j < NIA_W; ++j) {
                 const int n = sp0 + a_row[j];
                 const int c = m0 + a_ch[j];
-                const T* src = (n < p_end && c < a.Cout) ? dyg + (long)n * a.lddy + c : zero;
+                const bool ok = (n < p_end) & (c < a.Cout);         // (& not &&: straight-line address selects, no exec-mask branches)
+                const T* src = ok ? dyg + (long)n * a.lddy + c : zero;
                 wg_glds16(src, wg_lds_addr(da + (j * 4 + wv) * 1024));
             }
 #pragma unroll
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc
                 const int n = sp0 + b_row[j];
                 const int c = n0 + b_ch[j];
                 const int yi = b_yo[j] * a.isy + tdy, xi = b_xo[j] * a.isx + tdx;
-                const bool ok = n < p_end && c < a.Cin && ((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi);
+                const bool ok = (n < p_end) & (c < a.Cin) & ((unsigned)yi < (unsigned)a.Hi) & ((unsigned)xi < (unsigned)a.Wi);
                 const T* src = ok ? xg + ((long)(b_img[j] * a.Hi + yi) * a.Wi + xi) * a.ldx + c : zero;
                 wg_glds16(src, wg_lds_addr(db + (j * 4 + wv) * 1024));
             }
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mt_kernel(const DykWgradDesc a
 #pragma unroll
             for (int j = 0; j < NIB_W; ++j) {
                 const int yi = yo * SI + b_rr[j] - 1, xi = xo0 * SI + b_jj[j] - 1;
-                const bool ok = b_ch[j] < a.Cin && ((unsigned)yi < (unsigned)a.Hi) && ((unsigned)xi < (unsigned)a.Wi);
+                const bool ok = (b_ch[j] < a.Cin) & ((unsigned)yi < (unsigned)a.Hi) & ((unsigned)xi < (unsigned)a.Wi);
                 const T* src = ok ? xg + ((long)(b * a.Hi + yi) * a.Wi + xi) * a.ldx + b_ch[j] : zero;
                 wg_glds16(src, wg_lds_addr(db + (j * 4 + wv) * 1024));
             }
