@@ -252,18 +252,32 @@ __global__ __launch_bounds__(256) void se_pool_kernel(DykEwDesc d, float* __rest
     if (active) {
         const T* __restrict__ a = (const T*)d.a;
         const T* __restrict__ bb = (const T*)d.b;
-        for (int p = ty; p < HW; p += PY) {
-            const long pp = (long)b * HW + p;
-            float x[EPV];
-            vec_unpack<T>(*(const uint4*)(a + pp * d.lda + c), x);
-            if (bb) {
-                float y[EPV];
-                vec_unpack<T>(*(const uint4*)(bb + pp * d.ldb + c), y);
+        // four pixels per thread in flight: with one dependent load (pair) per iteration the loop ran at HBM latency
+        // (32..192 workgroups per launch: nothing else hides it)
+        constexpr int U = 4;
+        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+        for (int p0 = ty; p0 < HW; p0 += PY * U) {
+            uint4 va[U], vb[U];
 #pragma unroll
-                for (int j = 0; j < EPV; ++j) s[j] += x[j] * y[j];
-            } else {
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * PY;
+                const long pp = (long)b * HW + (p < HW ? p : 0);
+                va[u] = p < HW ? *(const uint4*)(a + pp * d.lda + c) : z4;          // (zero contributes nothing)
+                if (bb) vb[u] = *(const uint4*)(bb + pp * d.ldb + c);
+            }
 #pragma unroll
-                for (int j = 0; j < EPV; ++j) s[j] += x[j];
+            for (int u = 0; u < U; ++u) {
+                float x[EPV];
+                vec_unpack<T>(va[u], x);
+                if (bb) {
+                    float y[EPV];
+                    vec_unpack<T>(vb[u], y);
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) s[j] += x[j] * y[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) s[j] += x[j];
+                }
             }
         }
     }
