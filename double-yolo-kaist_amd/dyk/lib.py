@@ -199,6 +199,8 @@ SIGNATURES = {
     "dyk_sgd_step": (_i32, [_P(DykOptimDesc), _vp]),
     "dyk_run_commands_timed": (_i32, [_P(DykCommand), _i32, _vp, _P(_f32)]),
     "dyk_loss_scale_grads": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "dyk_box_convert": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "dyk_scale_coords": (_i32, [_vp, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
 }
 
 

@@ -580,6 +580,19 @@ typedef struct DykOptimDesc {
 int dyk_adam_step(const DykOptimDesc* desc, void* stream);
 int dyk_sgd_step(const DykOptimDesc* desc, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Box-coordinate helpers of the evaluation chain (build_utils/utils.py:40-92; callers evaluate.py:82,
+ * detect.py:114).  Rows of `ld` floats, the first four columns are the box.  fp32, rounded exactly like the
+ * reference's torch-CPU expressions.
+ *   dyk_box_convert : to_xyxy != 0: (xc,yc,w,h) -> (x1,y1,x2,y2) [xywh2xyxy :50-57]; else the inverse
+ *                     [xyxy2xywh :40-47].  in may equal out.
+ *   dyk_scale_coords: in place.  do_scale != 0: x = (x - pad_x) / gain, y = (y - pad_y) / gain [scale_coords
+ *                     :60-81] and then, always, clamp x to [0, w0], y to [0, h0] [clip_coords :84-92].
+ * ---------------------------------------------------------------------------------- */
+int dyk_box_convert(const float* in, float* out, int32_t n, int32_t ld_in, int32_t ld_out, int32_t to_xyxy, void* stream);
+int dyk_scale_coords(float* boxes, int32_t n, int32_t ld, float pad_x, float pad_y, float gain, float w0, float h0,
+                     int32_t do_scale, void* stream);
+
 /* Profiling variant of dyk_run_commands: brackets every command with HIP events on `stream`
  * and, after synchronising the stream, writes each command's duration in milliseconds to
  * ms_out[0..n).  Used by bench.py's roofline pass, never in a timed throughput region. */
