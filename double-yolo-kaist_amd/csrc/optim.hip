@@ -12,6 +12,10 @@ __global__ __launch_bounds__(256) void adam_kernel(DykOptimDesc d, float bc1, fl
     const float lr = d.lr, b1 = d.beta1, b2 = d.beta2, eps = d.eps, wd = d.weight_decay, gs = d.grad_scale;
     const float step_size = lr / bc1;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        if (d.mask && ((const uint32_t*)d.mask)[i] == 0) {      // frozen parameters (entries are 64-element aligned)
+            if (d.zero_grad) ((float4*)d.g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
         float4 p = ((float4*)d.p)[i];
         float4 g = ((const float4*)d.g)[i];
         float4 m = ((float4*)d.m)[i];
@@ -43,6 +47,10 @@ __global__ __launch_bounds__(256) void sgd_kernel(DykOptimDesc d, int first_step
     const long n4 = d.n >> 2;
     const float lr = d.lr, mom = d.beta1, wd = d.weight_decay, gs = d.grad_scale;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        if (d.mask && ((const uint32_t*)d.mask)[i] == 0) {
+            if (d.zero_grad) ((float4*)d.g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
         float4 p = ((float4*)d.p)[i];
         float4 g = ((const float4*)d.g)[i];
         float4 m = ((float4*)d.m)[i];
@@ -71,6 +79,7 @@ int check(const DykOptimDesc* d, bool need_v) {
     if (!d || !d->p || !d->g || !d->m || (need_v && !d->v) || d->n <= 0 || (d->n & 3)) return DYK_ERR_ARG;
     if (((uintptr_t)d->p | (uintptr_t)d->g | (uintptr_t)d->m | (uintptr_t)d->v) & 15) return DYK_ERR_ARG;
     if (d->wc && ((uintptr_t)d->wc & 7)) return DYK_ERR_ARG;
+    if (d->mask && ((uintptr_t)d->mask & 3)) return DYK_ERR_ARG;
     return DYK_OK;
 }
 

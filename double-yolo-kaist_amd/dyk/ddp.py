@@ -11,7 +11,96 @@ buckets are kept large (default 8 buckets of ~58 MB for the 464 MB of the target
 bound collectives instead of many latency-bound ones.  The 1/world_size averaging is folded into the fused
 optimizer step (FusedAdam.grad_scale).
 """
+import pickle
+
 import torch
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def is_dist_avail_and_initialized():
+    dist = _dist()
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return _dist().get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return _dist().get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def _comm_device():
+    """where collective payloads live: the rank's GPU under nccl (= RCCL), host memory under gloo"""
+    return torch.device("cuda", torch.cuda.current_device()) if _dist().get_backend() == "nccl" else torch.device("cpu")
+
+
+def reduce_dict(input_dict, average=True):
+    """The per-step loss exchange of the reference harness (train_utils/distributed_utils.py:117-142, called at
+    kaist_train_eval_utils.py:82): the values of `input_dict` (the three [1]-shaped loss terms: 12 bytes) are
+    stacked in key order, all-reduced and, with `average`, divided by the world size.  One rank: returned as is."""
+    world = get_world_size()
+    if world < 2:
+        return input_dict
+    with torch.no_grad():
+        names = sorted(input_dict.keys())
+        values = torch.stack([input_dict[k] for k in names], dim=0)
+        _dist().all_reduce(values)
+        if average:
+            values /= world
+        return {k: v for k, v in zip(names, values)}
+
+
+def all_gather(data):
+    """list over ranks of an arbitrary picklable object (train_utils/distributed_utils.py:74-114): sizes first,
+    then the pickles padded to the longest."""
+    world = get_world_size()
+    if world == 1:
+        return [data]
+    dist, dev = _dist(), _comm_device()
+    payload = torch.frombuffer(bytearray(pickle.dumps(data)), dtype=torch.uint8).to(dev)
+    size = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    sizes = [int(s.item()) for s in sizes]
+    buf = torch.zeros(max(sizes), dtype=torch.uint8, device=dev)
+    buf[:payload.numel()] = payload
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    return [pickle.loads(t.cpu().numpy().tobytes()[:n]) for n, t in zip(sizes, parts)]
+
+
+def gather_detections(dets, image_ids):
+    """Evaluation shards images over ranks; every rank gets all detections as one float32 tensor of rows
+    (image_id, x1, y1, x2, y2, conf, cls) in rank order, without pickling: the per-rank row counts are exchanged
+    first, then the rows padded to the longest shard.  `dets`: the list non_max_suppression returns (tensor [n,6]
+    or None per image); `image_ids`: the dataset index of each image of this rank's batch."""
+    rows = []
+    for d, i in zip(dets, image_ids):
+        if d is not None and d.shape[0]:
+            rows.append(torch.cat([torch.full((d.shape[0], 1), float(i), dtype=torch.float32, device=d.device), d.float()], 1))
+    world = get_world_size()
+    if world == 1:
+        return torch.cat(rows, 0) if rows else torch.zeros((0, 7))
+    dist, dev = _dist(), _comm_device()
+    mine = torch.cat(rows, 0).to(dev) if rows else torch.zeros((0, 7), device=dev)
+    n = torch.tensor([mine.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    pad = torch.zeros((max(max(counts), 1), 7), dtype=torch.float32, device=dev)
+    pad[:mine.shape[0]] = mine
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([t[:c] for c, t in zip(counts, parts)], 0)
 
 
 class GradAllReduce:
@@ -19,12 +108,12 @@ class GradAllReduce:
         self.model, self.dist, self.n_buckets = model, dist, n_buckets
         self.engine = model.engine
         self.engine.grad_sync = self
-        self._segs = {}
         self._works = []
 
     def segments(self, plan):
-        key = id(plan)
-        segs = self._segs.get(key)
+        # cached on the plan object itself: a plan evicted under multi-scale training takes its cuts with it (an
+        # id()-keyed table could hand them to a later plan that re-uses the address)
+        segs = plan.__dict__.get("_ddp_segs", {}).get(self.n_buckets)
         if segs is None:
             store = self.engine.store
             total = store.total
@@ -48,7 +137,7 @@ class GradAllReduce:
                     c_prev, hi = c_end, lo
             if c_prev < len(plan.bwd):
                 segs.append((c_prev, len(plan.bwd), 0, hi))
-            self._segs[key] = segs
+            plan.__dict__.setdefault("_ddp_segs", {})[self.n_buckets] = segs
         return segs
 
     def bucket_ready(self, lo, hi):

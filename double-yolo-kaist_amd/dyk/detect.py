@@ -109,7 +109,21 @@ class _LossFunction(torch.autograd.Function):
         check(load().dyk_yolo_loss(ctypes.byref(d), ctypes.byref(t), _stream()), "dyk_yolo_loss")
         ctx.dps = dps
         ctx.no = d.no
-        m._dyk_loss_flag = flag          # bit 0: a target fell outside the grid (reference: IndexError)
+        # bit 0: a target fell outside the grid (the reference raises IndexError there).  Copied to pinned host memory
+        # behind the loss kernels; examined without a host sync by raise_if_target_outside_grid (optimizer.step())
+        ring = m.__dict__.get("_dyk_flag_ring")
+        if ring is None:
+            ring = m.__dict__["_dyk_flag_ring"] = [torch.zeros(32, dtype=torch.int32).pin_memory(), 0]
+        pend = m.__dict__.setdefault("_dyk_loss_flags", [])
+        if len(pend) >= 32:                      # nobody examined them (no fused optimizer in use): recycle the oldest slot
+            pend.pop(0)[1].synchronize()
+        host = ring[0][ring[1] % 32:ring[1] % 32 + 1]
+        ring[1] += 1
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        pend.append((host, ev, flag))
+        m._dyk_loss_flag = flag
         m._dyk_loss_keep = (keep, tobjs, acc, ps)
         return out[0:1].clone(), out[1:2].clone(), out[2:3].clone()
 
@@ -121,6 +135,27 @@ class _LossFunction(torch.autograd.Function):
         for dp in ctx.dps:
             check(lib.dyk_loss_scale_grads(dp.data_ptr(), dp.numel(), ctx.no, g.data_ptr(), _stream()), "dyk_loss_scale_grads")
         return (None, None) + tuple(ctx.dps)
+
+
+def raise_if_target_outside_grid(model, wait=True):
+    """IndexError if a compute_loss call since the last check saw a target whose grid cell lies outside the
+    prediction grid (x or y == 1.0 exactly) -- the reference fails there with 'index out of range'
+    (build_utils/utils.py:248 after the unclamped :370).  wait=False only examines flags whose asynchronous copy
+    has completed; the fused optimizers call it that way on every step."""
+    m = _model_of(model)
+    pending = m.__dict__.get("_dyk_loss_flags", [])
+    keep, bad = [], False
+    for host, ev, flag in pending:
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            bad = bad or bool(int(host[0]) & 1)
+        else:
+            keep.append((host, ev, flag))
+    m.__dict__["_dyk_loss_flags"] = keep
+    if bad:
+        raise IndexError("a target box centre lies outside the prediction grid (x or y == 1.0): the reference fails "
+                         "with 'index out of range' in compute_loss (build_utils/utils.py:248)")
 
 
 def compute_loss(p, targets, model):

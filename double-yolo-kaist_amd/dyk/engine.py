@@ -45,6 +45,7 @@ class Engine:
         self.store = ParamStore(model)
         self.plans = {}
         self.grad_sync = None           # set by dyk.ddp.GradAllReduce
+        self._anchor = None
 
     # ------------------------------------------------------------------ helpers
     def _prepare(self, x):
@@ -61,7 +62,9 @@ class Engine:
             self.plans = {}
 
     def get_plan(self, B, H, W, dtype, training, device):
-        key = (B, H, W, dtype, bool(training))
+        # frozen parameters (reference train.py:77-82) change the backward list: no weight gradients for them and no
+        # backward at all below the first trainable section
+        key = (B, H, W, dtype, bool(training)) + ((self.store.frozen_key(),) if training and self.store.frozen_key() else ())
         plan = self.plans.pop(key, None)
         if plan is None:
             if H % 32 or W % 32:
@@ -112,6 +115,7 @@ class Engine:
     def _run_backward(self, plan, dps):
         stream = torch.cuda.current_stream().cuda_stream
         self.store.attach_grads()
+        self.store.grads_dirty = True
         keep = []
         for desc, hi in plan.dyn_dp:
             g = dps[hi]
@@ -143,8 +147,12 @@ class Engine:
         if "second_index" in model.net_info and not di:
             raise L.DykError("this cfg is dual-stream (second_index set): call model(visible, lwir)")
         if training:
-            if torch.is_grad_enabled():
-                anchor = next(model.parameters())
+            if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
+                # the differentiable input that ties the outputs to autograd: a private leaf, so that freezing any
+                # prefix of the layers (module_list[0] included) leaves `loss.backward()` working
+                anchor = self._anchor
+                if anchor is None or anchor.device != x.device:
+                    anchor = self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
                 outs = _NetFunction.apply(self, plan, anchor, x, y)
                 return list(outs)
             self._run_forward(plan, x, y)

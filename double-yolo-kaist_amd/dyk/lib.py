@@ -132,7 +132,7 @@ class DykLossDesc(ctypes.Structure):
 
 
 class DykOptimDesc(ctypes.Structure):
-    _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("wc", _vp), ("n", _i64), ("lr", _f32), ("beta1", _f32),
+    _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("wc", _vp), ("mask", _vp), ("n", _i64), ("lr", _f32), ("beta1", _f32),
                 ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("grad_scale", _f32), ("step", _i32),
                 ("zero_grad", _i32)]
 

@@ -1,7 +1,10 @@
 """Fused optimizers over the flat parameter store (one HIP launch per step for the whole model).
 
 Drop-in for the torch.optim.Adam / SGD(nesterov) instances reference train.py:85-91 builds: same update
-rule, same constructor arguments, `step()` / `zero_grad()` / `param_groups[0]['lr']` for LR schedulers.
+rule, same constructor arguments, `step()` / `zero_grad()` / `param_groups[0]['lr']` for LR schedulers,
+`state_dict()` / `load_state_dict()` in torch.optim's own per-parameter format (the reference checkpoint stores
+`optimizer.state_dict()`, train.py:229), and -- like `pg = [p for p in model.parameters() if p.requires_grad]`
+(train.py:84) -- no update of parameters frozen with `requires_grad_(False)` (`--freeze-layers`, train.py:77-82).
 """
 import ctypes
 
@@ -12,12 +15,17 @@ from .lib import check, load
 
 
 class _FusedBase(torch.optim.Optimizer):
+    _state_names = ()            # torch.optim state entries that map onto the flat buffers (m, v)
+
     def __init__(self, model, defaults):
         self.model = model
-        params = [p for p in model.parameters()]
+        params = [p for p in model.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("optimizer got an empty parameter list")
         super().__init__(params, defaults)
         self._t = 0
         self._m = self._v = None
+        self._mask, self._mask_key = None, None
         self.grad_scale = 1.0
         self.zero_in_step = True
 
@@ -28,29 +36,64 @@ class _FusedBase(torch.optim.Optimizer):
         return st
 
     def zero_grad(self, set_to_none=False):
+        """Clears the flat gradient buffer unless it is known to be clean: a fused step that ran AFTER the last
+        backward has already zeroed it.  A step skipped by GradScaler (inf/NaN gradients) or by the caller leaves
+        `store.grads_dirty` set, so the stale gradients are dropped here as with torch.optim."""
         st = self.model.engine.store
         if st.G is not None:
             st.attach_grads()
-            if not getattr(self, "_grads_clean", False):
+            if st.grads_dirty:
                 st.G.zero_()
-                self._grads_clean = True
+                st.grads_dirty = False
 
-    def _desc(self, st):
+    def _buffers(self, st):
         if self._m is None or self._m.device != st.P.device:
             self._m = torch.zeros_like(st.P)
-            self._v = torch.zeros_like(st.P)
+            self._v = torch.zeros_like(st.P) if "exp_avg_sq" in self._state_names else None
+        return self._m, self._v
+
+    def _trainable_mask(self, st):
+        """None when every parameter is trainable, else a byte per element of the flat buffer (1 = update):
+        frozen parameters get neither the update nor weight decay nor moments."""
+        key = st.frozen_key()
+        if key != self._mask_key:
+            self._mask_key = key
+            if not key:
+                self._mask = None
+            else:
+                mask = torch.zeros(st.total, dtype=torch.uint8)
+                for e in st.entries:
+                    if e.param.requires_grad:
+                        mask[e.offset:e.offset + e.numel] = 1
+                self._mask = mask.to(st.P.device)
+        return self._mask
+
+    def _desc(self, st):
+        m, v = self._buffers(st)
         g = self.param_groups[0]
         d = L.DykOptimDesc()
-        d.p, d.g, d.m, d.v = st.P.data_ptr(), st.G.data_ptr(), self._m.data_ptr(), self._v.data_ptr()
+        d.p, d.g, d.m = st.P.data_ptr(), st.G.data_ptr(), m.data_ptr()
+        d.v = v.data_ptr() if v is not None else None
         d.n = st.total
         d.lr, d.weight_decay, d.grad_scale = float(g["lr"]), float(g["weight_decay"]), float(self.grad_scale)
         d.zero_grad = 1 if self.zero_in_step else 0
+        mask = self._trainable_mask(st)
+        d.mask = mask.data_ptr() if mask is not None else None
         bf = st._compute.get(torch.bfloat16)
         d.wc = bf["Wc"].data_ptr() if bf is not None else None
         return d, bf
 
+    def _check_loss_flag(self):
+        """the reference raises IndexError inside compute_loss when a target lies on the right / bottom image edge
+        (grid index == grid size: build_utils/utils.py:370 with :248); the HIP loss records that in a device flag
+        which dyk.detect copies to pinned host memory asynchronously.  Flags whose copy has completed are examined
+        here (no host synchronisation: the error surfaces one optimizer step late at most)."""
+        from .detect import raise_if_target_outside_grid
+        raise_if_target_outside_grid(self.model, wait=False)
+
     def _finish(self, st, bf):
-        self._grads_clean = bool(self.zero_in_step)
+        if self.zero_in_step:
+            st.grads_dirty = False
         st.mark_dirty()
         if bf is not None:                # the bf16 copy was written by the step kernel: refresh the rest only
             st.compute_weights(torch.bfloat16, skip_cast=True)
@@ -58,14 +101,55 @@ class _FusedBase(torch.optim.Optimizer):
             if dt != torch.bfloat16:
                 st.compute_weights(dt)
 
+    # ------------------------------------------------------------------ checkpoint format of torch.optim
+    def _export_state(self):
+        st = self.model.engine.store
+        if self._m is None or st.P is None:
+            return
+        by_param = {id(e.param): e for e in st.entries}
+        flats = dict(zip(self._state_names, (self._m, self._v)))
+        for p in self.param_groups[0]["params"]:
+            e = by_param[id(p)]
+            s = {"step": torch.tensor(float(self._t))}
+            for name, flat in flats.items():
+                s[name] = st._view(flat, e)
+            self.state[p] = s
+
+    def state_dict(self):
+        self._export_state()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        st = self._store()
+        m, v = self._buffers(st)
+        flats = dict(zip(self._state_names, (m, v)))
+        by_param = {id(e.param): e for e in st.entries}
+        steps = set()
+        with torch.no_grad():
+            for p, s in list(self.state.items()):
+                e = by_param[id(p)]
+                for name, flat in flats.items():
+                    if name in s and s[name] is not None:
+                        st._view(flat, e).copy_(s[name].to(flat.device, torch.float32))
+                if "step" in s:
+                    steps.add(int(float(s["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ (%s): the fused step keeps one counter" % sorted(steps))
+        self._t = steps.pop() if steps else 0
+        self.state.clear()               # the flat buffers are the state; views are rebuilt on demand
+
 
 class FusedAdam(_FusedBase):
+    _state_names = ("exp_avg", "exp_avg_sq")
+
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(model, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
     @torch.no_grad()
     def step(self, closure=None):
         st = self._store()
+        self._check_loss_flag()
         st.attach_grads()
         self._t += 1
         d, bf = self._desc(st)
@@ -76,14 +160,17 @@ class FusedAdam(_FusedBase):
 
 
 class FusedSGD(_FusedBase):
+    _state_names = ("momentum_buffer",)
+
     def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=0.0, nesterov=True):
         if not nesterov:
             raise NotImplementedError("the reference only uses nesterov=True (train.py:88-89)")
-        super().__init__(model, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        super().__init__(model, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=True, dampening=0))
 
     @torch.no_grad()
     def step(self, closure=None):
         st = self._store()
+        self._check_loss_flag()
         st.attach_grads()
         self._t += 1
         d, bf = self._desc(st)

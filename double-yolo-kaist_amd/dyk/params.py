@@ -73,6 +73,12 @@ class ParamStore:
         self._ttable = None
         self._pad_layout = None
         self._dirty = 0
+        self.grads_dirty = False   # set by every backward pass, cleared by zero_grad() / a fused step that zeroes G
+
+    def frozen_key(self):
+        """names of the parameters frozen with requires_grad_(False) (reference train.py:77-82): part of the plan
+        key (their weight gradients are not computed) and of the fused optimizers' update mask"""
+        return tuple(e.name for e in self.entries if not e.param.requires_grad)
 
     # ------------------------------------------------------------------ adoption
     def _view(self, flat, e):
@@ -115,8 +121,11 @@ class ParamStore:
         self._ttable = None
 
     def grads_attached(self):
-        e0, e1 = self.entries[0], self.entries[-1]
-        for e in (e0, e1):
+        live = [e for e in self.entries if e.param.requires_grad]
+        for e in self.entries:
+            if not e.param.requires_grad and e.param.grad is not None:
+                return False
+        for e in live[:1] + live[-1:]:
             g = e.param.grad
             if g is None or g.data_ptr() != self.G.data_ptr() + 4 * e.offset:
                 return False
@@ -128,8 +137,10 @@ class ParamStore:
         if self.grads_attached():
             return
         self.G.zero_()
+        self.grads_dirty = False
         for e in self.entries:
-            e.param.grad = self._view(self.G, e)
+            # frozen parameters have no .grad, as under autograd (the backward skips their weight gradients)
+            e.param.grad = self._view(self.G, e) if e.param.requires_grad else None
 
     # ------------------------------------------------------------------ pointers
     def p_ptr(self, name):

@@ -224,13 +224,14 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     na_no = []
 
     def conv_forward(i, x_in, stem_src, wname, bnpre, bnm, bias_name, k, stride, pad, cout, act, groups=1, out_layer=None,
-                     out_ref=None):
+                     out_ref=None, entry=True):
         """emit forward commands of Conv2d [+ BatchNorm2d] [+ activation]; returns (out TRef, info dict).
         wname / bnpre / bias_name are parameter-store names (bnpre None = no BatchNorm)."""
         bn = bnpre is not None
         dw = groups > 1
         rec = {"kind": "conv", "bn": bn, "k": k, "stride": stride, "pad": pad, "cout": cout, "act": act, "i": i,
-               "stem": stem_src is not None, "wname": wname, "bnpre": bnpre, "bias_name": bias_name, "dw": dw}
+               "stem": stem_src is not None, "wname": wname, "bnpre": bnpre, "bias_name": bias_name, "dw": dw,
+               "entry": entry}                   # entry: the conv reads the section's input (not an intermediate of it)
         if dw:
             if stem_src is not None or groups != x_in.C or cout != x_in.C:
                 raise NotImplementedError("grouped convolution that is not depthwise (layer %d)" % i)
@@ -408,7 +409,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             mid, rec_dw = conv_forward(i, cur, None, pre + "0.weight", pre + "1.", mod.conv[1], None, ks, m["stride"], 1,
                                        cur.C, relu6, groups=cur.C)
             cur, rec_pw = conv_forward(i, mid, None, pre + "3.weight", pre + "4.", mod.conv[4], None, 1, 1, 0,
-                                       m["filters"], relu6, out_layer=i)
+                                       m["filters"], relu6, out_layer=i, entry=False)
             rec = {"kind": "dwsep", "i": i, "parts": [rec_dw, rec_pw]}
         elif t == "inception":
             # Inception (layers.py:148-172): 1x1 | 1x1-3x3 | 1x1-3x3-3x3 | maxpool3-1x1, every conv = Conv2d + BN +
@@ -436,7 +437,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     bnm_ = getattr(mod, "branch%d" % (bi + 1))[ci + (1 if bi == 3 else 0)].conv[1]
                     last = ci == len(sp) - 1
                     h, r_ = conv_forward(i, h, None, q + "0.weight", q + "1.", bnm_, None, kk, 1, kk // 2, co, leaky,
-                                         out_ref=cat.chan_slice(c0, co) if last else None)
+                                         out_ref=cat.chan_slice(c0, co) if last else None, entry=(ci == 0))
                     recs.append(r_)
                 branches.append((recs, c0, sp[-1][0]))
                 c0 += sp[-1][0]
@@ -579,7 +580,11 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             yolo_rows.append(na * ny * nx)
             head_idx += 1
         elif t == "dropout":
-            rec["alias"] = True              # identity at inference; training dropout is not on the hot path
+            # identity at inference (models.py:96-98 builds nn.Dropout); a training plan would silently diverge from
+            # the reference, so it is refused like the other unbuilt constructs (no shipped cfg has a [dropout])
+            if training and float(m.get("probability", 0.5)) > 0:
+                raise NotImplementedError("[dropout] in a training plan (layer %d): only the inference identity is built" % i)
+            rec["alias"] = True
         else:
             raise NotImplementedError("cfg section [%s] (layer %d) is not built yet" % (t, i))
         outs.append(cur)
@@ -605,6 +610,10 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
 
     # ---------------------------------------------------------------- backward
     if training:
+        # parameters frozen with requires_grad_(False) (reference train.py:77-82): no weight gradient for them, and no
+        # backward at all for the sections below the first one that owns a trainable parameter
+        frozen = {e.name for e in store.entries if not e.param.requires_grad}
+        first_trainable = min((e.layer for e in store.entries if e.param.requires_grad), default=len(defs))
         grads = {}           # tid -> TRef in the grad arena
         ginit = set()        # tids whose gradient buffer holds a value already
         red_offs = []        # (offset, bytes) fp64 reduction scratch zeroed at the start of backward
@@ -668,7 +677,10 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 wd.k, wd.stride, wd.pad = k, stride, pad
                 wd.ldx, wd.ldy = x_in.ld, dy.ld
                 later(lambda wd=wd, x=x_in, dy=dy: (setattr(wd, "x", ptr_of(x)), setattr(wd, "y", ptr_of(dy))))
-                plan.bwd.append((L.OP_DW_WGRAD, wd))
+                if wname not in frozen:
+                    plan.bwd.append((L.OP_DW_WGRAD, wd))
+                if rec["i"] == first_trainable and rec["entry"]:
+                    return
                 gx = gref(x_in)
                 gd = L.DykDwDesc()
                 plan._keep.append(gd)
@@ -694,9 +706,10 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 wd.tdy[q], wd.tdx[q], wd.twt[q] = ty, tx, wt
             wd.splits, wd.lddw = 0, wg["lddw"]
             later(lambda wd=wd, x=wg["x"], dy=dy: (setattr(wd, "x", ptr_of(x)), setattr(wd, "dy", ptr_of(dy))))
-            plan.bwd.append((L.OP_WGRAD, wd))
-            if rec["stem"]:
-                return
+            if wname not in frozen:
+                plan.bwd.append((L.OP_WGRAD, wd))
+            if rec["stem"] or (rec["i"] == first_trainable and rec["entry"]):
+                return                           # nothing trainable upstream: the input gradient is not needed
             gx = gref(x_in)
             first = x_in.tid not in ginit
             e = store.by_name[wname]
@@ -811,7 +824,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             rec = info[i]
             t = rec["kind"]
             plan.bwd_marks.append((len(plan.bwd), i))
-            if rec.get("alias"):
+            if rec.get("alias") or i < first_trainable:
                 continue
             if t == "yolo":
                 y_in = rec["y"]

@@ -563,6 +563,9 @@ int dyk_nms(const DykNmsDesc* desc, void* stream);
  *   grad_scale : multiplies the gradient first (1/world_size after an all-reduce SUM, 1/loss_scale)
  *   wc         : if not NULL, also writes the bf16 copy of the updated parameters (same offsets)
  *   zero_grad  : if non-zero, clears g after use (next backward accumulates into zeros)
+ *   mask       : if not NULL, one byte per element, 0 = frozen: no update, no decay, moments untouched (the
+ *                reference builds its optimizer from `p.requires_grad` parameters only, train.py:84); a parameter's
+ *                elements start at multiples of 64, so four consecutive bytes always agree
  * dyk_adam_step : m = exp_avg, v = exp_avg_sq, beta1/beta2/eps, step = 1-based step count
  * dyk_sgd_step  : m = momentum buffer, beta1 = momentum, Nesterov, dampening 0 (v, beta2, eps unused)
  * ---------------------------------------------------------------------------------- */
@@ -572,6 +575,7 @@ typedef struct DykOptimDesc {
     float* m;
     float* v;
     void* wc;
+    const uint8_t* mask;
     int64_t n;
     float lr, beta1, beta2, eps, weight_decay, grad_scale;
     int32_t step;

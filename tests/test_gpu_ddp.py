@@ -1,0 +1,121 @@
+"""Data-parallel path on ONE GPU (`-m gpu`): torch.distributed backend "nccl" (= RCCL) with world_size 1 runs the REAL
+segmented backward (dyk_run_commands* on sub-ranges of the command list, side streams included) with a REAL
+asynchronous all-reduce enqueued behind every segment.  Weight gradients go through per-split planes and the
+statistics through fixed-order / fp64 reductions, so the result must equal the monolithic backward bit for bit.
+SURVEY 4's N-rank == 1-rank oracle is emulated with two micro-batches: what two ranks would each compute and the
+all-reduce would sum is accumulated by two passes through the exchange path and must equal the sum of two
+independent monolithic runs; the fused optimizer then applies the 1/N average."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import C3, C5, GOLDEN, hyp, oracle_net
+
+sys.path.insert(0, GOLDEN)
+import cases  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nccl_world1():
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    port = 29600 + (os.getpid() % 300)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def _model(name, dtype):
+    from build_utils.parse_config import materialize_cfg
+    from models import YOLO
+    torch.manual_seed(0)
+    m = YOLO(materialize_cfg(name))
+    m.load_state_dict(oracle_net(name).synth_state(0))
+    m.dyk_dtype = dtype
+    m.nc, m.hyp, m.gr = 1, hyp("hyp.scratch.4"), 1.0
+    return m.cuda().train()
+
+
+def _batch(step, B=2, H=128, W=160):
+    g = torch.Generator().manual_seed(100 + step)
+    x, y = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
+    tg = torch.zeros(B * 3, 6)
+    tg[:, 0] = torch.arange(B).repeat_interleave(3).float()
+    tg[:, 2:4] = torch.rand(B * 3, 2, generator=g) * 0.8 + 0.1
+    tg[:, 4:6] = torch.rand(B * 3, 2, generator=g) * 0.3 + 0.05
+    return x.cuda(), y.cuda(), tg.cuda()
+
+
+def _backward(m, batch):
+    from build_utils.utils import compute_loss
+    x, y, tg = batch
+    ld = compute_loss(m(x, y), tg, m)
+    (ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]).backward()
+    return ld
+
+
+@pytest.mark.parametrize("name,dtype", [(C3, "fp32"), (C3, "bf16"), (C5, "bf16")])
+def test_segmented_backward_with_nccl_allreduce_equals_monolithic_bitwise(nccl_world1, name, dtype):
+    from dyk.ddp import GradAllReduce
+    batch = _batch(0)
+    ref = _model(name, dtype)
+    _backward(ref, batch)
+    g_ref = ref.engine.store.G.clone()
+    m = _model(name, dtype)
+    red = GradAllReduce(m, nccl_world1, n_buckets=8)
+    calls = []
+    orig = red.bucket_ready
+    red.bucket_ready = lambda lo, hi: (calls.append((lo, hi)), orig(lo, hi))[1]
+    _backward(m, batch)
+    red.all_reduce()
+    torch.cuda.synchronize()
+    total = m.engine.store.total
+    assert len(calls) >= 3 and calls[0][1] == total and calls[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(calls, calls[1:])), "buckets must tile the gradient buffer"
+    assert bool(torch.isfinite(g_ref).all()) and float(g_ref.abs().sum()) > 0
+    assert torch.equal(m.engine.store.G, g_ref), "segmented + all-reduced gradients differ from the monolithic backward"
+
+
+def test_two_rank_emulation_matches_sum_of_independent_ranks(nccl_world1):
+    """rank r of a 2-rank job sees micro-batch r; the SUM all-reduce + grad_scale = 1/2 of the fused step must equal
+    Adam on the mean of the two per-rank gradients (per-rank BatchNorm statistics and per-rank loss normalisation,
+    as stock DDP over the reference would do: SURVEY 8e)."""
+    from dyk.ddp import GradAllReduce, reduce_dict
+    from dyk.optim import FusedAdam
+    b0, b1 = _batch(1), _batch(2)
+    per_rank = []
+    for b in (b0, b1):
+        r = _model(C3, "fp32")
+        _backward(r, b)
+        per_rank.append(r.engine.store.G.clone())
+    want_sum = per_rank[0] + per_rank[1]
+    m = _model(C3, "fp32")
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    red = GradAllReduce(m, nccl_world1)
+    opt = FusedAdam(m, lr=1e-3, betas=(0.937, 0.999), weight_decay=5e-4)
+    opt.grad_scale = 0.5
+    for b in (b0, b1):
+        ld = _backward(m, b)
+        red.all_reduce()
+    assert torch.equal(m.engine.store.G, want_sum)
+    assert reduce_dict(ld) is ld                       # one rank: the loss dict is returned untouched (distributed_utils.py:127)
+    opt.step()
+    # the same update through torch.optim.Adam on the averaged gradient
+    r = _model(C3, "fp32")
+    r.load_state_dict(sd0)
+    x, y, _ = b0
+    r(x, y)                                            # adopt the store on the device
+    st = r.engine.store
+    st.attach_grads()
+    st.G.copy_(want_sum * 0.5)
+    topt = torch.optim.Adam(r.parameters(), lr=1e-3, betas=(0.937, 0.999), weight_decay=5e-4)
+    topt.step()
+    a, b = m.engine.store.P, st.P
+    assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())

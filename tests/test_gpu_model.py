@@ -241,40 +241,6 @@ def test_module_surface_device_moves_and_checkpoints():
         _model(C3).eval()(x.cuda())
 
 
-def test_segmented_backward_equals_monolithic():
-    """data-parallel path on one GPU: the bucketed, segmented backward produces the same gradients"""
-    x, y = _inputs()
-    grads = []
-    for seg in (False, True):
-        m = _model(C3).train()
-        if seg:
-            class Rec:
-                def __init__(self, eng):
-                    self.eng, self.ready = eng, []
-                    from dyk.ddp import GradAllReduce
-                    self._impl = GradAllReduce.__new__(GradAllReduce)
-                    self._impl.engine, self._impl.n_buckets, self._impl._segs = eng, 8, {}
-                def segments(self, plan):
-                    return self._impl.segments(plan)
-                def bucket_ready(self, lo, hi):
-                    self.ready.append((lo, hi))
-            rec = Rec(m.engine)
-            m.engine.grad_sync = rec
-        out = m(x.cuda(), y.cuda())
-        sum((t ** 2).mean() for t in out).backward()
-        grads.append(m.engine.store.G.clone())
-        if seg:
-            assert len(rec.ready) >= 4 and rec.ready[0][1] == m.engine.store.total and rec.ready[-1][0] == 0
-    # two independent runs differ by the summation order of the fp32 atomics, which the ill-conditioned early
-    # layers amplify (see the fp64 test): the tail of the buffer (last layers, no amplification) must agree
-    # tightly, the whole buffer statistically.
-    e = m.engine.store.by_name["module_list.280.Conv2d.weight"]      # last head conv: directly under the loss
-    tail = slice(e.offset, e.offset + e.numel)
-    assert float((grads[0][tail] - grads[1][tail]).norm() / grads[0][tail].norm()) < 5e-3
-    rel = float((grads[0] - grads[1]).norm() / grads[0].norm())
-    assert rel < 0.15, rel
-
-
 def test_baseline_size_train_step_is_bit_reproducible():
     """the BASELINE workload (target cfg, 16 pairs of 512x640, bf16): shapes, finiteness, and run-to-run bit identity of
     the head outputs, the loss and EVERY parameter gradient (statistics are folded in a fixed order inside a workgroup

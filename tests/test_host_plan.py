@@ -222,3 +222,106 @@ def test_darknet_weights_roundtrip(tmp_path):
         if "num_batches_tracked" not in k:
             assert torch.equal(got[k], v), k
     assert int(m.seen[0]) == 12345
+
+
+def test_darknet_weights_match_reference_loader():
+    """the REFERENCE's load_darknet_weights (models.py:318-364) ran on a formula-generated weight stream
+    (tests/golden/make_golden_round2.py weights): the same stream through this loader must touch the same tensors and
+    leave the same values -- including `cutoff`, the header fields and the quirk that only [convolutional]
+    sections consume weights (a MobileNet cfg's [depthwiseconvolutional] / [se] sections are skipped)."""
+    import json
+    import sys
+    from helpers import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_golden_round2 as R2
+    from models import load_darknet_weights
+    with open(os.path.join(GOLDEN, "weights_load.json")) as f:
+        gold = json.load(f)
+    import tempfile
+    for cfg_name, cutoff in R2.WEIGHTS_CASES:
+        g = gold["%s|%d" % (cfg_name, cutoff)]
+        torch.manual_seed(1)
+        m = _model(cfg_name)
+        before = {k: v.clone() for k, v in m.state_dict().items()}
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "synthetic.weights")
+            R2.write_weights_file(path, g["n_stream"])
+            load_darknet_weights(m, path, cutoff)
+        after = m.state_dict()
+        # (the reference model starts from different random values, so "changed" is judged against the stream itself)
+        want = set(g["changed"])
+        for k in after:
+            if k in want:
+                assert abs(float(after[k].double().sum()) - g["sums"][k]) <= 1e-9 * max(1.0, abs(g["sums"][k])), (cfg_name, k)
+                assert float(after[k].reshape(-1)[0]) == g["first"][k], (cfg_name, k)
+            else:
+                assert torch.equal(after[k], before[k]), (cfg_name, k, "must not be touched")
+        assert [int(q) for q in m.version] == g["version"] and int(m.seen[0]) == g["seen"]
+
+
+def test_frozen_layers_shrink_the_backward_list():
+    """--freeze-layers (reference train.py:77-82): frozen parameters get no weight-gradient launch and nothing is
+    differentiated below the first trainable section"""
+    from dyk import lib as L
+    from dyk.params import ParamStore
+    from dyk.plan import compile_plan
+    m = _model(C3)
+    st = ParamStore(m)
+    st.adopt(torch.device("cpu"))
+    full = compile_plan(m, st, 2, 64, 96, torch.bfloat16, True, torch.device("cpu"), dry=True)
+    cut = 224                                           # both backbones and the three fusion stages
+    for idx in range(cut + 1):
+        for p in m.module_list[idx].parameters():
+            p.requires_grad_(False)
+    assert st.frozen_key()
+    part = compile_plan(m, st, 2, 64, 96, torch.bfloat16, True, torch.device("cpu"), dry=True)
+    n_conv_trainable = sum(1 for i, d in enumerate(m.module_defs) if d["type"] == "convolutional" and i > cut)
+    assert [op for op, _ in part.bwd].count(L.OP_WGRAD) == n_conv_trainable
+    assert len(part.bwd) < len(full.bwd) // 2
+    assert len(part.fwd) == len(full.fwd)               # train-mode BatchNorm of frozen layers still runs (model.train())
+    # the first trainable conv has a weight gradient but no data gradient: nothing upstream needs it
+    first = min(e.layer for e in st.entries if e.param.requires_grad)
+    assert first == cut + 1
+    st.attach_grads()
+    assert m.module_list[0][0].weight.grad is None and m.module_list[first][0].weight.grad is not None
+
+
+def test_dropout_is_refused_in_training_plans(tmp_path):
+    """(the reference's parser keeps '.5' a string, so only probability=0/1 even constructs there: models.py:77-79)"""
+    from dyk.params import ParamStore
+    from dyk.plan import compile_plan
+    from models import YOLO
+    cfg = tmp_path / "tiny_kaist_drop.cfg"
+    cfg.write_text("""[net]
+channels=3
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[dropout]
+probability=1
+
+[convolutional]
+size=1
+stride=1
+pad=1
+filters=18
+activation=linear
+
+[yolo]
+mask = 0,1,2
+anchors = 10,13, 16,30, 33,23
+classes=1
+num=3
+""")
+    m = YOLO(str(cfg))
+    st = ParamStore(m)
+    st.adopt(torch.device("cpu"))
+    compile_plan(m, st, 1, 64, 64, torch.bfloat16, False, torch.device("cpu"), dry=True)     # inference: identity
+    with pytest.raises(NotImplementedError):
+        compile_plan(m, st, 1, 64, 64, torch.bfloat16, True, torch.device("cpu"), dry=True)
