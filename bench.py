@@ -29,6 +29,7 @@ import torch  # noqa: E402
 CFG = "kaist_dyolov4_fshare_global_concat_se3"
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+PROFILE_TAG = "r02"            # profiles/<tag>_*.json written by tools/run_gpu_round.sh for this round
 
 
 def synth_batch(B, H, W, rank, device):
@@ -97,32 +98,59 @@ def profile_plan(plan, stream, dump=None):
     return res
 
 
-def cpu_baseline(cfg_name, steps=6):
-    """oracle (CPU restatement of the reference's train step: forward + loss + backward) on B=2, 512x640"""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg_name, steps=2):
+    """the oracle (CPU restatement of the reference path, plain torch CPU ops, parity-checked against the
+    imported reference) on the host cores, bounded: (a) the BASELINE workload's cfg at batch 2, 512x640, full train step
+    (forward + loss + backward), one untimed warm-up step then `steps` timed ones -> pairs/s, the unit of `value`;
+    (b) config C1 exactly as BASELINE.json states it: kaist_yolov3.cfg, batch 2, 416x416, forward + loss."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from build_utils.parse_config import sections_from_json
     from oracle.model import OracleNet
     from oracle import loss as oloss
-    threads = min(os.cpu_count() or 1, 32)      # beyond ~32 threads the many small CPU convs only oversubscribe
+    cores = os.cpu_count() or 1
+    threads = int(os.environ.get("DYK_CPU_THREADS", cores))
     torch.set_num_threads(threads)
-    net = OracleNet(sections_from_json(os.path.join(PKG, "config", "netdefs", cfg_name + ".json")), "config/%s.cfg" % cfg_name)
-    sd = net.synth_state(0)
-    for k, v in sd.items():
-        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
-            v.requires_grad_(True)
-    B = 1
-    v, l, t = synth_batch(B, 512, 640, 0, "cpu")
     hyp = load_hyp()
-    av = net.anchor_vecs()
-    t0 = time.time()
-    for _ in range(steps):
-        p = net.forward(sd, v.float() / 255, l.float() / 255, training=True)
-        ld = oloss.compute_loss(p, t, av, hyp, 1, 1.0, net.v4)
-        (ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]).backward()
-    dt = time.time() - t0
-    return {"value": B * steps / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": "%d train step(s) (forward+loss+backward, fp32) of %s, batch %d, 512x640, oracle/ on host CPU, %.1f s"
-                      % (steps, cfg_name, B, dt)}
+
+    def run(name, B, H, W, backward, n):
+        net = OracleNet(sections_from_json(os.path.join(PKG, "config", "netdefs", name + ".json")), "config/%s.cfg" % name)
+        sd = net.synth_state(0)
+        if backward:
+            for k, v in sd.items():
+                if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+                    v.requires_grad_(True)
+        v, l, t = synth_batch(B, H, W, 0, "cpu")
+        av = net.anchor_vecs()
+        dt = 0.0
+        for i in range(n + 1):                       # step 0 = warm-up (first-call allocation / thread-pool start)
+            t0 = time.time()
+            with torch.set_grad_enabled(backward):
+                p = net.forward(sd, v.float() / 255, l.float() / 255 if net.second_index is not None else None, training=True)
+                ld = oloss.compute_loss(p, t, av, hyp, 1, 1.0, net.v4)
+                if backward:
+                    (ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]).backward()
+            if i:
+                dt += time.time() - t0
+        return B * n / dt, dt
+
+    c3, dt3 = run(cfg_name, 2, 512, 640, True, steps)
+    c1, dt1 = run("kaist_yolov3", 2, 416, 416, False, 3)
+    return {"value": c3, "unit": "pairs/s", "cores": threads, "kind": "port", "cpu": _cpu_model(), "host_cores": cores,
+            "sample": "%d train steps (forward+loss+backward, fp32) of %s, batch 2, 512x640, after 1 warm-up step, oracle/ "
+                      "(torch CPU ops) on %d threads, %.1f s" % (steps, cfg_name, threads, dt3),
+            "c1": {"value": c1, "unit": "images/s", "sample": "kaist_yolov3.cfg batch 2, 416x416, forward + loss, 3 passes "
+                   "after 1 warm-up, %.1f s" % dt1}}
 
 
 def eval_bench(args):
@@ -196,7 +224,25 @@ def main():
     if args.mode == "eval":
         return eval_bench(args)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start one rank per GPU over RCCL (the driver's torchrun form sets
+        # WORLD_SIZE itself and lands in the branch below)
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, have))
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not os.environ.get("DYK_FORCE_DDP"):
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -210,7 +256,7 @@ def main():
 
     from build_utils.parse_config import materialize_cfg
     from build_utils.utils import compute_loss
-    from dyk.ddp import GradAllReduce
+    from dyk.ddp import GradAllReduce, reduce_dict
     from dyk.optim import FusedAdam
     from models import YOLO
 
@@ -247,6 +293,8 @@ def main():
         ld = compute_loss(pred, targets, model)
         loss = ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]
         if host_tl: tl.append(time.perf_counter())
+        if reducer is not None:
+            reduce_dict(ld)                          # the harness's per-step loss exchange (kaist_train_eval_utils.py:82)
         loss.backward()
         if host_tl: tl.append(time.perf_counter())
         if reducer is not None:
@@ -302,18 +350,36 @@ def main():
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = 2.0 * f1 / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0      # forward + data-gradient launches
             tot_ms = sum(a[1] for w in prof.values() for a in w.values())
-            # HBM-side bytes per launch of the same kernel from the committed rocprofv3 PMC passes of this command
-            # (tools/run_gpu_round.sh: --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 fetch correction)
-            traffic = None
+            # HBM-side bytes per launch and the IN-STEP durations of the same kernel come from rocprofv3 runs of this very
+            # command (tools/run_gpu_round.sh -> profiles/): they are reported only when those files were produced by
+            # the code that is running now (hash over the kernel sources and the plan compiler), otherwise null
+            traffic, in_step, src = None, None, None
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-                    traffic = json.load(f)["conv_igemm_kernel"]["hbm_bytes_per_launch"]
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from code_sha import code_sha
+                sha = code_sha()
+                with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_summary.json")) as f:
+                    pj = json.load(f)
+                if pj.get("code_sha") == sha:
+                    traffic = pj["kernels"]["conv_igemm_kernel"]["hbm_bytes_per_launch"]
+                    src = "profiles/%s_pmc_summary.json" % PROFILE_TAG
+                with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_step_kernels.json")) as f:
+                    kj = json.load(f)
+                if kj.get("code_sha") == sha:
+                    fam = kj["families"]["conv_igemm_kernel"]
+                    t_us = fam["total_us"] + kj["families"].get("conv_halo_kernel", {"total_us": 0.0})["total_us"]
+                    in_step = {"tflops": 2.0 * f1 / (t_us * 1e-6) / 1e12, "frac": 2.0 * f1 / (t_us * 1e-6) / 1e12 / peak,
+                               "launches": fam["n"] + kj["families"].get("conv_halo_kernel", {"n": 0})["n"], "total_us": t_us,
+                               "source": "profiles/%s_step_kernels.json (rocprofv3 kernel trace of one step, three streams "
+                                         "running concurrently: durations include time shared with other kernels)" % PROFILE_TAG}
             except Exception:
                 pass
             out["roofline"] = {
                 "bound": "mfma", "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.json)",
+                "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % src if src else None,
+                "frac_is": "isolated-kernel fraction: every launch timed alone on the chip with HIP events (this run)",
+                "in_step": in_step,
                 "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1),
                 "flops_per_launch": 2.0 * f1 / max(ig_n, 1),
                 "detail": {

@@ -47,6 +47,22 @@ def _worker(rank, world, port, q):
             red.bucket_ready(lo, hi)
         red.all_reduce()
         ok = bool((G == float(sum(range(1, world + 1)))).all())
+        # the harness's other exchanges: per-step loss reduction (distributed_utils.py:117-142), object gather (:74-114)
+        # and the padded detection gather of the sharded evaluation
+        from dyk.ddp import all_gather, gather_detections, get_rank, get_world_size, reduce_dict
+        assert get_world_size() == world and get_rank() == rank
+        ld = {"obj_loss": torch.tensor([2.0 * (rank + 1)]), "box_loss": torch.tensor([1.0 * (rank + 1)]),
+              "class_loss": torch.tensor([0.0])}
+        red_ld = reduce_dict(ld)
+        ok = ok and list(red_ld.keys()) == ["box_loss", "class_loss", "obj_loss"]
+        ok = ok and float(red_ld["box_loss"]) == 1.5 and float(red_ld["obj_loss"]) == 3.0 and red_ld["box_loss"].shape == (1,)
+        ok = ok and float(reduce_dict(ld, average=False)["obj_loss"]) == 6.0
+        objs = all_gather({"rank": rank, "blob": list(range(rank * 100))})
+        ok = ok and [o["rank"] for o in objs] == [0, 1] and len(objs[1]["blob"]) == 100
+        dets = [torch.full((2 + rank, 6), float(rank)), None]          # rank 0: 2 rows, rank 1: 3 rows, one empty image each
+        rows = gather_detections(dets, [10 * rank, 10 * rank + 1])
+        ok = ok and tuple(rows.shape) == (5, 7) and rows[:, 0].tolist() == [0.0, 0.0, 10.0, 10.0, 10.0]
+        ok = ok and rows[:2, 1:].eq(0).all().item() and rows[2:, 1:].eq(1).all().item()
         q.put((rank, ok, len(segs), ran == [(a, b) for a, b, _, _ in segs]))
     finally:
         dist.destroy_process_group()

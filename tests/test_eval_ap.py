@@ -1,0 +1,91 @@
+"""End-to-end evaluation parity (north_star: "eval AP@IoU=0.5 within +-0.1 of the reference on identical inputs").
+
+tests/golden/evalap.npz holds what the REFERENCE's own chain produced on seeded weights and images
+(make_golden_round2.py evalap): YOLO eval forward -> non_max_suppression(conf, 0.6, multi_label=False) ->
+scale_coords -> other_utils.metrics.compute_ap_lamr (evaluate.py:64-117), with ground truth derived from the
+reference's detections.  CPU: the oracle's chain reproduces it.  GPU: the product's chain (HIP forward / decode /
+NMS / scale_coords + the AP evaluator) must land within 0.1 AP points (1e-3 absolute) -- in fp32 AND on the bf16
+MFMA path the benchmark runs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, oracle_net
+
+sys.path.insert(0, GOLDEN)
+import make_golden_round2 as R2  # noqa: E402
+
+GOLD = np.load(os.path.join(GOLDEN, "evalap.npz"))
+
+
+def _state():
+    net = oracle_net(R2.EVAL_CFG)
+    sd = net.synth_state(3)
+    for j, f in zip(net.yolo_layers, GOLD["head_scale"]):
+        k = "module_list.%d.Conv2d.weight" % (j - 1)
+        sd[k] = sd[k] * float(f)
+    return net, sd
+
+
+def _labels():
+    return [GOLD["labels%d" % i].copy() for i in range(R2.EVAL_B)], GOLD["shapes"]
+
+
+def _preds(dets, scale_coords):
+    preds = []
+    for idx, p in enumerate(dets):
+        if p is None:
+            continue
+        boxes = scale_coords((R2.EVAL_H, R2.EVAL_W), p[:, :4].clone(), R2.EVAL_SHAPES[idx][0], R2.EVAL_SHAPES[idx][1])
+        boxes, conf = boxes.cpu().numpy(), p[:, 4].cpu().numpy()
+        preds += [{"img_id": idx, "conf": float(conf[i]), "bbox": boxes[i]} for i in range(boxes.shape[0])]
+    preds.sort(key=lambda q: q["conf"], reverse=True)
+    return preds
+
+
+def test_oracle_eval_chain_reproduces_the_reference_ap():
+    from oracle import metrics as ometrics, nms as onms
+    net, sd = _state()
+    v8, l8 = R2.eval_images()
+    with torch.no_grad():
+        io, _ = net.forward(sd, v8.float() / 255.0, l8.float() / 255.0, training=False)
+    assert np.allclose(io.numpy(), GOLD["io"], rtol=1e-4, atol=1e-4)
+    dets = onms.non_max_suppression(io, conf_thres=float(GOLD["conf"]), iou_thres=0.6, multi_label=False)
+    for i, d in enumerate(dets):
+        assert d.shape[0] == GOLD["ndet"][i]
+    labels, shapes = _labels()
+    res = ometrics.compute_ap_lamr(_preds(dets, onms.scale_coords), labels, shapes)
+    assert abs(res["ap"] - float(GOLD["ap"])) < 1e-6 and abs(res["lamr"] - float(GOLD["lamr"])) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol_ap", [("fp32", 1e-3), ("bf16", 1e-3)])
+def test_hip_eval_chain_matches_reference_ap(dtype, tol_ap):
+    from build_utils.parse_config import materialize_cfg
+    from build_utils.utils import non_max_suppression, scale_coords
+    from models import YOLO
+    from other_utils.metrics import compute_ap_lamr
+    _, sd = _state()
+    torch.manual_seed(0)
+    m = YOLO(materialize_cfg(R2.EVAL_CFG))
+    m.load_state_dict(sd)
+    m.dyk_dtype = dtype
+    m = m.cuda().eval()
+    v8, l8 = R2.eval_images()
+    with torch.no_grad():
+        io, _ = m(v8.cuda().float() / 255.0, l8.cuda().float() / 255.0)
+    dets = non_max_suppression(io, conf_thres=float(GOLD["conf"]), iou_thres=0.6, multi_label=False)
+    labels, shapes = _labels()
+    res = compute_ap_lamr(_preds(dets, scale_coords), labels, shapes)
+    print("AP %.5f (reference %.5f)  LAMR %.5f (reference %.5f)  dtype %s" % (res["ap"], GOLD["ap"], res["lamr"], GOLD["lamr"], dtype))
+    if dtype == "fp32":
+        for i, d in enumerate(dets):                 # same detections, to rounding
+            ref = GOLD["det%d" % i]
+            got = torch.cat([scale_coords((R2.EVAL_H, R2.EVAL_W), d[:, :4].clone(), *R2.EVAL_SHAPES[i]), d[:, 4:6]], 1).cpu().numpy()
+            assert got.shape == ref.shape, (i, got.shape, ref.shape)
+            assert np.allclose(got, ref, rtol=2e-3, atol=0.25), i
+    assert abs(res["ap"] - float(GOLD["ap"])) <= tol_ap, (res["ap"], float(GOLD["ap"]))
+    assert abs(res["lamr"] - float(GOLD["lamr"])) <= 5e-3, (res["lamr"], float(GOLD["lamr"]))

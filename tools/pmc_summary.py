@@ -45,8 +45,11 @@ def main():
         wb = write.get(fam, {}).get("sum", 0.0) * 1024
         res[fam] = {"dispatches": n, "fetch_bytes": fb, "write_bytes": wb,
                     "hbm_bytes_per_launch": (fb + wb) / n if n else None}
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from code_sha import code_sha
     with open(sys.argv[3], "w") as f:
-        json.dump(res, f, indent=1)
+        json.dump({"code_sha": code_sha(), "step_hbm_bytes": sum(v["fetch_bytes"] + v["write_bytes"] for v in res.values()),
+                   "kernels": res}, f, indent=1)
     tot = sum(v["fetch_bytes"] + v["write_bytes"] for v in res.values())
     print("one train step: %.2f GB of HBM-side traffic (fetch x2-corrected + write)" % (tot / 1e9))
     for k, v in sorted(res.items(), key=lambda kv: -(kv[1]["fetch_bytes"] + kv[1]["write_bytes"]))[:14]:

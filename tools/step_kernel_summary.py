@@ -27,7 +27,10 @@ def main():
         d = fam.setdefault(family(n), {"n": 0, "total_us": 0.0})
         d["n"] += 1
         d["total_us"] += (e - s) / 1e3
-    out = {"step_us": round(T, 1), "launches": len(seg), "sum_kernel_us": round(sum(d["total_us"] for d in fam.values()), 1),
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from code_sha import code_sha
+    out = {"code_sha": code_sha(), "step_us": round(T, 1), "launches": len(seg), "sum_kernel_us": round(sum(d["total_us"] for d in fam.values()), 1),
            "families": {}}
     print("one step: %.1f us wall, %d launches, sum of kernel durations %.1f us" % (T, len(seg), out["sum_kernel_us"]))
     for k, d in sorted(fam.items(), key=lambda kv: -kv[1]["total_us"]):
