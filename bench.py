@@ -119,7 +119,10 @@ def cpu_baseline(cfg_name, steps=2):
     from oracle.model import OracleNet
     from oracle import loss as oloss
     cores = os.cpu_count() or 1
-    threads = int(os.environ.get("DYK_CPU_THREADS", cores))
+    # SURVEY 8(d) says "all host cores"; measured on the 256-thread GPU host (round 2): with all 256 threads this very
+    # sample took 260 s per step (0.0077 pairs/s) -- the ~400 small CPU convolutions of a step only oversubscribe --
+    # against ~1 pair/s on 32 threads.  The baseline is quoted at the setting that is fastest for the reference path.
+    threads = int(os.environ.get("DYK_CPU_THREADS", min(cores, 32)))
     torch.set_num_threads(threads)
     hyp = load_hyp()
 
@@ -239,6 +242,12 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
+
+    # the ONE JSON line must be the last thing on stdout: RCCL / HIP libraries write banners through C stdio (flushed at
+    # exit, i.e. after Python's own output), so fd 1 is pointed at stderr and the JSON goes out through a private handle
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and not os.environ.get("DYK_FORCE_DDP"):
@@ -390,7 +399,8 @@ def main():
                     "per_op_ms": {w: {str(k): [a[0], round(a[1], 4)] for k, a in prof[w].items()} for w in prof}}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cfg)
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -210,6 +210,8 @@ extern "C" int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream,
                 rc = dyk_grad_reduce((float*)m->p[0], (const float*)m->p[1], (const DykGradReduceEntry*)m->p[2], m->i[0], m->i[1], stream); break;
             case DYK_OP_BN_FWD_FUSED:
                 rc = dyk_bn_finalize_act_fwd((const DykBnFinalizeDesc*)m->p[0], (const DykEwDesc*)m->p[1], stream); break;
+            case DYK_OP_STEM_FWD: rc = dyk_stem_conv_fwd((const DykStemDesc*)dp, stream); break;
+            case DYK_OP_STEM_WGRAD: rc = dyk_stem_conv_wgrad((const DykStemDesc*)dp, stream); break;
             case DYK_OP_CAST_PAD_ROWS:
                 rc = dyk_cast_pad_rows((const float*)m->p[0], m->p[1], m->i[0], m->i[1], m->i[2], m->i[3], stream); break;
             default: rc = DYK_ERR_UNSUPPORTED; break;
@@ -300,6 +302,71 @@ extern "C" int dyk_run_commands_overlap(const DykCommand* cmds, int32_t n, void*
     if (used_side) {
         if (hipEventRecord(ev_done, side) != hipSuccess || hipStreamWaitEvent(main_s, ev_done, 0) != hipSuccess) return DYK_ERR_HIP;
     }
+    return DYK_OK;
+}
+
+extern "C" int dyk_run_schedule(const DykCommand* cmds, const DykSchedEntry* sched, int32_t n, int32_t n_streams,
+                                int32_t low_priority_last, void* stream, int32_t* failed_index) {
+    if (!cmds || !sched || n < 0 || n_streams < 1 || n_streams > 8) return DYK_ERR_ARG;
+    static hipStream_t aux[2][8] = {};            // [low_priority_last][index]: created on first use
+    static hipEvent_t* events = nullptr;          // one completion event per schedule position, grown on demand
+    static int n_events = 0;
+    static hipEvent_t ev_start = nullptr, ev_join[8] = {};
+    if (!ev_start) {
+        if (hipEventCreateWithFlags(&ev_start, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
+        for (auto& e : ev_join)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
+    }
+    if (n > n_events) {
+        hipEvent_t* grown = (hipEvent_t*)realloc(events, sizeof(hipEvent_t) * (size_t)n);
+        if (!grown) return DYK_ERR_HIP;
+        events = grown;
+        for (int i = n_events; i < n; ++i)
+            if (hipEventCreateWithFlags(&events[i], hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
+        n_events = n;
+    }
+    const int lp = low_priority_last ? 1 : 0;
+    hipStream_t main_s = (hipStream_t)stream;
+    bool used[8] = {};
+    auto stream_of = [&](int s) -> hipStream_t {
+        if (s == 0) return main_s;
+        if (!aux[lp][s]) {
+            int lo = 0, hi = 0;
+            hipDeviceGetStreamPriorityRange(&lo, &hi);
+            const int prio = (lp && s == n_streams - 1) ? lo : 0;
+            if (hipStreamCreateWithPriority(&aux[lp][s], hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
+        }
+        return aux[lp][s];
+    };
+    if (n_streams > 1 && hipEventRecord(ev_start, main_s) != hipSuccess) return DYK_ERR_HIP;
+    for (int32_t k = 0; k < n; ++k) {
+        const DykSchedEntry& e = sched[k];
+        if (e.stream < 0 || e.stream >= n_streams || e.nwait < 0 || e.nwait > 7) return DYK_ERR_ARG;
+        hipStream_t s = stream_of(e.stream);
+        if (!s && e.stream) return DYK_ERR_HIP;
+        if (e.stream && !used[e.stream]) {
+            if (hipStreamWaitEvent(s, ev_start, 0) != hipSuccess) return DYK_ERR_HIP;
+            used[e.stream] = true;
+        }
+        for (int q = 0; q < e.nwait; ++q) {
+            const int32_t w = e.wait[q];
+            if (w < 0 || w >= k) return DYK_ERR_ARG;
+            if (hipStreamWaitEvent(s, events[w], 0) != hipSuccess) return DYK_ERR_HIP;
+        }
+        if (e.cmd >= 0) {
+            const int rc = dyk_run_commands(cmds + e.cmd, 1, (void*)s, nullptr);
+            if (rc != DYK_OK) {
+                if (failed_index) *failed_index = e.cmd;
+                return rc;
+            }
+        }
+        if (e.record && hipEventRecord(events[k], s) != hipSuccess) return DYK_ERR_HIP;
+    }
+    for (int s = 1; s < n_streams; ++s)
+        if (used[s]) {
+            if (hipEventRecord(ev_join[s], aux[lp][s]) != hipSuccess || hipStreamWaitEvent(main_s, ev_join[s], 0) != hipSuccess)
+                return DYK_ERR_HIP;
+        }
     return DYK_OK;
 }
 

@@ -96,13 +96,23 @@ class Engine:
         stream = torch.cuda.current_stream().cuda_stream
         self.store.compute_weights(plan.dtype, force=False)
         xs = {"x": x, "y": y if y is not None else x}
-        keep = []
+        keep, prepared = [], {}
         for desc, which in plan.dyn_in:
             t = xs[which]
+            if isinstance(desc, L.DykStemDesc):
+                # direct stem kernels read the image batch as it comes: float32 0..1, or the loader's uint8 (divided by
+                # 255 inside the kernel exactly as `imgs.float() / 255.0` does)
+                if t.dtype not in (torch.uint8, torch.float32) or not t.is_contiguous():
+                    t = prepared.setdefault((which, "f"), t.float().contiguous())
+                desc.img, desc.in_u8 = t.data_ptr(), 1 if t.dtype == torch.uint8 else 0
+                keep.append(t)
+                continue
             if t.dtype == torch.uint8:
                 # the loader's uint8 batch handed over as is: `.float() / 255.0` in one HIP pass
                 from .functional import prepare_images
-                t = prepare_images(t)
+                t = prepared.get((which, "p"))
+                if t is None:
+                    t = prepared[(which, "p")] = prepare_images(xs[which])
             elif t.dtype != torch.float32 or not t.is_contiguous():
                 t = t.float().contiguous()
             keep.append(t)

@@ -21,7 +21,7 @@ MAX_TAPS = 25
  OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_SE_POOL, OP_SE_FC_FWD, OP_SE_FC_BWD,
  OP_SE_SCALE, OP_BN_BWD_PARAMS, OP_BN_FOLD, OP_WFUSE_WEIGHTS, OP_WFUSE_BWD_PARAMS, OP_HEAD_PERMUTE_FWD,
  OP_HEAD_PERMUTE_BWD, OP_PATCH_GATHER, OP_MEMSET, OP_YOLO_DECODE, OP_DW_FWD, OP_DW_DGRAD, OP_DW_WGRAD,
- OP_CAST_PAD_ROWS, OP_BN_FWD_FUSED, OP_GRAD_REDUCE) = range(1, 32)
+ OP_CAST_PAD_ROWS, OP_BN_FWD_FUSED, OP_GRAD_REDUCE, OP_STEM_FWD, OP_STEM_WGRAD) = range(1, 34)
 
 
 class DykLibraryError(RuntimeError):
@@ -113,6 +113,17 @@ class DykCommand(ctypes.Structure):
     _fields_ = [("op", _i32), ("lane", _i32), ("desc", _vp)]
 
 
+class DykStemDesc(ctypes.Structure):
+    _fields_ = [("img", _vp), ("wt", _vp), ("y", _vp), ("stats", _vp), ("scale", _vp), ("shift", _vp), ("dy", _vp),
+                ("dw", _vp), ("part", _vp), ("dtype", _i32), ("in_u8", _i32),
+                ("B", _i32), ("H", _i32), ("W", _i32), ("Cout", _i32), ("k", _i32), ("stride", _i32), ("pad", _i32),
+                ("Ho", _i32), ("Wo", _i32), ("ldy", _i32), ("lddy", _i32), ("act", _i32), ("stats_slots", _i32)]
+
+
+class DykSchedEntry(ctypes.Structure):
+    _fields_ = [("cmd", _i32), ("stream", ctypes.c_int16), ("nwait", _i8), ("record", _i8), ("wait", _i32 * 7)]
+
+
 class DykDecodeDesc(ctypes.Structure):
     _fields_ = [("p", _vp), ("io", _vp), ("B", _i32), ("na", _i32), ("ny", _i32), ("nx", _i32), ("no", _i32),
                 ("rows_total", _i32), ("row_offset", _i32), ("v4", _i32), ("stride", _f32),
@@ -190,6 +201,7 @@ SIGNATURES = {
     "dyk_dwconv_wgrad_rows": (_i32, [_P(DykDwDesc)]),
     "dyk_run_commands": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
     "dyk_run_commands_overlap": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
+    "dyk_run_schedule": (_i32, [_P(DykCommand), _P(DykSchedEntry), _i32, _i32, _i32, _vp, _P(_i32)]),
     "dyk_yolo_decode": (_i32, [_P(DykDecodeDesc), _vp]),
     "dyk_build_targets": (_i32, [_P(DykTargetsDesc), _vp]),
     "dyk_yolo_loss": (_i32, [_P(DykLossDesc), _P(DykTargetsDesc), _vp]),
@@ -199,6 +211,9 @@ SIGNATURES = {
     "dyk_sgd_step": (_i32, [_P(DykOptimDesc), _vp]),
     "dyk_run_commands_timed": (_i32, [_P(DykCommand), _i32, _vp, _P(_f32)]),
     "dyk_loss_scale_grads": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "dyk_stem_conv_fwd": (_i32, [_P(DykStemDesc), _vp]),
+    "dyk_stem_conv_wgrad": (_i32, [_P(DykStemDesc), _vp]),
+    "dyk_stem_wgrad_planes": (_i32, [_P(DykStemDesc)]),
     "dyk_box_convert": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "dyk_scale_coords": (_i32, [_vp, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
 }

@@ -213,7 +213,7 @@ class ParamStore:
 
     def _alloc(self, dtype):
         fwd_off, fwd_n, bwd_off, bwd_n = self._layout_padded()
-        st = {"stems": {}, "fwd_pad_off": fwd_off, "bwd_pad_off": bwd_off}
+        st = {"stems": {}, "stems_t": {}, "fwd_pad_off": fwd_off, "bwd_pad_off": bwd_off}
         st["Wc"] = self.P if dtype == torch.float32 else torch.empty(self.total, dtype=dtype, device=self.device)
         st["Wt"] = torch.zeros(self.total, dtype=dtype, device=self.device)
         st["Wc_pad"] = torch.zeros(fwd_n, dtype=dtype, device=self.device)
@@ -222,6 +222,8 @@ class ParamStore:
             if e.kind == "stem_w":
                 co, ci, kh, kw = e.shape
                 st["stems"][e.name] = torch.zeros((co, _round_up(ci * kh * kw, 32)), dtype=dtype, device=self.device)
+                # fp32 [kh*kw*ci][co]: the direct stem kernel streams it through scalar loads (csrc/stem.hip)
+                st["stems_t"][e.name] = torch.zeros((ci * kh * kw, co), dtype=torch.float32, device=self.device)
         return st
 
     def compute_weights(self, dtype, force=False, skip_cast=False):
@@ -258,5 +260,7 @@ class ParamStore:
                 t = st["stems"][e.name]
                 check(lib.dyk_cast_pad_rows(self.P.data_ptr() + 4 * e.offset, t.data_ptr(), co, ci * kh * kw, t.shape[1],
                                             code, stream), "dyk_cast_pad_rows")
+                with torch.no_grad():
+                    st["stems_t"][e.name].copy_(self.P[e.offset:e.offset + e.numel].view(co, ci * kh * kw).t())
         st["version"] = ver
         return st

@@ -51,10 +51,12 @@ class TRef:
 class Arena:
     def __init__(self, name):
         self.name, self.size, self.tensor = name, 0, None
+        self.blocks = []                       # (offset, bytes) of every allocation, ascending (dyk/sched.py)
 
     def alloc(self, nbytes, align=256):
         off = _ru(self.size, align)
         self.size = off + nbytes
+        self.blocks.append((off, nbytes))
         return off
 
     def materialize(self, device, zero=True):
@@ -79,6 +81,7 @@ class Plan:
         self.arenas = {}
         self._keep = []
         self._cfwd = self._cbwd = None
+        self._cmd_us, self._rw_extra, self._part_extent = {}, {}, {}
 
     def _pack(self, cmds, lanes):
         arr = (L.DykCommand * max(len(cmds), 1))()
@@ -91,17 +94,36 @@ class Plan:
     def finalize(self):
         self._cfwd = self._pack(self.fwd, getattr(self, "fwd_lanes", {}))
         self._cbwd = self._pack(self.bwd, getattr(self, "bwd_lanes", {}))
+        self._desc_at = {ctypes.addressof(d): d for d in self._keep if isinstance(d, ctypes.Structure)}
+        self._schedules = {}
+
+    def schedule(self, which, start, end):
+        """dependency schedule of commands [start, end) (dyk/sched.py), built on first use"""
+        key = (which, start, end)
+        sc = self._schedules.get(key)
+        if sc is None:
+            from . import sched
+            sc = self._schedules[key] = sched.build(self, self.store, which, start, end)
+        return sc
 
     def run(self, which, stream_ptr, start=0, end=None):
         arr, n = (self._cfwd, len(self.fwd)) if which == "fwd" else (self._cbwd, len(self.bwd))
         end = n if end is None else end
         if end <= start:
             return
-        sub = ctypes.cast(ctypes.addressof(arr) + start * ctypes.sizeof(L.DykCommand), ctypes.POINTER(L.DykCommand))
         failed = ctypes.c_int32(-1)
-        overlap = os.environ.get("DYK_OVERLAP", "1") != "0"
-        fn = L.load().dyk_run_commands_overlap if overlap else L.load().dyk_run_commands
-        rc = fn(sub, end - start, ctypes.c_void_p(stream_ptr), ctypes.byref(failed))
+        mode = os.environ.get("DYK_SCHED", "dag")
+        if mode == "dag" and os.environ.get("DYK_OVERLAP", "1") != "0":
+            sc = self.schedule(which, start, end)
+            rc = L.load().dyk_run_schedule(arr, sc.array, sc.n, sc.n_streams,
+                                           1 if os.environ.get("DYK_SCHED_FILLER", "0") != "0" else 0,
+                                           ctypes.c_void_p(stream_ptr), ctypes.byref(failed))
+            start = 0
+        else:
+            sub = ctypes.cast(ctypes.addressof(arr) + start * ctypes.sizeof(L.DykCommand), ctypes.POINTER(L.DykCommand))
+            overlap = os.environ.get("DYK_OVERLAP", "1") != "0"
+            fn = L.load().dyk_run_commands_overlap if overlap else L.load().dyk_run_commands
+            rc = fn(sub, end - start, ctypes.c_void_p(stream_ptr), ctypes.byref(failed))
         if rc != 0 and failed.value >= 0:
             failed.value += start
         if rc != 0:
@@ -244,8 +266,20 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             d.k, d.stride, d.pad = k, stride, pad
             d.ldx = x_in.ld
             conv_op = L.OP_DW_FWD
+        elif (stem_src is not None and k == 3 and pad == 1 and stride in (1, 2) and cout in (16, 32) and bn
+              and os.environ.get("DYK_STEM_DIRECT", "1") != "0"):
+            # Cin=3 stem straight from the image batch (csrc/stem.hip): no float conversion pass, no im2col
+            Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+            Hi, Wi = H, W
+            d = L.DykStemDesc()
+            plan._keep.append(d)
+            d.dtype, d.B, d.H, d.W, d.Cout, d.k, d.stride, d.pad, d.Ho, d.Wo = code, B, H, W, cout, k, stride, pad, Ho, Wo
+            d.wt = cw["stems_t"][wname].data_ptr()
+            plan.dyn_in.append((d, stem_src))
+            conv_op = L.OP_STEM_FWD
+            rec["stem_direct"] = d
         elif stem_src is not None:
-            # Cin=3 stem: gather k*k*3 patches (zero padded to 32) and run a 1x1 MFMA conv on them
+            # Cin=3 stem, general shape: gather k*k*3 patches (zero padded to 32) and run a 1x1 MFMA conv on them
             Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
             patches = new_act(B, Ho, Wo, 32)
             g = misc()
@@ -275,7 +309,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         rec["x"] = x_in
         if stem_src is None:
             consume(x_in)
-        if not dw:
+        direct = "stem_direct" in rec
+        if not dw and not direct:
             d = L.DykConvDesc()
             plan._keep.append(d)
             d.dtype = code
@@ -302,10 +337,14 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 stats = st_arena.alloc(slots * 2 * cout * 8)   # fp64 replicas; the whole arena is zeroed at the start of a pass
                 vecs = new_ws(4 * cout * 4)          # scale | shift | mean | rstd
                 d.ldy, d.stats_slots = y_raw.ld, slots
-                if not dw:
+                if not dw and not direct:
                     d.act, d.flags = 0, L.EPI_STATS
-                later(lambda d=d, x_in=x_in, y_raw=y_raw, stats=stats: (
-                    setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", st_arena.ptr(stats))))
+                if direct:
+                    later(lambda d=d, y_raw=y_raw, stats=stats: (
+                        setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", st_arena.ptr(stats))))
+                else:
+                    later(lambda d=d, x_in=x_in, y_raw=y_raw, stats=stats: (
+                        setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", st_arena.ptr(stats))))
                 plan.fwd.append((conv_op, d))
                 f = L.DykBnFinalizeDesc()
                 plan._keep.append(f)
@@ -345,6 +384,13 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 a = ew_desc(a=z, out=z, act=act)
                 later(lambda a=a, vecs=vecs: (setattr(a, "p0", ws.ptr(vecs)), setattr(a, "p1", ws.ptr(vecs + 4 * cout))))
                 plan.fwd.append((L.OP_BN_ACT_FWD, a))
+                rec.update(z=z)
+                return z, rec
+            if direct:
+                d.ldy, d.act = z.ld, act
+                later(lambda d=d, z=z, vecs=vecs: (
+                    setattr(d, "y", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)), setattr(d, "shift", ws.ptr(vecs + 4 * cout))))
+                plan.fwd.append((L.OP_STEM_FWD, d))
                 rec.update(z=z)
                 return z, rec
             d.ldy, d.act, d.flags = z.ld, act, L.EPI_AFFINE
@@ -692,6 +738,22 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 later(lambda gd=gd, gx=gx, dy=dy: (setattr(gd, "x", ptr_of(gx)), setattr(gd, "y", ptr_of(dy))))
                 plan.bwd.append((L.OP_DW_DGRAD, gd))
                 return
+            if "stem_direct" in rec:
+                if wname in frozen:
+                    return
+                f = rec["stem_direct"]
+                wd = L.DykStemDesc()
+                plan._keep.append(wd)
+                wd.dtype, wd.B, wd.H, wd.W, wd.Cout, wd.k, wd.stride, wd.pad, wd.Ho, wd.Wo = (
+                    code, f.B, f.H, f.W, f.Cout, f.k, f.stride, f.pad, f.Ho, f.Wo)
+                wd.lddy, wd.dw = dy.ld, store.g_ptr(wname)
+                planes = max(1, (f.B * f.Ho * f.Wo + 2047) // 2048)
+                planes = (min(planes, 2048) + 3) // 4 * 4                   # == dyk_stem_wgrad_planes
+                part = new_ws(planes * f.Cout * 27 * 4)
+                later(lambda wd=wd, dy=dy, part=part: (setattr(wd, "dy", ptr_of(dy)), setattr(wd, "part", ws.ptr(part))))
+                plan.dyn_in.append((wd, [k_ for (d_, k_) in plan.dyn_in if d_ is f][0]))
+                plan.bwd.append((L.OP_STEM_WGRAD, wd))
+                return
             wg = rec["wgrad"]
             wd = L.DykWgradDesc()
             plan._keep.append(wd)
@@ -1027,6 +1089,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         for q in wg[len(wg) - ntail:] if ntail > 0 else []:
             plan.bwd_lanes[q] = plan.bwd_lanes.get(q, 0) | 8
 
+    plan.store = store
     plan.finalize()
     plan.info = info
     plan.grads = grads if training else {}
@@ -1070,10 +1133,12 @@ def _setup_wgrad_partials(plan, store, device, force_layers=()):
     plan.part = torch.empty(total, dtype=torch.float32, device=device)
     plan.part_bytes = total * 4
     base = plan.part.data_ptr()
+    plan._rw_extra, plan._part_extent = {}, {}
     for it in items.values():
         d = it["d"]
         if it.get("dw"):
             d.part = base + 4 * it["part_off"]
+            plan._part_extent[ctypes.addressof(d)] = 4 * it["splits"] * it["plane"]
         else:
             d.part, d.part_stride, d.splits = base + 4 * it["part_off"], it["plane"], it["splits"]
     target = sum(it["plane"] for it in items.values()) // 16
@@ -1090,6 +1155,10 @@ def _setup_wgrad_partials(plan, store, device, force_layers=()):
         m.p[0], m.p[1], m.p[2] = G0, base, tab.data_ptr()
         m.i[0], m.i[1] = len(entries), chunks
         plan._keep += [tab, m]
+        # read / write footprint for the dependency scheduler: the planes of its entries, their slices of G
+        plan._rw_extra[ctypes.addressof(m)] = (
+            [(base + 4 * it["part_off"], 4 * it["splits"] * it["plane"]) for it in entries],
+            [(G0 + 4 * it["g_off"], 4 * it["plane"]) for it in entries])
         return (L.OP_GRAD_REDUCE, m)
 
     starts = {}
@@ -1114,6 +1183,7 @@ def _setup_wgrad_partials(plan, store, device, force_layers=()):
     plan.bwd, plan.bwd_marks, plan.bwd_cut_ok = new, marks, cut_ok
 
 
+_TUNE_MS = {}        # problem key -> measured duration (ms) of the chosen configuration
 _TUNE_CACHE = {}     # process-wide: the same problem always runs the same tile configuration (bit-reproducible
                      # results across plans / model instances within a process)
 def _conv_candidates(d):
@@ -1195,8 +1265,11 @@ def autotune(plan, cache=None):
                 times.append(_time_launch(fn, d, stream))
             best = cands[times.index(min(times))]
             cache[key] = best
+            _TUNE_MS[key] = min(times)
         for d in descs:
             d.tune = best
+            if key in _TUNE_MS:
+                plan._cmd_us[ctypes.addressof(d)] = 1e3 * _TUNE_MS[key]      # measured duration: cost of the scheduler
     plan.tuned = dict(cache)
     # the trial launches polluted the statistics accumulators / scratch: reset
     plan.arenas["ws"].tensor.zero_()

@@ -445,6 +445,8 @@ enum {
     DYK_OP_CAST_PAD_ROWS = 29,  /* Misc: p0=src p1=dst i0=R i1=C i2=Cpad i3=dtype */
     DYK_OP_BN_FWD_FUSED = 30,   /* Misc: p0=DykBnFinalizeDesc* p1=DykEwDesc* -> dyk_bn_finalize_act_fwd */
     DYK_OP_GRAD_REDUCE = 31,    /* Misc: p0=G p1=part p2=table i0=n_entries i1=total_chunks -> dyk_grad_reduce */
+    DYK_OP_STEM_FWD = 32,       /* DykStemDesc -> dyk_stem_conv_fwd */
+    DYK_OP_STEM_WGRAD = 33,     /* DykStemDesc -> dyk_stem_conv_wgrad */
     DYK_OP_COUNT_
 };
 
@@ -583,6 +585,54 @@ typedef struct DykOptimDesc {
 } DykOptimDesc;
 int dyk_adam_step(const DykOptimDesc* desc, void* stream);
 int dyk_sgd_step(const DykOptimDesc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Stem convolution (Cin = 3, 3x3, pad 1, stride 1 | 2, Cout 16 | 32) straight from the image batch, no im2col.
+ * Replaces `imgs.float() / 255.0` (train_utils/kaist_train_eval_utils.py:54-55, evaluate.py:67-68) + nn.Conv2d(3, C, 3)
+ * of module_list[0] / module_list[second_index] (models.py:34-42) and that layer's weight gradient.
+ *   img  : [B][3][H][W] NCHW, float32 in 0..1, or uint8 (in_u8 != 0: each value is divided by 255.0f on the fly, the
+ *          same fp32 quotient the reference's `.float() / 255.0` produces)
+ *   fwd  : y[b, yo, xo, co] = sum_{ky,kx,c} img[b, c, yo*stride-1+ky, xo*stride-1+kx] * w[co][ky][kx][c]  (fp32 FMAs),
+ *          wt = the same weights transposed to [27][Cout] fp32; raw output + per-channel sum / sum of squares into a
+ *          `stats` replica (training), or act(y*scale + shift) when scale != NULL (eval: folded BatchNorm)
+ *   wgrad: dw[co][(ky*3+kx)*3 + c] += sum over pixels dy * img, on the fp32-input MFMA; `part` = workspace of
+ *          dyk_stem_wgrad_planes(desc) * Cout * 27 floats (per-wave partial tiles, folded in a fixed order)
+ * ---------------------------------------------------------------------------------- */
+typedef struct DykStemDesc {
+    const void* img;
+    const float* wt;       /* [27][Cout] (forward) */
+    void* y;               /* forward output, dtype, rows of ldy elements */
+    double* stats;         /* [stats_slots][2*Cout] or NULL */
+    const float* scale;    /* [Cout] or NULL */
+    const float* shift;    /* [Cout] or NULL */
+    const void* dy;        /* wgrad: gradient wrt y, dtype, rows of lddy elements */
+    float* dw;             /* wgrad: [Cout][27], accumulated */
+    float* part;           /* wgrad workspace */
+    int32_t dtype, in_u8;
+    int32_t B, H, W, Cout, k, stride, pad, Ho, Wo;
+    int32_t ldy, lddy, act, stats_slots;
+} DykStemDesc;
+int dyk_stem_conv_fwd(const DykStemDesc* desc, void* stream);
+int dyk_stem_conv_wgrad(const DykStemDesc* desc, void* stream);
+int dyk_stem_wgrad_planes(const DykStemDesc* desc);
+
+/* Dependency-scheduled execution on several HIP streams.  The plan compiler derives the read / write sets of every
+ * command from its descriptor, builds the dependency graph and list-schedules it onto n_streams in-order streams
+ * (dyk/sched.py); this entry point replays the result.  Entries are in ISSUE order.  Entry k launches command
+ * cmds[sched[k].cmd] on stream sched[k].stream (0 = the caller's `stream`, 1.. = library-owned streams) after making
+ * that stream wait for the completion events of the entries sched[k].wait[0..nwait) (positions < k, always on other
+ * streams), and records a completion event afterwards when `record` is set.  On entry every library stream waits for
+ * what the caller's stream holds so far; on return the caller's stream waits for all of them.  No host synchronisation.
+ * low_priority_last != 0: the last stream is created with the lowest priority (filler work such as weight gradients). */
+typedef struct DykSchedEntry {
+    int32_t cmd;
+    int16_t stream;
+    int8_t nwait;
+    int8_t record;
+    int32_t wait[7];
+} DykSchedEntry;
+int dyk_run_schedule(const DykCommand* cmds, const DykSchedEntry* sched, int32_t n_entries, int32_t n_streams,
+                     int32_t low_priority_last, void* stream, int32_t* failed_index);
 
 /* ------------------------------------------------------------------------------------
  * Box-coordinate helpers of the evaluation chain (build_utils/utils.py:40-92; callers evaluate.py:82,

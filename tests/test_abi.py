@@ -43,7 +43,7 @@ def test_null_descriptors_are_rejected_without_a_gpu():
 
 
 STRUCTS = ["DykConvDesc", "DykWgradDesc", "DykEwDesc", "DykBnFinalizeDesc", "DykSeFcDesc", "DykTransposeEntry",
-           "DykMiscDesc", "DykCommand", "DykDwDesc", "DykGradReduceEntry", "DykDecodeDesc", "DykTargetsDesc", "DykLossDesc", "DykNmsDesc", "DykOptimDesc"]
+           "DykMiscDesc", "DykCommand", "DykDwDesc", "DykGradReduceEntry", "DykDecodeDesc", "DykTargetsDesc", "DykLossDesc", "DykNmsDesc", "DykOptimDesc", "DykSchedEntry", "DykStemDesc"]
 
 
 def test_struct_layouts_match_the_c_compiler(tmp_path):

@@ -119,3 +119,33 @@ def test_two_rank_emulation_matches_sum_of_independent_ranks(nccl_world1):
     topt.step()
     a, b = m.engine.store.P, st.P
     assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("name,dtype", [(C3, "bf16"), (C5, "bf16"), (C3, "fp32")])
+def test_dependency_scheduled_streams_equal_serial_execution_bitwise(name, dtype, monkeypatch):
+    """the multi-stream dependency schedule (dyk/sched.py + dyk_run_schedule) must not change a single bit relative to
+    the same command lists enqueued in order on one stream: outputs, loss, every gradient, running statistics"""
+    from build_utils.utils import compute_loss
+    res = []
+    for mode in ("serial", "dag", "dag6"):
+        monkeypatch.setenv("DYK_OVERLAP", "0" if mode == "serial" else "1")
+        monkeypatch.setenv("DYK_STREAMS", "6" if mode == "dag6" else "4")
+        m = _model(name, dtype)
+        x, y, tg = _batch(5, B=4)
+        outs = []
+        for _ in range(2):                                   # second pass: re-armed statistics, accumulated gradients
+            pred = m(x, y)
+            ld = compute_loss(pred, tg, m)
+            (ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]).backward()
+            outs += [p.detach().clone() for p in pred] + [ld["box_loss"].detach().clone(), ld["obj_loss"].detach().clone()]
+        torch.cuda.synchronize()
+        if mode != "serial":
+            plan = next(iter(m.engine.plans.values()))
+            sc = plan.schedule("bwd", 0, len(plan.bwd))
+            assert len({e["stream"] for e in sc.entries}) >= 3
+        res.append((outs, m.engine.store.G.clone(), m.engine.store.R.clone()))
+    for other in res[1:]:
+        for a, b in zip(res[0][0], other[0]):
+            assert torch.equal(a, b)
+        assert torch.equal(res[0][1], other[1]), "gradients differ between serial and scheduled execution"
+        assert torch.equal(res[0][2], other[2]), "running statistics differ"

@@ -85,8 +85,9 @@ def test_plan_compiles_consistently(name, training):
     ops = [op for op, _ in plan.fwd]
     n_conv = sum(1 for d in m.module_defs if d["type"] == "convolutional")
     n_bn = sum(1 for d in m.module_defs if d["type"] == "convolutional" and d["batch_normalize"])
-    assert ops.count(L.OP_CONV) == n_conv
-    assert ops.count(L.OP_PATCH_GATHER) == (2 if "second_index" in m.net_info else 1)
+    n_stem = 2 if "second_index" in m.net_info else 1
+    assert ops.count(L.OP_CONV) == n_conv - n_stem          # the Cin=3 stems run in the direct kernel (csrc/stem.hip)
+    assert ops.count(L.OP_STEM_FWD) == n_stem and ops.count(L.OP_PATCH_GATHER) == 0
     assert len(plan.p_out) == 3 and [tuple(p.shape) for p in plan.p_out] == [
         (B, 3, H // s, W // s, 6) for s in ([32, 16, 8] if "yolov3" in name else [8, 16, 32])]
     if training:
@@ -94,7 +95,7 @@ def test_plan_compiles_consistently(name, training):
         assert ops[0] == L.OP_MEMSET
         bops = [op for op, _ in plan.bwd]
         assert bops[0] == L.OP_MEMSET
-        assert bops.count(L.OP_WGRAD) == n_conv
+        assert bops.count(L.OP_WGRAD) == n_conv - n_stem and bops.count(L.OP_STEM_WGRAD) == n_stem
         n_fused = sum(1 for op, d in plan.bwd if op == L.OP_CONV and d.flags & L.EPI_BNBWD and d.ooy == 0 and d.oox == 0)
         assert bops.count(L.OP_BN_BWD_APPLY) == n_bn and bops.count(L.OP_BN_BWD_REDUCE) + n_fused == n_bn and n_fused > 0
         assert bops.count(L.OP_BN_BWD_PARAMS) == 0
@@ -186,9 +187,11 @@ def test_mobilenet_plans_use_depthwise_and_padded_channel_rows(name):
     ops = [op for op, _ in plan.fwd]
     bops = [op for op, _ in plan.bwd]
     assert ops.count(L.OP_DW_FWD) == n_dw + n_sep
-    assert ops.count(L.OP_CONV) == n_dense + n_sep
+    n_stem = ops.count(L.OP_STEM_FWD)
+    assert n_stem == 2                                        # both 3x3 stride-2 stems run in the direct kernel
+    assert ops.count(L.OP_CONV) == n_dense + n_sep - n_stem
     assert bops.count(L.OP_DW_WGRAD) == bops.count(L.OP_DW_DGRAD) == n_dw + n_sep
-    assert bops.count(L.OP_WGRAD) == n_dense + n_sep
+    assert bops.count(L.OP_WGRAD) == n_dense + n_sep - n_stem and bops.count(L.OP_STEM_WGRAD) == n_stem
     for op, d in plan.fwd + plan.bwd:
         if op == L.OP_CONV:
             assert d.Cin % 32 == 0 and d.ldx >= d.Cin and d.ldy % 8 == 0
