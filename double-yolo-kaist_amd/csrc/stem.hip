@@ -30,20 +30,22 @@ template <bool U8> __device__ inline float load_px(const void* img, long idx) {
 
 // -------------------------------------------------------------------------------------------------- forward
 template <typename T, int COUT, bool U8>
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const DykStemDesc d) {
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const DykStemDesc d, const float* __restrict__ wt) {
+    // wt: [27][COUT] as a `const __restrict__` kernel argument -- uniform addresses of provably read-only memory become
+    // scalar loads (s_load_dwordx16 into SGPRs, one SGPR operand per FMA); read through the by-value descriptor they
+    // were 216 vector loads of one address per pixel and the kernel ran at 1.1 ms instead of ~0.1
     __shared__ float s_red[4][2 * COUT];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const long HoWo = (long)d.Ho * d.Wo, npix = (long)d.B * HoWo;
+    const int HoWo = d.Ho * d.Wo, npix = d.B * HoWo;
     const long plane = (long)d.H * d.W;
-    const float* __restrict__ wt = d.wt;                 // [27][COUT]: uniform addresses -> scalar loads
     const bool stats = d.stats != nullptr;
     const bool affine = d.scale != nullptr;
     float s1[COUT], s2[COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) s1[c] = s2[c] = 0.f;
-    for (long p = (long)blockIdx.x * 256 + tid; p < npix; p += (long)gridDim.x * 256) {
-        const int b = (int)(p / HoWo);
-        const int r = (int)(p - (long)b * HoWo);
+    for (int p = blockIdx.x * 256 + tid; p < npix; p += gridDim.x * 256) {
+        const int b = p / HoWo;
+        const int r = p - b * HoWo;
         const int yo = r / d.Wo, xo = r - yo * d.Wo;
         const int y0 = yo * d.stride - 1, x0 = xo * d.stride - 1;
         float x[27];
@@ -63,20 +65,32 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const DykStemDesc d) {
         float acc[COUT];
 #pragma unroll
         for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+        // the weights are re-read (scalar cache) for every pixel: hoisted out of the pixel loop all 27*COUT of them would
+        // live in SGPRs and spill into VGPR lanes (1600 v_readlane per pixel)
+        uintptr_t wa = (uintptr_t)wt;
+        asm volatile("" : "+s"(wa));
+        const __attribute__((address_space(4))) float* w = (const __attribute__((address_space(4))) float*)wa;   // constant address space: s_load
 #pragma unroll
         for (int t = 0; t < 27; ++t)
 #pragma unroll
-            for (int c = 0; c < COUT; ++c) acc[c] = fmaf(x[t], wt[t * COUT + c], acc[c]);
+            for (int c = 0; c < COUT; ++c) acc[c] = fmaf(x[t], w[t * COUT + c], acc[c]);
         if (stats) {
 #pragma unroll
             for (int c = 0; c < COUT; ++c) { s1[c] += acc[c]; s2[c] += acc[c] * acc[c]; }
         }
-        if (affine) {
-#pragma unroll
-            for (int c = 0; c < COUT; ++c) acc[c] = act_fwd(d.act, acc[c] * d.scale[c] + (d.shift ? d.shift[c] : 0.f));
+        if (affine) {                            // eval: folded BatchNorm + activation (one switch, not one per channel)
+            switch (d.act) {
+#define STEM_ACT_CASE(A) case A: _Pragma("unroll") for (int c = 0; c < COUT; ++c) acc[c] = act_fwd_c<A>(acc[c] * d.scale[c] + (d.shift ? d.shift[c] : 0.f), A); break;
+                STEM_ACT_CASE(DYK_ACT_LINEAR)
+                STEM_ACT_CASE(DYK_ACT_LEAKY)
+                STEM_ACT_CASE(DYK_ACT_MISH)
+#undef STEM_ACT_CASE
+            default:
+                for (int c = 0; c < COUT; ++c) acc[c] = act_fwd(d.act, acc[c] * d.scale[c] + (d.shift ? d.shift[c] : 0.f));
+            }
         }
         if (sizeof(T) == 2) {
-            bf16_t* yp = (bf16_t*)d.y + p * d.ldy;
+            bf16_t* yp = (bf16_t*)d.y + (long)p * d.ldy;
 #pragma unroll
             for (int c = 0; c < COUT; c += 8) {
                 uint4 pk;
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const DykStemDesc d) {
                 *(uint4*)(yp + c) = pk;
             }
         } else {
-            float* yp = (float*)d.y + p * d.ldy;
+            float* yp = (float*)d.y + (long)p * d.ldy;
 #pragma unroll
             for (int c = 0; c < COUT; c += 4) *(float4*)(yp + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
         }
@@ -117,7 +131,7 @@ template <typename T, int COUT, bool U8>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const DykStemDesc d, int pix_per_wave) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wave = blockIdx.x * 4 + wid;
-    const long HoWo = (long)d.Ho * d.Wo, npix = (long)d.B * HoWo;
+    const int HoWo = d.Ho * d.Wo, npix = d.B * HoWo;
     const long plane = (long)d.H * d.W;
     const int i = lane & 31, kk = lane >> 5;
     // B operand: which image element this lane fetches relative to the pixel
@@ -127,25 +141,31 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const DykStemDesc d, in
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const long p_begin = (long)wave * pix_per_wave;
-    long p_end = p_begin + pix_per_wave;
+    const int p_begin = wave * pix_per_wave;
+    int p_end = p_begin + pix_per_wave;
     if (p_end > npix) p_end = npix;
     const T* __restrict__ dy = (const T*)d.dy;
-#pragma unroll 4
-    for (long p0 = p_begin; p0 < p_end; p0 += 2) {
-        const long p = p0 + kk;
+    // this lane's pixel walks p_begin + kk, +2, +2, ...: coordinates are carried along (one division per wave, not per MFMA)
+    int p = p_begin + kk;
+    int b = p / HoWo, r0 = p - b * HoWo;
+    int yo = r0 / d.Wo, xo = r0 - yo * d.Wo;
+    const T* dyp = dy + (long)p * d.lddy + i;
+    const long dy_step = 2L * d.lddy;
+    for (int p0 = p_begin; p0 < p_end; p0 += 2, p += 2) {         // wave-uniform trip count: the MFMA needs all 64 lanes
         const bool live = p < p_end;
         float a = 0.f, bv = 0.f;
-        if (live) {
-            if (i < COUT) a = ElemTraits<T>::to_f32(dy[p * d.lddy + i]);
-            const int b = (int)(p / HoWo);
-            const int r = (int)(p - (long)b * HoWo);
-            const int yo = r / d.Wo, xo = r - yo * d.Wo;
-            const int yi = yo * d.stride - 1 + ky, xi = xo * d.stride - 1 + kx;
-            if (tc_ok && (unsigned)yi < (unsigned)d.H && (unsigned)xi < (unsigned)d.W)
-                bv = load_px<U8>(d.img, ((long)b * 3 + c) * plane + (long)yi * d.W + xi);
-        }
+        if (live && i < COUT) a = ElemTraits<T>::to_f32(*dyp);
+        const int yi = yo * d.stride - 1 + ky, xi = xo * d.stride - 1 + kx;
+        if (live && tc_ok && (unsigned)yi < (unsigned)d.H && (unsigned)xi < (unsigned)d.W)
+            bv = load_px<U8>(d.img, ((long)b * 3 + c) * plane + (long)yi * d.W + xi);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+        dyp += dy_step;
+        xo += 2;
+        if (xo >= d.Wo) {
+            xo -= d.Wo; ++yo;
+            if (xo >= d.Wo) { xo -= d.Wo; ++yo; }          // Wo == 1
+            if (yo >= d.Ho) { yo -= d.Ho; ++b; }
+        }
     }
     // C/D: col = lane & 31 (tc), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (co)
     float* out = d.part + (size_t)wave * COUT * 27;
@@ -175,6 +195,7 @@ int check(const DykStemDesc* d) {
     if (d->k != 3 || d->pad != 1 || (d->stride != 1 && d->stride != 2)) return DYK_ERR_UNSUPPORTED;
     if (d->Cout != 16 && d->Cout != 32) return DYK_ERR_UNSUPPORTED;
     if (d->dtype != DYK_BF16 && d->dtype != DYK_F32) return DYK_ERR_ARG;
+    if ((long)d->B * d->H * d->W * 3 >= (1L << 31)) return DYK_ERR_ARG;       // 32-bit pixel indices
     if (d->Ho != (d->H + 2 - 3) / d->stride + 1 || d->Wo != (d->W + 2 - 3) / d->stride + 1) return DYK_ERR_ARG;
     return DYK_OK;
 }
@@ -203,7 +224,7 @@ extern "C" int dyk_stem_conv_fwd(const DykStemDesc* d, void* stream) {
     // a fixed, bounded grid: every block folds its statistics once (2 * Cout atomics per block)
     if (blocks > 2048) blocks = 2048;
     const dim3 grid((unsigned)blocks);
-    STEM_DISPATCH(stem_fwd_kernel, grid, *d);
+    STEM_DISPATCH(stem_fwd_kernel, grid, *d, d->wt);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

@@ -191,10 +191,20 @@ class OracleNet:
             sd[pre + "num_batches_tracked"] += 1
         return y
 
-    def forward(self, sd, x, y=None, training=False, keep_all=False):
+    def forward(self, sd, x, y=None, training=False, keep_all=False, emulate_bf16=False):
         """Returns what reference YOLO.forward returns (models.py:307-315): training -> list of
         [B,na,ny,nx,no]; eval -> (cat(io,1), tuple(p)).  keep_all additionally returns every layer's
-        output tensor (for per-layer parity)."""
+        output tensor (for per-layer parity).
+
+        emulate_bf16 (eval only): the same arithmetic with the roundings of the bf16 MFMA path -- conv operands
+        (activations and weights) and every stored activation rounded to bfloat16, accumulation / BatchNorm affine /
+        activation / pooling in fp32, the Cin=3 stems and the detection heads' outputs in fp32 -- so that a bf16 run of
+        the HIP path can be held to a per-layer bound instead of a statistical one."""
+        if emulate_bf16:
+            assert not training
+            rnd = lambda t: t.bfloat16().float()                     # noqa: E731
+        else:
+            rnd = lambda t: t                                      # noqa: E731
         di = self.second_index is not None and y is not None
         yolo_out, out = [], []
         every = []
@@ -205,13 +215,18 @@ class OracleNet:
             if t == "convolutional":
                 if di and i == self.second_index:
                     x = y                                           # models.py:299-301 stream switch
-                x = F.conv2d(x, sd[pre + "Conv2d.weight"], sd.get(pre + "Conv2d.bias"), L["stride"], L["pad"], 1,
-                             L["groups"])
+                stem = i == 0 or (self.second_index is not None and i == self.second_index)
+                w = sd[pre + "Conv2d.weight"]
+                if L["groups"] == 1 and not stem:
+                    w = rnd(w)                                      # (stem and depthwise kernels read fp32 weights)
+                x = F.conv2d(x, w, sd.get(pre + "Conv2d.bias"), L["stride"], L["pad"], 1, L["groups"])
                 if keep_all:
                     self.raw[i] = x
                 if L["bn"]:
                     x = self._bn(sd, pre + "BatchNorm2d.", x, training)
                 x = _act(L["act"], x)
+                if L["bn"]:
+                    x = rnd(x)                                      # heads (no BN) stay fp32
             elif t == "depthwiseconvolutional":                     # layers.py:223-231: pad fixed at 1, ReLU6
                 x = F.conv2d(x, sd[pre + "conv.0.weight"], None, L["stride"], 1, 1, L["cin"])
                 x = F.relu6(self._bn(sd, pre + "conv.1.", x, training))
@@ -221,7 +236,7 @@ class OracleNet:
                 s = F.adaptive_avg_pool2d(x, 1)
                 s = F.relu(F.conv2d(s, sd[pre + "fc1.weight"], sd[pre + "fc1.bias"]))
                 s = F.hardsigmoid(F.conv2d(s, sd[pre + "fc2.weight"], sd[pre + "fc2.bias"]))
-                x = s * x
+                x = rnd(s * x)
             elif t == "maxpool":
                 x = F.max_pool2d(x, L["k"], L["stride"], L["pad"])
             elif t == "inception":
@@ -253,6 +268,7 @@ class OracleNet:
                         x = torch.cat((x[:, :na] + a, x[:, na:]), 1)
                     else:
                         x = x + a[:, :nx]
+                x = rnd(x)
             elif t == "yolo":
                 yolo_out.append(self._yolo(L, x, training))
             elif t == "dropout":

@@ -124,8 +124,19 @@ def main():
         torch.manual_seed(0)
         m = ref_models.YOLO(cfg, (EVAL_H, EVAL_W))
         m.load_state_dict(sd)
-        m.eval()
         v8, l8 = eval_images()
+        # calibrate the BatchNorm running statistics on the batch (momentum 1: running = batch statistics), as a trained
+        # network's would be: with random running statistics the activations grow by 1e5 through the 100+ layers and
+        # every rounding difference is amplified with them.  The calibrated statistics are stored in the fixture.
+        m.train()
+        bns = [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d)]
+        for mod in bns:
+            mod.momentum = 1.0
+        with torch.no_grad():
+            m(v8.float() / 255.0, l8.float() / 255.0)
+        m.eval()
+        calib = {k: v.clone() for k, v in m.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+        sd.update(calib)
         # random weights saturate the heads (every score 0 or 1): rescale the three head convs so that the logits have
         # a standard deviation of 1.5 around their bias (the factors are stored; tests apply them to synth_state(3))
         with torch.no_grad():
@@ -171,6 +182,8 @@ def main():
         rec = {"head_scale": np.array(head_scale, dtype=np.float64), "conf": np.float64(conf), "io": pred.numpy().astype(np.float32), "ap": np.float64(res["ap"]), "lamr": np.float64(res["lamr"]),
                "recall": np.asarray(res["recall"]), "precision": np.asarray(res["precision"]),
                "shapes": np.array(shapes, dtype=np.int64), "ndet": np.array([d.shape[0] for d in per_image])}
+        for k, v in calib.items():
+            rec["bn|" + k] = v.numpy()
         for idx in range(EVAL_B):
             rec["det%d" % idx] = per_image[idx]
             rec["labels%d" % idx] = labels[idx]

@@ -16,6 +16,7 @@ sys.path.insert(0, GOLDEN)
 import cases  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+STEP23_RTOL = 0.35          # steps 2-3 of the three-Adam-step fixture (set from the measured deviation, see the test)
 
 
 def _inputs():
@@ -85,9 +86,9 @@ def test_gradients_against_fp64_oracle_with_fp32_yardstick(name):
     itself deviates from an fp64 evaluation of the same net by 6 % (target cfg), 23 % (MobileNetV3), 1.5 % (Inception
     cfg) per tensor.  A wrong gradient would be O(100 %) off, so the yardstick is torch-fp32's own distance to fp64:
     the HIP fp32 path must stay within 4x of it in aggregate (measured 1.3-2.4x: the fp32 MFMA accumulates its K
-    dimension sequentially where the CPU kernels block their sums, and the fp32 atomics of the weight-gradient kernels
-    change the rounding from run to run), with at most 10 % of the tensors beyond 6x and every tensor norm within the
-    same multiple.  fp64 / fp32 oracle gradients: fixture tests/golden/grad64_*.npz (tests/golden/make_grad64.py),
+    dimension sequentially where the CPU kernels block their sums; the path itself is bit-reproducible from run to run
+    since the weight gradients go through per-split planes), with at most 10 % of the tensors beyond 6x and every
+    tensor norm within the same multiple.  fp64 / fp32 oracle gradients: fixture tests/golden/grad64_*.npz (tests/golden/make_grad64.py),
     64 sampled entries per tensor + norms."""
     sys.path.insert(0, GOLDEN)
     from make_grad64 import sample_index
@@ -139,10 +140,11 @@ def test_three_adam_steps_match_reference_losses():
     assert np.allclose(losses[0], gold["losses"][0], rtol=5e-4)
     # Steps 2 and 3 see parameters after Adam updates: Adam's first steps move every weight by ~lr*sign(g), so
     # elements whose gradient is at rounding-noise level (see the fp64 test above) flip between runs -- the
-    # reference itself is not reproducible beyond this level across fp32 summation orders.  The fp32 atomics of the
-    # weight-gradient kernel make this path's own summation order vary run to run too: observed spread of the step-2
-    # objectness loss 15.3 .. 18.0 around the reference's 15.26.
-    assert np.allclose(losses[1:, :2], gold["losses"][1:, :2], rtol=0.35), (losses, gold["losses"])
+    # reference itself is not reproducible beyond this level across fp32 summation orders (this path is: planes instead
+    # of atomics, see test_baseline_size_train_step_is_bit_reproducible).  The bound is the measured deviation with margin.
+    print("three Adam steps: losses", losses.tolist(), "reference", gold["losses"].tolist(),
+          "relative deviation", (np.abs(losses - gold["losses"]) / np.maximum(np.abs(gold["losses"]), 1e-9)).tolist())
+    assert np.allclose(losses[1:, :2], gold["losses"][1:, :2], rtol=STEP23_RTOL), (losses, gold["losses"])
     sd = m.state_dict()
     probes = np.array([[sd[k].double().sum().item(), sd[k].double().abs().sum().item()] for k in cases.step_probe_names()])
     assert np.allclose(probes[:, 1], gold["probes"][:, 1], rtol=5e-3)
