@@ -191,7 +191,7 @@ class OracleNet:
             sd[pre + "num_batches_tracked"] += 1
         return y
 
-    def forward(self, sd, x, y=None, training=False, keep_all=False, emulate_bf16=False):
+    def forward(self, sd, x, y=None, training=False, keep_all=False, emulate_bf16=False, force=None):
         """Returns what reference YOLO.forward returns (models.py:307-315): training -> list of
         [B,na,ny,nx,no]; eval -> (cat(io,1), tuple(p)).  keep_all additionally returns every layer's
         output tensor (for per-layer parity).
@@ -199,7 +199,10 @@ class OracleNet:
         emulate_bf16 (eval only): the same arithmetic with the roundings of the bf16 MFMA path -- conv operands
         (activations and weights) and every stored activation rounded to bfloat16, accumulation / BatchNorm affine /
         activation / pooling in fp32, the Cin=3 stems and the detection heads' outputs in fp32 -- so that a bf16 run of
-        the HIP path can be held to a per-layer bound instead of a statistical one."""
+        the HIP path can be held to a per-layer bound instead of a statistical one.
+        force: {section index: tensor}: after section i has been evaluated (and recorded in `every`), its output is
+        REPLACED by force[i] for everything downstream -- with the tensors of another implementation this measures every
+        section's own error on identical inputs (no accumulation through the depth of the net)."""
         if emulate_bf16:
             assert not training
             rnd = lambda t: t.bfloat16().float()                     # noqa: E731
@@ -273,9 +276,11 @@ class OracleNet:
                 yolo_out.append(self._yolo(L, x, training))
             elif t == "dropout":
                 x = F.dropout(x, L["p"], training)
-            out.append(x if self.routs[i] else None)
             if keep_all:
                 every.append(x)
+            if force is not None and i in force:
+                x = force[i]
+            out.append(x if self.routs[i] else None)
         if training:
             res = yolo_out
         else:
