@@ -16,7 +16,7 @@ sys.path.insert(0, GOLDEN)
 import cases  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-STEP23_RTOL = 0.35          # steps 2-3 of the three-Adam-step fixture (set from the measured deviation, see the test)
+STEP23_RTOL = 0.15          # steps 2-3 of the three-Adam-step fixture: measured 0.7 % / 1.8 % (box) and 10.8 % / 11.2 % (obj), deterministic
 
 
 def _inputs():
