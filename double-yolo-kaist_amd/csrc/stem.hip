@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const DykStemDesc d, cons
 #pragma unroll
         for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
         // the weights are re-read (scalar cache) for every pixel: hoisted out of the pixel loop all 27*COUT of them would
-        // live in SGPRs and spill into VGPR lanes (1600 v_readlane per pixel)
+        // live in SGPRs and spill into VGPR lanes (1600 v_readlane per pixel).  (Two pixels per thread and weight fetch
+        // were tried: the second patch spills to scratch and the kernel runs 17x slower.)
         uintptr_t wa = (uintptr_t)wt;
         asm volatile("" : "+s"(wa));
         const __attribute__((address_space(4))) float* w = (const __attribute__((address_space(4))) float*)wa;   // constant address space: s_load
@@ -124,51 +125,93 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const DykStemDesc d, cons
 }
 
 // -------------------------------------------------------------------------------------------------- weight gradient
-// One wave = one 32 x 32 fp32 accumulator tile D[co][tc] (16 registers per lane) over its own pixel range.
 // v_mfma_f32_32x32x2_f32: A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]; here i = output channel,
-// j = patch element tc = (ky*3 + kx)*3 + c (27 used), k = pixel (two per instruction).
+// j = patch element tc = (ky*3 + kx)*3 + c (27 used), k = pixel (two per instruction), D[co][tc] 16 registers per lane.
+// ONE WAVE per workgroup walks segments of SEG output pixels of one row: the dy segment (SEG x 32 channels, coalesced
+// 16-byte loads, one batch = one memory round trip) and the 3 rows x 3 channels of image under it (fp32, converted
+// once, zero padded) are staged in its private LDS slice, the MFMA operands are single LDS reads per lane.  Many small
+// independent workgroups (12 per CU) hide the staging latency of one behind the MFMAs of the others; operands gathered
+// straight from global memory cost an L1 transaction per distinct line (27 per instruction on the image side: 370 us
+// per launch), and a 256-thread workgroup staging whole rows behind barriers was latency bound as well (380-480 us).
+constexpr int STEM_SEG = 128;
+
 template <typename T, int COUT, bool U8>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const DykStemDesc d, int pix_per_wave) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wave = blockIdx.x * 4 + wid;
-    const int HoWo = d.Ho * d.Wo, npix = d.B * HoWo;
-    const long plane = (long)d.H * d.W;
+__global__ __launch_bounds__(64) void stem_wgrad_kernel(const DykStemDesc d, int segs_per_wg, int segs_per_row, int nsegs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const int Wseg = STEM_SEG * d.stride + 2;                     // image columns under a segment (+ halo)
+    T* s_dy = (T*)smem;                                           // [SEG][32]
+    float* s_img = (float*)(smem + STEM_SEG * 32 * sizeof(T));    // [3 ky][3 c][Wseg]
     const int i = lane & 31, kk = lane >> 5;
-    // B operand: which image element this lane fetches relative to the pixel
     const int tc = i;
     const int c = tc % 3, kx = (tc / 3) % 3, ky = tc / 9;
     const bool tc_ok = tc < 27;
+    const long plane = (long)d.H * d.W;
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int p_begin = wave * pix_per_wave;
-    int p_end = p_begin + pix_per_wave;
-    if (p_end > npix) p_end = npix;
-    const T* __restrict__ dy = (const T*)d.dy;
-    // this lane's pixel walks p_begin + kk, +2, +2, ...: coordinates are carried along (one division per wave, not per MFMA)
-    int p = p_begin + kk;
-    int b = p / HoWo, r0 = p - b * HoWo;
-    int yo = r0 / d.Wo, xo = r0 - yo * d.Wo;
-    const T* dyp = dy + (long)p * d.lddy + i;
-    const long dy_step = 2L * d.lddy;
-    for (int p0 = p_begin; p0 < p_end; p0 += 2, p += 2) {         // wave-uniform trip count: the MFMA needs all 64 lanes
-        const bool live = p < p_end;
-        float a = 0.f, bv = 0.f;
-        if (live && i < COUT) a = ElemTraits<T>::to_f32(*dyp);
-        const int yi = yo * d.stride - 1 + ky, xi = xo * d.stride - 1 + kx;
-        if (live && tc_ok && (unsigned)yi < (unsigned)d.H && (unsigned)xi < (unsigned)d.W)
-            bv = load_px<U8>(d.img, ((long)b * 3 + c) * plane + (long)yi * d.W + xi);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
-        dyp += dy_step;
-        xo += 2;
-        if (xo >= d.Wo) {
-            xo -= d.Wo; ++yo;
-            if (xo >= d.Wo) { xo -= d.Wo; ++yo; }          // Wo == 1
-            if (yo >= d.Ho) { yo -= d.Ho; ++b; }
+    const float* s_b = s_img + (ky * 3 + c) * Wseg + kx;          // + (pixel in segment) * stride
+    constexpr int VEC = 16 / (int)sizeof(T);                     // dy elements per 16-byte load
+    constexpr int NV = STEM_SEG * 32 / VEC / 64;                  // 16-byte loads per lane per segment (8 | 16)
+    const int nimg = 9 * Wseg;
+    const int seg0 = blockIdx.x * segs_per_wg;
+    for (int sg = seg0; sg < seg0 + segs_per_wg && sg < nsegs; ++sg) {
+        const int row = sg / segs_per_row, x_begin = (sg - row * segs_per_row) * STEM_SEG;
+        const int b = row / d.Ho, yo = row - b * d.Ho;
+        const int npx = min(STEM_SEG, d.Wo - x_begin);
+        __syncthreads();                                          // previous segment consumed (one wave: a cheap barrier)
+        // ---- dy segment (clamped index, unconditional load, select: one batch = one memory round trip)
+        const T* dyseg = (const T*)d.dy + ((long)row * d.Wo + x_begin) * d.lddy;
+        if (d.lddy == 32) {
+            const int nvec = npx * 32 / VEC;
+            uint4 t[NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) { const int v = lane + u * 64; t[u] = ((const uint4*)dyseg)[v < nvec ? v : 0]; }
+#pragma unroll
+            for (int u = 0; u < NV; ++u) { const int v = lane + u * 64; if (v < nvec) ((uint4*)s_dy)[v] = t[u]; }
+        } else {
+            for (int e = lane; e < npx * 32; e += 64) {
+                const int px = e >> 5, ch = e & 31;
+                s_dy[e] = ch < d.lddy ? dyseg[(long)px * d.lddy + ch] : (T)0;
+            }
+        }
+        // ---- image: 3 rows x 3 channels x Wseg columns starting at x_begin*stride - 1
+        const int xi0 = x_begin * d.stride - 1;
+        for (int e0 = lane; e0 < nimg; e0 += 64 * 8) {
+            float t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 64;
+                const int ec = e < nimg ? e : 0;
+                const int rc = ec / Wseg, xp = ec - rc * Wseg;
+                const int kyy = rc / 3, cc = rc - kyy * 3;
+                const int yi = yo * d.stride - 1 + kyy, xi = xi0 + xp;
+                const bool in = (unsigned)yi < (unsigned)d.H && (unsigned)xi < (unsigned)d.W;
+                const float v = load_px<U8>(d.img, in ? ((long)b * 3 + cc) * plane + (long)yi * d.W + xi : 0L);
+                t8[u] = in ? v : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + u * 64; if (e < nimg) s_img[e] = t8[u]; }
+        }
+        __syncthreads();
+        // ---- MFMAs: pixel pairs, four pairs per trip (their LDS reads are in flight together)
+        for (int x0 = 0; x0 < npx; x0 += 8) {
+            float a[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int xo = x0 + u * 2 + kk;
+                const bool live = xo < npx;
+                const float av = ElemTraits<T>::to_f32(s_dy[(live ? xo : 0) * 32 + i]);
+                const float xv = s_b[(live ? xo : 0) * d.stride];
+                a[u] = (live && i < COUT) ? av : 0.f;
+                bv[u] = (live && tc_ok) ? xv : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u], acc, 0, 0, 0);
         }
     }
     // C/D: col = lane & 31 (tc), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (co)
-    float* out = d.part + (size_t)wave * COUT * 27;
+    float* out = d.part + (size_t)blockIdx.x * COUT * 27;
     if (tc_ok) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -178,16 +221,24 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const DykStemDesc d, in
     }
 }
 
-// dw[e] += sum over planes, fixed order: 8 lanes per element, 8 strided partial sums folded by xor shuffles
+// dw[e] += sum over planes, fixed order: one wave per element, lane l takes planes l, l + 64, ... (eight independent
+// loads in flight per lane), then a fixed xor-shuffle tree.  (With 8 lanes per element every lane walked hundreds of
+// planes through dependent loads: 250-500 us, several times the MFMA kernel it follows.)
 __global__ __launch_bounds__(256) void stem_wgrad_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int planes) {
-    const int g = (blockIdx.x * 256 + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+    const int g = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     float s = 0.f;
-    if (g < n)
-        for (int q = sub; q < planes; q += 8) s += part[(size_t)q * n + g];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (g < n && sub == 0) dw[g] += s;
+    if (g < n) {
+        for (int q0 = lane; q0 < planes; q0 += 64 * 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int q = q0 + u * 64; t[u] = part[(size_t)(q < planes ? q : 0) * n + g]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int q = q0 + u * 64; s += q < planes ? t[u] : 0.f; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (g < n && lane == 0) dw[g] += s;
 }
 
 int check(const DykStemDesc* d) {
@@ -202,15 +253,31 @@ int check(const DykStemDesc* d) {
 
 }  // namespace
 
-#define STEM_DISPATCH(KERNEL, grid, ...)                                                                             \
+template <typename K> static inline void stem_allow_lds(K kfn, size_t bytes) {
+    if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+#define STEM_DISPATCH(KERNEL, grid, ...) STEM_DISPATCH_LDS(KERNEL, grid, 0, __VA_ARGS__)
+#define STEM_DISPATCH_LDS(KERNEL, grid, LDSB, ...)                                                                   \
     do {                                                                                                              \
         const bool u8 = d->in_u8 != 0;                                                                                \
         if (d->dtype == DYK_BF16) {                                                                                   \
-            if (d->Cout == 32) { if (u8) hipLaunchKernelGGL((KERNEL<bf16_t, 32, true>), grid, dim3(256), 0, s, __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<bf16_t, 32, false>), grid, dim3(256), 0, s, __VA_ARGS__); } \
-            else               { if (u8) hipLaunchKernelGGL((KERNEL<bf16_t, 16, true>), grid, dim3(256), 0, s, __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<bf16_t, 16, false>), grid, dim3(256), 0, s, __VA_ARGS__); } \
+            if (d->Cout == 32) { if (u8) { stem_allow_lds(KERNEL<bf16_t, 32, true>, LDSB); hipLaunchKernelGGL((KERNEL<bf16_t, 32, true>), grid, dim3(256), LDSB, s, __VA_ARGS__); } else { stem_allow_lds(KERNEL<bf16_t, 32, false>, LDSB); hipLaunchKernelGGL((KERNEL<bf16_t, 32, false>), grid, dim3(256), LDSB, s, __VA_ARGS__); }; } \
+            else               { if (u8) { stem_allow_lds(KERNEL<bf16_t, 16, true>, LDSB); hipLaunchKernelGGL((KERNEL<bf16_t, 16, true>), grid, dim3(256), LDSB, s, __VA_ARGS__); } else { stem_allow_lds(KERNEL<bf16_t, 16, false>, LDSB); hipLaunchKernelGGL((KERNEL<bf16_t, 16, false>), grid, dim3(256), LDSB, s, __VA_ARGS__); }; } \
         } else {                                                                                                      \
-            if (d->Cout == 32) { if (u8) hipLaunchKernelGGL((KERNEL<float, 32, true>), grid, dim3(256), 0, s, __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<float, 32, false>), grid, dim3(256), 0, s, __VA_ARGS__); }   \
-            else               { if (u8) hipLaunchKernelGGL((KERNEL<float, 16, true>), grid, dim3(256), 0, s, __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<float, 16, false>), grid, dim3(256), 0, s, __VA_ARGS__); }   \
+            if (d->Cout == 32) { if (u8) { stem_allow_lds(KERNEL<float, 32, true>, LDSB); hipLaunchKernelGGL((KERNEL<float, 32, true>), grid, dim3(256), LDSB, s, __VA_ARGS__); } else { stem_allow_lds(KERNEL<float, 32, false>, LDSB); hipLaunchKernelGGL((KERNEL<float, 32, false>), grid, dim3(256), LDSB, s, __VA_ARGS__); }; }   \
+            else               { if (u8) { stem_allow_lds(KERNEL<float, 16, true>, LDSB); hipLaunchKernelGGL((KERNEL<float, 16, true>), grid, dim3(256), LDSB, s, __VA_ARGS__); } else { stem_allow_lds(KERNEL<float, 16, false>, LDSB); hipLaunchKernelGGL((KERNEL<float, 16, false>), grid, dim3(256), LDSB, s, __VA_ARGS__); }; }   \
+        }                                                                                                             \
+    } while (0)
+
+#define STEM_DISPATCH_W(KERNEL, grid, LDSB, ...)                                                                     \
+    do {                                                                                                              \
+        const bool u8 = d->in_u8 != 0;                                                                                \
+        if (d->dtype == DYK_BF16) {                                                                                   \
+            if (d->Cout == 32) { if (u8) hipLaunchKernelGGL((KERNEL<bf16_t, 32, true>), grid, dim3(64), LDSB, s, __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<bf16_t, 32, false>), grid, dim3(64), LDSB, s, __VA_ARGS__); } \
+            else               { if (u8) hipLaunchKernelGGL((KERNEL<bf16_t, 16, true>), grid, dim3(64), LDSB, s, __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<bf16_t, 16, false>), grid, dim3(64), LDSB, s, __VA_ARGS__); } \
+        } else {                                                                                                      \
+            if (d->Cout == 32) { if (u8) hipLaunchKernelGGL((KERNEL<float, 32, true>), grid, dim3(64), LDSB, s, __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<float, 32, false>), grid, dim3(64), LDSB, s, __VA_ARGS__); }   \
+            else               { if (u8) hipLaunchKernelGGL((KERNEL<float, 16, true>), grid, dim3(64), LDSB, s, __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<float, 16, false>), grid, dim3(64), LDSB, s, __VA_ARGS__); }   \
         }                                                                                                             \
     } while (0)
 
@@ -229,14 +296,13 @@ extern "C" int dyk_stem_conv_fwd(const DykStemDesc* d, void* stream) {
     return DYK_OK;
 }
 
-// number of partial planes (= waves) of the weight-gradient launch: the workspace `part` holds that many [Cout][27] tiles
+// number of partial planes (= one-wave workgroups) of the weight-gradient launch: `part` holds that many [Cout][27] tiles
 extern "C" int dyk_stem_wgrad_planes(const DykStemDesc* d) {
     if (check(d)) return 0;
-    const long npix = (long)d->B * d->Ho * d->Wo;
-    long waves = (npix + 2047) / 2048;               // >= 2048 pixels (1024 MFMAs) per wave
-    if (waves > 2048) waves = 2048;
-    waves = (waves + 3) / 4 * 4;
-    return (int)waves;
+    const long nsegs = (long)d->B * d->Ho * ((d->Wo + STEM_SEG - 1) / STEM_SEG);
+    long spw = (nsegs + 4095) / 4096;                // <= 4096 workgroups
+    if (spw < 1) spw = 1;
+    return (int)((nsegs + spw - 1) / spw);
 }
 
 extern "C" int dyk_stem_conv_wgrad(const DykStemDesc* d, void* stream) {
@@ -245,14 +311,18 @@ extern "C" int dyk_stem_conv_wgrad(const DykStemDesc* d, void* stream) {
     if (!d->dy || !d->dw || !d->part || d->lddy < d->Cout) return DYK_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long npix = (long)d->B * d->Ho * d->Wo;
-    const int waves = dyk_stem_wgrad_planes(d);
-    long ppw = (npix + waves - 1) / waves;
-    ppw = (ppw + 1) / 2 * 2;
-    const dim3 grid((unsigned)(waves / 4));
-    STEM_DISPATCH(stem_wgrad_kernel, grid, *d, (int)ppw);
+    const int planes = dyk_stem_wgrad_planes(d);
+    const int segs_per_row = (d->Wo + STEM_SEG - 1) / STEM_SEG;
+    const long nsegs = (long)d->B * d->Ho * segs_per_row;
+    const int spw = (int)((nsegs + planes - 1) / planes);
+    const dim3 grid((unsigned)planes);
+    const size_t es = d->dtype == DYK_BF16 ? 2 : 4;
+    const size_t lds = (size_t)STEM_SEG * 32 * es + (size_t)9 * (STEM_SEG * d->stride + 2) * 4;
+    (void)npix;
+    STEM_DISPATCH_W(stem_wgrad_kernel, grid, lds, *d, spw, segs_per_row, (int)nsegs);
     DYK_LAUNCH_CHECK();
     const int n = d->Cout * 27;
-    hipLaunchKernelGGL(stem_wgrad_fold_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, s, (const float*)d->part, d->dw, n, waves);
+    hipLaunchKernelGGL(stem_wgrad_fold_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, s, (const float*)d->part, d->dw, n, planes);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

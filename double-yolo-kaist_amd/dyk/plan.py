@@ -747,8 +747,9 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 wd.dtype, wd.B, wd.H, wd.W, wd.Cout, wd.k, wd.stride, wd.pad, wd.Ho, wd.Wo = (
                     code, f.B, f.H, f.W, f.Cout, f.k, f.stride, f.pad, f.Ho, f.Wo)
                 wd.lddy, wd.dw = dy.ld, store.g_ptr(wname)
-                planes = max(1, (f.B * f.Ho * f.Wo + 2047) // 2048)
-                planes = (min(planes, 2048) + 3) // 4 * 4                   # == dyk_stem_wgrad_planes
+                nsegs = f.B * f.Ho * ((f.Wo + 127) // 128)
+                spw = max(1, (nsegs + 4095) // 4096)
+                planes = (nsegs + spw - 1) // spw                            # == dyk_stem_wgrad_planes
                 part = new_ws(planes * f.Cout * 27 * 4)
                 later(lambda wd=wd, dy=dy, part=part: (setattr(wd, "dy", ptr_of(dy)), setattr(wd, "part", ws.ptr(part))))
                 plan.dyn_in.append((wd, [k_ for (d_, k_) in plan.dyn_in if d_ is f][0]))

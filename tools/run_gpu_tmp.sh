@@ -1,4 +1,4 @@
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-mkdir -p gpurun_out
-python -m pytest tests/test_eval_ap.py tests/test_gpu_model.py -m gpu -q -s -k "eval_chain or layer_by_layer or three_adam" 2>&1 | grep -E "AP 0|bf16|three Adam|passed|failed|FAILED|Error|section" | cut -c1-900 > gpurun_out/pytest_sel.log
-cat gpurun_out/pytest_sel.log
+rm -rf gpurun_out/sp; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sp -o sp -- python tools/stem_probe.py > /dev/null 2>&1
+cat $(ls gpurun_out/sp/sp_kernel_stats.csv gpurun_out/sp/*/sp_kernel_stats.csv 2>/dev/null | head -1) | cut -c1-160 | head -8
+rm -rf gpurun_out/sp
