@@ -3,7 +3,7 @@
 # Outputs under gpurun_out/ (copy what should be judged into profiles/).
 set -x
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/pytest_gpu.log
+python -m pytest tests -m gpu -q 2>&1 | grep -vE "RCCL version|HIP version|ROCm version|Hostname|Librccl path|amdgpu.ids" | tail -60 > gpurun_out/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err
 tail -c 3000 gpurun_out/bench.json
