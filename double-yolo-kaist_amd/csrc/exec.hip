@@ -1,4 +1,5 @@
 // Native command-list executor, parameter staging kernels and the YOLO box decode.
+#include <stdio.h>
 #include <stdlib.h>
 #include "dyk_common.h"
 
@@ -305,68 +306,191 @@ extern "C" int dyk_run_commands_overlap(const DykCommand* cmds, int32_t n, void*
     return DYK_OK;
 }
 
-extern "C" int dyk_run_schedule(const DykCommand* cmds, const DykSchedEntry* sched, int32_t n, int32_t n_streams,
-                                int32_t low_priority_last, void* stream, int32_t* failed_index) {
-    if (!cmds || !sched || n < 0 || n_streams < 1 || n_streams > 8) return DYK_ERR_ARG;
-    static hipStream_t aux[2][8] = {};            // [low_priority_last][index]: created on first use
-    static hipEvent_t* events = nullptr;          // one completion event per schedule position, grown on demand
-    static int n_events = 0;
-    static hipEvent_t ev_start = nullptr, ev_join[8] = {};
-    if (!ev_start) {
-        if (hipEventCreateWithFlags(&ev_start, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
-        for (auto& e : ev_join)
+namespace {
+// Replays an issue-ordered schedule: shared by the direct path (dyk_run_schedule) and by stream capture into a hipGraph
+// (dyk_schedule_graph_create).  The event pools are per use (direct / capture): an event recorded inside a capture
+// belongs to that capture.
+struct SchedRuntime {
+    hipStream_t aux[2][8] = {};
+    hipEvent_t* events = nullptr;
+    int n_events = 0;
+    hipEvent_t ev_start = nullptr, ev_join[8] = {};
+};
+
+// streams and events of a runtime, created up front (never inside a stream capture)
+int sched_prepare(SchedRuntime& rt, int32_t n, int32_t n_streams, int32_t low_priority_last) {
+    if (!rt.ev_start) {
+        if (hipEventCreateWithFlags(&rt.ev_start, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
+        for (auto& e : rt.ev_join)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
     }
-    if (n > n_events) {
-        hipEvent_t* grown = (hipEvent_t*)realloc(events, sizeof(hipEvent_t) * (size_t)n);
+    if (n > rt.n_events) {
+        hipEvent_t* grown = (hipEvent_t*)realloc(rt.events, sizeof(hipEvent_t) * (size_t)n);
         if (!grown) return DYK_ERR_HIP;
-        events = grown;
-        for (int i = n_events; i < n; ++i)
-            if (hipEventCreateWithFlags(&events[i], hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
-        n_events = n;
+        rt.events = grown;
+        for (int i = rt.n_events; i < n; ++i)
+            if (hipEventCreateWithFlags(&rt.events[i], hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
+        rt.n_events = n;
     }
     const int lp = low_priority_last ? 1 : 0;
-    hipStream_t main_s = (hipStream_t)stream;
+    for (int s = 1; s < n_streams; ++s)
+        if (!rt.aux[lp][s]) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            const int prio = (lp && s == n_streams - 1) ? lo : 0;
+            if (hipStreamCreateWithPriority(&rt.aux[lp][s], hipStreamNonBlocking, prio) != hipSuccess) return DYK_ERR_HIP;
+        }
+    return DYK_OK;
+}
+
+int sched_replay(SchedRuntime& rt, const DykCommand* cmds, const DykSchedEntry* sched, int32_t n, int32_t n_streams,
+                 int32_t low_priority_last, hipStream_t main_s, int32_t* failed_index) {
+    if (sched_prepare(rt, n, n_streams, low_priority_last) != DYK_OK) return DYK_ERR_HIP;
+    if (!rt.ev_start) {
+        if (hipEventCreateWithFlags(&rt.ev_start, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
+        for (auto& e : rt.ev_join)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
+    }
+    if (n > rt.n_events) {
+        hipEvent_t* grown = (hipEvent_t*)realloc(rt.events, sizeof(hipEvent_t) * (size_t)n);
+        if (!grown) return DYK_ERR_HIP;
+        rt.events = grown;
+        for (int i = rt.n_events; i < n; ++i)
+            if (hipEventCreateWithFlags(&rt.events[i], hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
+        rt.n_events = n;
+    }
+    const int lp = low_priority_last ? 1 : 0;
     bool used[8] = {};
     auto stream_of = [&](int s) -> hipStream_t {
         if (s == 0) return main_s;
-        if (!aux[lp][s]) {
+        if (!rt.aux[lp][s]) {
             int lo = 0, hi = 0;
-            hipDeviceGetStreamPriorityRange(&lo, &hi);
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
             const int prio = (lp && s == n_streams - 1) ? lo : 0;
-            if (hipStreamCreateWithPriority(&aux[lp][s], hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
+            if (hipStreamCreateWithPriority(&rt.aux[lp][s], hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
         }
-        return aux[lp][s];
+        return rt.aux[lp][s];
     };
-    if (n_streams > 1 && hipEventRecord(ev_start, main_s) != hipSuccess) return DYK_ERR_HIP;
+    if (n_streams > 1 && hipEventRecord(rt.ev_start, main_s) != hipSuccess) return DYK_ERR_HIP;
     for (int32_t k = 0; k < n; ++k) {
         const DykSchedEntry& e = sched[k];
         if (e.stream < 0 || e.stream >= n_streams || e.nwait < 0 || e.nwait > 7) return DYK_ERR_ARG;
         hipStream_t s = stream_of(e.stream);
         if (!s && e.stream) return DYK_ERR_HIP;
         if (e.stream && !used[e.stream]) {
-            if (hipStreamWaitEvent(s, ev_start, 0) != hipSuccess) return DYK_ERR_HIP;
+            if (hipStreamWaitEvent(s, rt.ev_start, 0) != hipSuccess) return DYK_ERR_HIP;
             used[e.stream] = true;
         }
+        static const int dbg_nowait = getenv("DYK_DBG_NOWAIT_K") ? atoi(getenv("DYK_DBG_NOWAIT_K")) : -1;
+        static const int dbg_nocmd = getenv("DYK_DBG_NOCMD_K") ? atoi(getenv("DYK_DBG_NOCMD_K")) : -1;
         for (int q = 0; q < e.nwait; ++q) {
             const int32_t w = e.wait[q];
             if (w < 0 || w >= k) return DYK_ERR_ARG;
-            if (hipStreamWaitEvent(s, events[w], 0) != hipSuccess) return DYK_ERR_HIP;
+            if (k == dbg_nowait) continue;
+            if (hipStreamWaitEvent(s, rt.events[w], 0) != hipSuccess) return DYK_ERR_HIP;
         }
-        if (e.cmd >= 0) {
+        if (e.cmd >= 0 && k != dbg_nocmd) {
+            static const bool trace = getenv("DYK_SCHED_TRACE") != nullptr;
+            if (trace) { fprintf(stderr, "sched k=%d cmd=%d op=%d stream=%d nwait=%d w0=%d rec=%d\n", k, e.cmd, cmds[e.cmd].op, e.stream, e.nwait, e.nwait ? e.wait[0] : -1, e.record); fflush(stderr); }
             const int rc = dyk_run_commands(cmds + e.cmd, 1, (void*)s, nullptr);
             if (rc != DYK_OK) {
                 if (failed_index) *failed_index = e.cmd;
                 return rc;
             }
         }
-        if (e.record && hipEventRecord(events[k], s) != hipSuccess) return DYK_ERR_HIP;
+        if (e.record && hipEventRecord(rt.events[k], s) != hipSuccess) return DYK_ERR_HIP;
     }
     for (int s = 1; s < n_streams; ++s)
         if (used[s]) {
-            if (hipEventRecord(ev_join[s], aux[lp][s]) != hipSuccess || hipStreamWaitEvent(main_s, ev_join[s], 0) != hipSuccess)
+            if (hipEventRecord(rt.ev_join[s], rt.aux[lp][s]) != hipSuccess || hipStreamWaitEvent(main_s, rt.ev_join[s], 0) != hipSuccess)
                 return DYK_ERR_HIP;
         }
+    return DYK_OK;
+}
+
+struct SchedGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+}  // namespace
+
+extern "C" int dyk_run_schedule(const DykCommand* cmds, const DykSchedEntry* sched, int32_t n, int32_t n_streams,
+                                int32_t low_priority_last, void* stream, int32_t* failed_index) {
+    if (!cmds || !sched || n < 0 || n_streams < 1 || n_streams > 8) return DYK_ERR_ARG;
+    static SchedRuntime rt;
+    return sched_replay(rt, cmds, sched, n, n_streams, low_priority_last, (hipStream_t)stream, failed_index);
+}
+
+// A command range as a hipGraph built from its DEPENDENCY lists (dyk/sched.py): every command is captured on its own
+// into a small child graph (single-stream capture of one dyk_run_commands call) and added to the master graph as a child
+// node behind the nodes of the commands it depends on.  No cross-stream events take part in a capture -- the multi-stream
+// capture of the issue-ordered schedule is what one would write first, but the HIP runtime PyTorch-ROCm 7.0 ships recurses
+// without end in hip::Stream::EndCapture as soon as two library streams have waited on each other's events (found with
+// rocgdb; the stand-alone ROCm 7.2 runtime handles it).  Kernel arguments are frozen at capture: capture again when a
+// pointer in a descriptor changes (dyk/plan.py keys its graphs on the per-call pointers).
+extern "C" int dyk_dag_graph_create(const DykCommand* cmds, int32_t n, const int32_t* dep_off, const int32_t* dep_idx,
+                                    void** graph_out, int32_t* failed_index) {
+    if (!cmds || n <= 0 || !dep_off || !graph_out) return DYK_ERR_ARG;
+    static hipStream_t origin = nullptr;
+    static const bool dbg = getenv("DYK_GRAPH_DEBUG") != nullptr;
+    if (!origin && hipStreamCreateWithFlags(&origin, hipStreamNonBlocking) != hipSuccess) return DYK_ERR_HIP;
+    SchedGraph* g = new SchedGraph();
+    if (hipGraphCreate(&g->graph, 0) != hipSuccess) { delete g; return DYK_ERR_HIP; }
+    hipGraphNode_t* nodes = (hipGraphNode_t*)calloc((size_t)n, sizeof(hipGraphNode_t));
+    hipGraphNode_t* deps = (hipGraphNode_t*)calloc((size_t)n, sizeof(hipGraphNode_t));
+    int rc = DYK_OK;
+    for (int32_t i = 0; i < n && rc == DYK_OK; ++i) {
+        hipGraph_t child = nullptr;
+        if (hipStreamBeginCapture(origin, hipStreamCaptureModeRelaxed) != hipSuccess) { rc = DYK_ERR_HIP; break; }
+        const int rc1 = dyk_run_commands(cmds + i, 1, (void*)origin, nullptr);
+        const hipError_t e = hipStreamEndCapture(origin, &child);
+        if (rc1 != DYK_OK || e != hipSuccess || !child) {
+            if (failed_index) *failed_index = i;
+            rc = rc1 != DYK_OK ? rc1 : DYK_ERR_HIP;
+            if (child) (void)hipGraphDestroy(child);
+            break;
+        }
+        int nd = 0;
+        for (int32_t q = dep_off[i]; q < dep_off[i + 1]; ++q) {
+            const int32_t j = dep_idx[q];
+            if (j < 0 || j >= i) { rc = DYK_ERR_ARG; break; }
+            deps[nd++] = nodes[j];
+        }
+        if (rc == DYK_OK && hipGraphAddChildGraphNode(&nodes[i], g->graph, deps, (size_t)nd, child) != hipSuccess) {
+            if (failed_index) *failed_index = i;
+            rc = DYK_ERR_HIP;
+        }
+        (void)hipGraphDestroy(child);             // the child node holds its own clone
+    }
+    free(nodes);
+    free(deps);
+    if (rc == DYK_OK) {
+        const hipError_t e2 = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+        if (dbg) fprintf(stderr, "dyk graph: %d commands, instantiate: %s\n", n, hipGetErrorString(e2));
+        if (e2 != hipSuccess) rc = DYK_ERR_HIP;
+    }
+    if (rc != DYK_OK) {
+        (void)hipGetLastError();
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        return rc;
+    }
+    *graph_out = g;
+    return DYK_OK;
+}
+
+extern "C" int dyk_schedule_graph_launch(void* graph, void* stream) {
+    SchedGraph* g = (SchedGraph*)graph;
+    if (!g || !g->exec) return DYK_ERR_ARG;
+    return hipGraphLaunch(g->exec, (hipStream_t)stream) == hipSuccess ? DYK_OK : DYK_ERR_HIP;
+}
+
+extern "C" int dyk_schedule_graph_destroy(void* graph) {
+    SchedGraph* g = (SchedGraph*)graph;
+    if (!g) return DYK_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
     return DYK_OK;
 }
 

@@ -202,6 +202,9 @@ SIGNATURES = {
     "dyk_run_commands": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
     "dyk_run_commands_overlap": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
     "dyk_run_schedule": (_i32, [_P(DykCommand), _P(DykSchedEntry), _i32, _i32, _i32, _vp, _P(_i32)]),
+    "dyk_dag_graph_create": (_i32, [_P(DykCommand), _i32, _P(_i32), _P(_i32), _P(_vp), _P(_i32)]),
+    "dyk_schedule_graph_launch": (_i32, [_vp, _vp]),
+    "dyk_schedule_graph_destroy": (_i32, [_vp]),
     "dyk_yolo_decode": (_i32, [_P(DykDecodeDesc), _vp]),
     "dyk_build_targets": (_i32, [_P(DykTargetsDesc), _vp]),
     "dyk_yolo_loss": (_i32, [_P(DykLossDesc), _P(DykTargetsDesc), _vp]),

@@ -309,7 +309,16 @@ def estimate_cost_us(op, d, plan):
 
 
 class Schedule:
-    """issue-ordered table for dyk_run_schedule"""
+    """issue-ordered table for dyk_run_schedule (+ the dependency lists in CSR form for dyk_dag_graph_create)"""
+
+    def set_deps(self, deps):
+        off = [0]
+        flat = []
+        for d in deps:
+            flat.extend(d)
+            off.append(len(flat))
+        self.dep_off = (ctypes.c_int32 * len(off))(*off)
+        self.dep_idx = (ctypes.c_int32 * max(len(flat), 1))(*flat)
 
     def __init__(self, entries, n_streams, makespan_us, serial_us):
         self.n = len(entries)
@@ -418,4 +427,18 @@ def build(plan, store, which, start, end, n_streams=None):
     filler = None
     if os.environ.get("DYK_SCHED_FILLER", "0") != "0":
         filler = {i for i, (op, _) in enumerate(cmds) if op in (L.OP_WGRAD, L.OP_DW_WGRAD, L.OP_GRAD_REDUCE)}
-    return schedule(cmds, deps, costs, max(1, min(n_streams, 8)), first=start, filler=filler)
+    sc = schedule(cmds, deps, costs, max(1, min(n_streams, 8)), first=start, filler=filler)
+    sc.set_deps(_reduce(deps))
+    return sc
+
+
+def _reduce(deps):
+    """drop dependencies implied by another one (j in deps[i] and j in deps[k] for some k in deps[i]): fewer graph edges"""
+    out = []
+    sets = [set(d) for d in deps]
+    for i, d in enumerate(deps):
+        implied = set()
+        for k in d:
+            implied |= sets[k]
+        out.append([j for j in d if j not in implied])
+    return out

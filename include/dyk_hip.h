@@ -633,6 +633,14 @@ typedef struct DykSchedEntry {
 } DykSchedEntry;
 int dyk_run_schedule(const DykCommand* cmds, const DykSchedEntry* sched, int32_t n_entries, int32_t n_streams,
                      int32_t low_priority_last, void* stream, int32_t* failed_index);
+/* A command range as a hipGraph built from dependency lists: command i depends on commands dep_idx[dep_off[i] ..
+ * dep_off[i+1]) (all < i).  Each command is captured alone (single-stream capture) into a child graph node of the master
+ * graph; the instantiated graph is launched with one host call per pass.  Kernel arguments -- every pointer inside the
+ * descriptors -- are frozen at capture; capture again when one changes.  *graph_out is an opaque handle. */
+int dyk_dag_graph_create(const DykCommand* cmds, int32_t n, const int32_t* dep_off, const int32_t* dep_idx,
+                         void** graph_out, int32_t* failed_index);
+int dyk_schedule_graph_launch(void* graph, void* stream);
+int dyk_schedule_graph_destroy(void* graph);
 
 /* ------------------------------------------------------------------------------------
  * Box-coordinate helpers of the evaluation chain (build_utils/utils.py:40-92; callers evaluate.py:82,

@@ -131,13 +131,14 @@ def test_dependency_scheduled_streams_equal_serial_execution_bitwise(name, dtype
     the same command lists enqueued in order on one stream: outputs, loss, every gradient, running statistics"""
     from build_utils.utils import compute_loss
     res = []
-    for mode in ("serial", "dag", "dag6"):
+    for mode in ("serial", "dag", "dag_graph", "dag6"):
         monkeypatch.setenv("DYK_OVERLAP", "0" if mode == "serial" else "1")
         monkeypatch.setenv("DYK_STREAMS", "6" if mode == "dag6" else "4")
+        monkeypatch.setenv("DYK_GRAPH", "1" if mode == "dag_graph" else "0")      # hipGraph of the dependency graph (optional path)
         m = _model(name, dtype)
         x, y, tg = _batch(5, B=4)
         outs = []
-        for _ in range(2):                                   # second pass: re-armed statistics, accumulated gradients
+        for _ in range(3):                                   # later passes: re-armed statistics, accumulated gradients, graphs
             pred = m(x, y)
             ld = compute_loss(pred, tg, m)
             (ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]).backward()
@@ -147,6 +148,7 @@ def test_dependency_scheduled_streams_equal_serial_execution_bitwise(name, dtype
             plan = next(iter(m.engine.plans.values()))
             sc = plan.schedule("bwd", 0, len(plan.bwd))
             assert len({e["stream"] for e in sc.entries}) >= 3
+            assert bool(plan._graphs) == (mode == "dag_graph"), "the forward graph is captured on the second pass with the same pointers"
         res.append((outs, m.engine.store.G.clone(), m.engine.store.R.clone()))
     for other in res[1:]:
         for a, b in zip(res[0][0], other[0]):

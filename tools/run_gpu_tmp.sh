@@ -1,3 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-bash tools/ab.sh "DYK_EPI_OLD=1" "A=1"
-python -m pytest tests/test_gpu_conv.py tests/test_gpu_model.py -m gpu -q 2>&1 | tail -3
+DYK_GRAPH=1 DYK_GRAPH_DEBUG=1 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/graph_dbg.log 2>&1
+echo "exit $?"; grep "dyk graph" gpurun_out/graph_dbg.log | head -4; tail -1 gpurun_out/graph_dbg.log | cut -c1-200
+bash tools/ab.sh "DYK_GRAPH=0" "DYK_GRAPH=1"
+export AB_ARGS="--batch 1"
+bash tools/ab.sh "DYK_GRAPH=0" "DYK_GRAPH=1"
