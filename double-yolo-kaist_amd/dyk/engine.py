@@ -19,7 +19,23 @@ def _compute_dtype(model):
                 "float32": torch.float32}[str(forced).replace("torch.", "")]
     # the reference trains under torch.cuda.amp.autocast (kaist_train_eval_utils.py:74); any autocast
     # region selects the reduced-precision path, which on MI355X is bf16 MFMA with fp32 accumulation
-    return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+    if torch.is_autocast_enabled():
+        try:
+            ac = torch.get_autocast_dtype("cuda")
+        except Exception:                      # older torch
+            ac = torch.get_autocast_gpu_dtype()
+        if ac != torch.bfloat16 and not _compute_dtype.warned:
+            _compute_dtype.warned = True
+            import warnings
+            warnings.warn("dyk: the autocast region asks for %s (the reference trains under fp16 autocast + GradScaler, "
+                          "kaist_train_eval_utils.py:74); the MI355X path computes reduced precision in bfloat16 MFMA with "
+                          "fp32 accumulation instead -- same storage width, wider exponent, so loss scaling is a no-op.  "
+                          "Set model.dyk_dtype = 'fp32' for bit-level comparisons against an fp32 reference run." % ac)
+        return torch.bfloat16
+    return torch.float32
+
+
+_compute_dtype.warned = False
 
 
 class _NetFunction(torch.autograd.Function):
