@@ -337,7 +337,10 @@ int sched_prepare(SchedRuntime& rt, int32_t n, int32_t n_streams, int32_t low_pr
         if (!rt.aux[lp][s]) {
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            const int prio = (lp && s == n_streams - 1) ? lo : 0;
+            int prio = (lp && s == n_streams - 1) ? lo : 0;
+            // DYK_SCHED_PRIO=1: the second chain (stream 1) at the highest priority, the filler streams (2..) at the lowest
+            static const bool tiered = getenv("DYK_SCHED_PRIO") && getenv("DYK_SCHED_PRIO")[0] == '1';
+            if (tiered) prio = (s == 1) ? hi : lo;
             if (hipStreamCreateWithPriority(&rt.aux[lp][s], hipStreamNonBlocking, prio) != hipSuccess) return DYK_ERR_HIP;
         }
     return DYK_OK;

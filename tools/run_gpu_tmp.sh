@@ -1,6 +1,2 @@
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-DYK_GRAPH=1 DYK_GRAPH_DEBUG=1 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/graph_dbg.log 2>&1
-echo "exit $?"; grep "dyk graph" gpurun_out/graph_dbg.log | head -4; tail -1 gpurun_out/graph_dbg.log | cut -c1-200
-bash tools/ab.sh "DYK_GRAPH=0" "DYK_GRAPH=1"
-export AB_ARGS="--batch 1"
-bash tools/ab.sh "DYK_GRAPH=0" "DYK_GRAPH=1"
+bash tools/ab.sh "A=1" "DYK_SCHED_PRIO=1" "DYK_STREAMS=5" "DYK_STREAMS=5 DYK_SCHED_PRIO=1"
