@@ -243,27 +243,28 @@ def test_module_surface_device_moves_and_checkpoints():
         _model(C3).eval()(x.cuda())
 
 
-def test_baseline_size_train_step_is_bit_reproducible():
-    """the BASELINE workload (target cfg, 16 pairs of 512x640, bf16): shapes, finiteness, and run-to-run bit identity of
+@pytest.mark.parametrize("name,B", [(C3, 16), (C5, 32)])
+def test_baseline_size_train_step_is_bit_reproducible(name, B):
+    """the BASELINE workloads at their full per-GPU size (target cfg: 16 pairs of 512x640; MobileNetV3 cfg: 32 pairs), bf16: shapes, finiteness, and run-to-run bit identity of
     the head outputs, the loss and EVERY parameter gradient (statistics are folded in a fixed order inside a workgroup
     and in fp64 across workgroups; weight gradients go through per-split planes instead of fp32 atomics)."""
     from build_utils.utils import compute_loss
-    m = _model(C3, dtype="bf16").train()
+    m = _model(name, dtype="bf16").train()
     m.nc, m.hyp, m.gr = 1, hyp(), 1.0
     g = torch.Generator().manual_seed(5)
-    v = torch.rand(16, 3, 512, 640, generator=g).cuda()
-    l = torch.rand(16, 3, 512, 640, generator=g).cuda()
-    tg = torch.zeros(64, 6)
-    tg[:, 0] = torch.arange(16).repeat_interleave(4).float()
-    tg[:, 2:4] = torch.rand(64, 2, generator=g) * 0.8 + 0.1
-    tg[:, 4] = (torch.rand(64, generator=g) * 60 + 16) / 640
-    tg[:, 5] = (torch.rand(64, generator=g) * 120 + 32) / 512
+    v = torch.rand(B, 3, 512, 640, generator=g).cuda()
+    l = torch.rand(B, 3, 512, 640, generator=g).cuda()
+    tg = torch.zeros(4 * B, 6)
+    tg[:, 0] = torch.arange(B).repeat_interleave(4).float()
+    tg[:, 2:4] = torch.rand(4 * B, 2, generator=g) * 0.8 + 0.1
+    tg[:, 4] = (torch.rand(4 * B, generator=g) * 60 + 16) / 640
+    tg[:, 5] = (torch.rand(4 * B, generator=g) * 120 + 32) / 512
     sd0 = {k: t.clone() for k, t in m.state_dict().items()}
     outs, grads, losses = [], [], []
     for _ in range(2):
         m.load_state_dict(sd0)                       # same running statistics / counters on both passes
         pred = m(v, l)
-        assert [tuple(p.shape) for p in pred] == [(16, 3, 64, 80, 6), (16, 3, 32, 40, 6), (16, 3, 16, 20, 6)]
+        assert [tuple(p.shape) for p in pred] == [(B, 3, 64, 80, 6), (B, 3, 32, 40, 6), (B, 3, 16, 20, 6)]
         assert all(bool(torch.isfinite(p).all()) for p in pred)
         ld = compute_loss(pred, tg.cuda(), m)
         loss = ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]
