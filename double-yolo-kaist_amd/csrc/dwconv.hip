@@ -167,12 +167,26 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(DykDwDesc d, int CVB)
                         }
                     }
                     const T* srow = x + ((long)b * Hsrc + ys) * Wsrc * ld_src + c;
+                    // the NS source vectors of the row: unconditional loads from clamped columns, zeroed afterwards -- a
+                    // branch around each load made hipcc wait for every one of them on the spot (5x5: 600 GB/s)
+                    uint4 raw[NS];
+                    // (5x5: keep the batches of different kernel rows apart -- hoisted together they need 256 VGPRs, one
+                    // wave per SIMD; one row's eight loads in flight at 2-3 waves per SIMD is the better trade)
+                    if (K >= 5) asm volatile("" ::: "memory");
 #pragma unroll
                     for (int sl = 0; sl < NS; ++sl) {
                         const int xs = xbase + sl;
-                        if (xs < 0 || xs >= Wsrc) continue;
+                        const int xc = xs < 0 ? 0 : (xs >= Wsrc ? Wsrc - 1 : xs);
+                        raw[sl] = *(const uint4*)(srow + (long)xc * ld_src);
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < NS; ++sl) {
+                        const int xs = xbase + sl;
+                        const bool in = xs >= 0 && xs < Wsrc;
                         float xv[EPV];
-                        vec_unpack<T>(*(const uint4*)(srow + (long)xs * ld_src), xv);
+                        vec_unpack<T>(raw[sl], xv);
+#pragma unroll
+                        for (int j = 0; j < EPV; ++j) xv[j] = in ? xv[j] : 0.f;
 #pragma unroll
                         for (int o = 0; o < XT; ++o) {
                             const int kw = GRAD ? o + (K - 1) - sl : sl - o;       // compile-time after unrolling
@@ -256,20 +270,34 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DykDwDesc d, int CVB)
                 constexpr int XT = 4;
                 for (int xo0 = ty * XT; xo0 < d.Wo; xo0 += PY * XT) {
                     float g[XT][EPV];
+                    // all loads of the strip first (clamped columns, values zeroed afterwards): one memory round trip
+                    uint4 graw[XT], xraw[XT + K - 1];
 #pragma unroll
                     for (int o = 0; o < XT; ++o) {
-                        if (xo0 + o < d.Wo) vec_unpack<T>(*(const uint4*)(dy + ((long)row * d.Wo + xo0 + o) * d.ldy + c), g[o]);
-                        else {
-#pragma unroll
-                            for (int j = 0; j < EPV; ++j) g[o][j] = 0.f;
-                        }
+                        const int xo = xo0 + o < d.Wo ? xo0 + o : d.Wo - 1;
+                        graw[o] = *(const uint4*)(dy + ((long)row * d.Wo + xo) * d.ldy + c);
                     }
 #pragma unroll
                     for (int sl = 0; sl < XT + K - 1; ++sl) {
                         const int xi = xo0 - d.pad + sl;
-                        if (xi < 0 || xi >= d.Wi) continue;
+                        const int xc = xi < 0 ? 0 : (xi >= d.Wi ? d.Wi - 1 : xi);
+                        xraw[sl] = *(const uint4*)(xrow + (long)xc * d.ldx);
+                    }
+#pragma unroll
+                    for (int o = 0; o < XT; ++o) {
+                        vec_unpack<T>(graw[o], g[o]);
+                        const bool in = xo0 + o < d.Wo;
+#pragma unroll
+                        for (int j = 0; j < EPV; ++j) g[o][j] = in ? g[o][j] : 0.f;
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < XT + K - 1; ++sl) {
+                        const int xi = xo0 - d.pad + sl;
+                        const bool in = xi >= 0 && xi < d.Wi;
                         float xv[EPV];
-                        vec_unpack<T>(*(const uint4*)(xrow + (long)xi * d.ldx), xv);
+                        vec_unpack<T>(xraw[sl], xv);
+#pragma unroll
+                        for (int j = 0; j < EPV; ++j) xv[j] = in ? xv[j] : 0.f;
 #pragma unroll
                         for (int o = 0; o < XT; ++o) {
                             const int t = sl - o;                  // tap within the kernel row (compile-time after unrolling)
@@ -286,14 +314,20 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DykDwDesc d, int CVB)
             float g[EPV];
             vec_unpack<T>(*(const uint4*)(dy + p * d.ldy + c), g);
             const int xi0 = xo * d.stride - d.pad;
+            uint4 xraw[K];
 #pragma unroll
             for (int t = 0; t < K; ++t) {
                 const int xi = xi0 + t;
-                if (xi < 0 || xi >= d.Wi) continue;
-                float xv[EPV];
-                vec_unpack<T>(*(const uint4*)(xrow + (long)xi * d.ldx), xv);
+                xraw[t] = *(const uint4*)(xrow + (long)(xi < 0 ? 0 : (xi >= d.Wi ? d.Wi - 1 : xi)) * d.ldx);
+            }
 #pragma unroll
-                for (int j = 0; j < EPV; ++j) acc[t][j] += g[j] * xv[j];
+            for (int t = 0; t < K; ++t) {
+                const int xi = xi0 + t;
+                const bool in = xi >= 0 && xi < d.Wi;
+                float xv[EPV];
+                vec_unpack<T>(xraw[t], xv);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) acc[t][j] += in ? g[j] * xv[j] : 0.f;
             }
           }
         }
