@@ -237,6 +237,115 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(DykDwDesc d, int CVB)
     }
 }
 
+// Stride-2 fast path (MobileNet down-sampling layers): K and the stride are compile-time, so the taps of a pixel are a
+// fixed, unrolled set whose loads are issued together -- clamped coordinates, values zeroed afterwards (the generic kernel
+// above walks runtime loops with a branch around every load: one memory round trip per tap).
+//   forward : y[yo, xo] = sum_{kh,kw} x[2 yo + kh - pad, 2 xo + kw - pad] w[kh, kw]              (K*K loads)
+//   gradient: dx[yi, xi] = sum over the taps of yi's / xi's parity, kh = (yi + pad) % 2 + 2 a:
+//             dy[(yi + pad - kh) / 2, (xi + pad - kw) / 2] w[kh, kw]                              (ceil(K/2)^2 loads)
+template <typename T, int K, bool GRAD>
+__global__ __launch_bounds__(256) void dwconv_s2_kernel(DykDwDesc d, int CVB) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    constexpr int KT = GRAD ? (K + 1) / 2 : K;                 // taps per dimension a pixel touches
+    __shared__ float red[256 * 2 * 8];
+    const int PY = 256 / CVB;
+    const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
+    const int cv = blockIdx.x * CVB + tx;
+    const int c = cv * EPV;
+    const bool active = c < d.C;
+    const T* __restrict__ x = GRAD ? (const T*)d.y : (const T*)d.x;     // tensor read
+    T* __restrict__ y = GRAD ? (T*)d.x : (T*)d.y;                       // tensor written
+    const int ld_src = GRAD ? d.ldy : d.ldx, ld_dst = GRAD ? d.ldx : d.ldy;
+    const int pad = d.pad;
+    const int Hout = GRAD ? d.Hi : d.Ho, Wout = GRAD ? d.Wi : d.Wo;
+    const int Hsrc = GRAD ? d.Ho : d.Hi, Wsrc = GRAD ? d.Wo : d.Wi;
+    const bool accum = d.flags & DYK_EW_ACCUM;
+    const bool stats = (!GRAD) && d.stats != nullptr;
+    float s1[EPV], s2[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) s1[j] = s2[j] = 0.f;
+    if (active) {
+        const int nrows = d.B * Hout;
+        for (int row = blockIdx.y; row < nrows; row += gridDim.y) {
+            const int b = row / Hout, yo = row - b * Hout;
+            const int kh0 = GRAD ? (yo + pad) & 1 : 0;
+            for (int xo = ty; xo < Wout; xo += PY) {
+                const int kw0 = GRAD ? (xo + pad) & 1 : 0;
+                uint4 raw[KT][KT];
+                bool ok[KT][KT];
+#pragma unroll
+                for (int a = 0; a < KT; ++a) {
+                    const int kh = GRAD ? kh0 + 2 * a : a;
+                    const int ys = GRAD ? (yo + pad - kh) >> 1 : yo * 2 + kh - pad;
+                    const bool yok = kh < K && ys >= 0 && ys < Hsrc && (!GRAD || yo + pad - kh >= 0);
+                    const int yc = ys < 0 ? 0 : (ys >= Hsrc ? Hsrc - 1 : ys);
+#pragma unroll
+                    for (int e = 0; e < KT; ++e) {
+                        const int kw = GRAD ? kw0 + 2 * e : e;
+                        const int xs = GRAD ? (xo + pad - kw) >> 1 : xo * 2 + kw - pad;
+                        ok[a][e] = yok && kw < K && xs >= 0 && xs < Wsrc && (!GRAD || xo + pad - kw >= 0);
+                        const int xc = xs < 0 ? 0 : (xs >= Wsrc ? Wsrc - 1 : xs);
+                        raw[a][e] = *(const uint4*)(x + (((long)b * Hsrc + yc) * Wsrc + xc) * ld_src + c);
+                    }
+                }
+                float acc[EPV];
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
+#pragma unroll
+                for (int a = 0; a < KT; ++a)
+#pragma unroll
+                    for (int e = 0; e < KT; ++e) {
+                        const int kh = GRAD ? kh0 + 2 * a : a, kw = GRAD ? kw0 + 2 * e : e;
+                        const int t = (kh < K && kw < K) ? kh * K + kw : 0;
+                        const float* wp = d.w + (long)t * d.C + c;
+                        const float4 w0 = *(const float4*)wp;
+                        float wv[8] = {w0.x, w0.y, w0.z, w0.w, 0.f, 0.f, 0.f, 0.f};
+                        if (EPV == 8) {
+                            const float4 w1 = *(const float4*)(wp + 4);
+                            wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+                        }
+                        float xv[EPV];
+                        vec_unpack<T>(raw[a][e], xv);
+                        const bool in = ok[a][e];
+#pragma unroll
+                        for (int j = 0; j < EPV; ++j) acc[j] += in ? xv[j] * wv[j] : 0.f;
+                    }
+                if (stats) {
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) { s1[j] += acc[j]; s2[j] += acc[j] * acc[j]; }
+                }
+                T* yp = y + ((long)row * Wout + xo) * ld_dst + c;
+                if (accum) {
+                    float old[EPV];
+                    vec_unpack<T>(*(const uint4*)yp, old);
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) acc[j] += old[j];
+                }
+                *(uint4*)yp = vec_pack<T>(acc);
+            }
+        }
+    }
+    if (stats) {
+        float* mine = red + threadIdx.x * 16;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) { mine[j] = s1[j]; mine[8 + j] = s2[j]; }
+        __syncthreads();
+        if (ty == 0 && active) {
+            for (int q = 1; q < PY; ++q) {
+                const float* o = red + (q * CVB + tx) * 16;
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) { s1[j] += o[j]; s2[j] += o[8 + j]; }
+            }
+            double* st = d.stats + (size_t)(blockIdx.y % (unsigned)(d.stats_slots > 0 ? d.stats_slots : 1)) * 2 * d.C;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                atomicAdd(st + c + j, (double)s1[j]);
+                atomicAdd(st + d.C + c + j, (double)s2[j]);
+            }
+        }
+    }
+}
+
 // dw[t][c] += sum_p dy[p][c] * x[src(p, t)][c].  grid.z = kernel row kh; a thread keeps the K taps of that row for its
 // 8 channels in registers (K*8 accumulators), reads the output-gradient vector of a pixel once and the K input vectors of
 // the row from L1 -- one pass over dy per kernel row instead of one per tap, K x fewer workgroup reductions and atomics.
@@ -395,7 +504,7 @@ extern "C" int dyk_dwconv_fwd(const DykDwDesc* d, void* stream) {
     if (d->stride == 1 && (d->k == 3 || d->k == 5) && d->dtype == DYK_BF16) {
         if (d->k == 3) hipLaunchKernelGGL((dwconv_strip_kernel<bf16_t, 3, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
         else hipLaunchKernelGGL((dwconv_strip_kernel<bf16_t, 5, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
-    } else if (d->dtype == DYK_BF16)
+    } else if (d->dtype == DYK_BF16)      // (stride 2 forward: the generic kernel measured faster than dwconv_s2_kernel<.., false>)
         hipLaunchKernelGGL((dwconv_kernel<bf16_t, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
     else
         hipLaunchKernelGGL((dwconv_kernel<float, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
@@ -413,6 +522,9 @@ extern "C" int dyk_dwconv_dgrad(const DykDwDesc* d, void* stream) {
     if (d->stride == 1 && (d->k == 3 || d->k == 5) && d->dtype == DYK_BF16) {
         if (d->k == 3) hipLaunchKernelGGL((dwconv_strip_kernel<bf16_t, 3, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
         else hipLaunchKernelGGL((dwconv_strip_kernel<bf16_t, 5, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
+    } else if (d->stride == 2 && (d->k == 3 || d->k == 5) && d->dtype == DYK_BF16) {
+        if (d->k == 3) hipLaunchKernelGGL((dwconv_s2_kernel<bf16_t, 3, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
+        else hipLaunchKernelGGL((dwconv_s2_kernel<bf16_t, 5, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
     } else if (d->dtype == DYK_BF16)
         hipLaunchKernelGGL((dwconv_kernel<bf16_t, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
     else
