@@ -1,6 +1,11 @@
 // Native command-list executor, parameter staging kernels and the YOLO box decode.
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
 #include "dyk_common.h"
 
 namespace {
@@ -349,51 +354,24 @@ int sched_prepare(SchedRuntime& rt, int32_t n, int32_t n_streams, int32_t low_pr
 int sched_replay(SchedRuntime& rt, const DykCommand* cmds, const DykSchedEntry* sched, int32_t n, int32_t n_streams,
                  int32_t low_priority_last, hipStream_t main_s, int32_t* failed_index) {
     if (sched_prepare(rt, n, n_streams, low_priority_last) != DYK_OK) return DYK_ERR_HIP;
-    if (!rt.ev_start) {
-        if (hipEventCreateWithFlags(&rt.ev_start, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
-        for (auto& e : rt.ev_join)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
-    }
-    if (n > rt.n_events) {
-        hipEvent_t* grown = (hipEvent_t*)realloc(rt.events, sizeof(hipEvent_t) * (size_t)n);
-        if (!grown) return DYK_ERR_HIP;
-        rt.events = grown;
-        for (int i = rt.n_events; i < n; ++i)
-            if (hipEventCreateWithFlags(&rt.events[i], hipEventDisableTiming) != hipSuccess) return DYK_ERR_HIP;
-        rt.n_events = n;
-    }
     const int lp = low_priority_last ? 1 : 0;
     bool used[8] = {};
-    auto stream_of = [&](int s) -> hipStream_t {
-        if (s == 0) return main_s;
-        if (!rt.aux[lp][s]) {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            const int prio = (lp && s == n_streams - 1) ? lo : 0;
-            if (hipStreamCreateWithPriority(&rt.aux[lp][s], hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
-        }
-        return rt.aux[lp][s];
-    };
     if (n_streams > 1 && hipEventRecord(rt.ev_start, main_s) != hipSuccess) return DYK_ERR_HIP;
+    static const bool trace = getenv("DYK_SCHED_TRACE") != nullptr;
     for (int32_t k = 0; k < n; ++k) {
         const DykSchedEntry& e = sched[k];
         if (e.stream < 0 || e.stream >= n_streams || e.nwait < 0 || e.nwait > 7) return DYK_ERR_ARG;
-        hipStream_t s = stream_of(e.stream);
-        if (!s && e.stream) return DYK_ERR_HIP;
+        hipStream_t s = e.stream ? rt.aux[lp][e.stream] : main_s;
         if (e.stream && !used[e.stream]) {
             if (hipStreamWaitEvent(s, rt.ev_start, 0) != hipSuccess) return DYK_ERR_HIP;
             used[e.stream] = true;
         }
-        static const int dbg_nowait = getenv("DYK_DBG_NOWAIT_K") ? atoi(getenv("DYK_DBG_NOWAIT_K")) : -1;
-        static const int dbg_nocmd = getenv("DYK_DBG_NOCMD_K") ? atoi(getenv("DYK_DBG_NOCMD_K")) : -1;
         for (int q = 0; q < e.nwait; ++q) {
             const int32_t w = e.wait[q];
             if (w < 0 || w >= k) return DYK_ERR_ARG;
-            if (k == dbg_nowait) continue;
             if (hipStreamWaitEvent(s, rt.events[w], 0) != hipSuccess) return DYK_ERR_HIP;
         }
-        if (e.cmd >= 0 && k != dbg_nocmd) {
-            static const bool trace = getenv("DYK_SCHED_TRACE") != nullptr;
+        if (e.cmd >= 0) {
             if (trace) { fprintf(stderr, "sched k=%d cmd=%d op=%d stream=%d nwait=%d w0=%d rec=%d\n", k, e.cmd, cmds[e.cmd].op, e.stream, e.nwait, e.nwait ? e.wait[0] : -1, e.record); fflush(stderr); }
             const int rc = dyk_run_commands(cmds + e.cmd, 1, (void*)s, nullptr);
             if (rc != DYK_OK) {
@@ -411,6 +389,123 @@ int sched_replay(SchedRuntime& rt, const DykCommand* cmds, const DykSchedEntry* 
     return DYK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One host thread per stream.  A launch costs the host ~9 us (runtime call + argument marshalling); a train step is
+// ~1150 launches, so ONE issuing thread needs ~10 ms per step -- as long as the whole batch-1 step takes on the GPU, and a
+// third of the batch-16 step during which later streams start late.  The schedule already says which stream every command
+// belongs to, so each library stream gets its own issuing thread (the caller's thread serves the caller's stream); the
+// only host-side ordering needed is that a stream's hipStreamWaitEvent must come after the hipEventRecord it refers to
+// has been issued: a per-entry flag, spun on by the waiter.  Entries are numbered in a topological order and a thread
+// never waits on a later entry, so the flags cannot deadlock.
+struct IssuePool {
+    struct Job {
+        SchedRuntime* rt = nullptr;
+        const DykCommand* cmds = nullptr;
+        const DykSchedEntry* sched = nullptr;
+        int32_t n = 0, n_streams = 0, lp = 0, device = 0;
+    } job;
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    uint64_t generation = 0;
+    int pending = 0;
+    std::vector<std::atomic<uint8_t>> issued;       // entry k: its completion event has been recorded (host side)
+    std::atomic<int> error{0};
+    std::atomic<int> failed_cmd{-1};
+    bool stop = false;
+
+    int run_stream(int sidx, hipStream_t s) {
+        const Job& j = job;
+        bool first = true;
+        for (int32_t k = 0; k < j.n; ++k) {
+            const DykSchedEntry& e = j.sched[k];
+            if (e.stream != sidx) continue;
+            if (error.load(std::memory_order_relaxed)) return DYK_ERR_HIP;
+            if (first && sidx) {
+                if (hipStreamWaitEvent(s, j.rt->ev_start, 0) != hipSuccess) return DYK_ERR_HIP;
+                first = false;
+            }
+            for (int q = 0; q < e.nwait; ++q) {
+                const int32_t w = e.wait[q];
+                if (w < 0 || w >= k) return DYK_ERR_ARG;
+                int spins = 0;
+                while (!issued[w].load(std::memory_order_acquire)) {
+                    if (error.load(std::memory_order_relaxed)) return DYK_ERR_HIP;
+                    if (++spins > 64) std::this_thread::yield();
+                }
+                if (hipStreamWaitEvent(s, j.rt->events[w], 0) != hipSuccess) return DYK_ERR_HIP;
+            }
+            if (e.cmd >= 0) {
+                const int rc = dyk_run_commands(j.cmds + e.cmd, 1, (void*)s, nullptr);
+                if (rc != DYK_OK) { failed_cmd.store(e.cmd); return rc; }
+            }
+            if (e.record) {
+                if (hipEventRecord(j.rt->events[k], s) != hipSuccess) return DYK_ERR_HIP;
+                issued[k].store(1, std::memory_order_release);
+            }
+        }
+        if (sidx && !first && hipEventRecord(j.rt->ev_join[sidx], s) != hipSuccess) return DYK_ERR_HIP;
+        return first && sidx ? 1 : DYK_OK;        // 1: this stream had no work (no join event recorded)
+    }
+
+    int worker_status[8] = {};
+
+    void worker(int sidx) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m);
+            cv_go.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            const bool mine = sidx < job.n_streams;
+            lk.unlock();
+            int rc = 1;
+            if (mine) {
+                (void)hipSetDevice(job.device);
+                rc = run_stream(sidx, job.rt->aux[job.lp][sidx]);
+                if (rc < 0) error.store(rc);
+            }
+            lk.lock();
+            worker_status[sidx] = rc;
+            if (--pending == 0) cv_done.notify_one();
+        }
+    }
+
+    int run(SchedRuntime& rt, const DykCommand* cmds, const DykSchedEntry* sched, int32_t n, int32_t n_streams, int32_t lp,
+            hipStream_t main_s, int32_t* failed_index) {
+        if (sched_prepare(rt, n, n_streams, lp) != DYK_OK) return DYK_ERR_HIP;
+        if ((int)issued.size() < n) issued = std::vector<std::atomic<uint8_t>>((size_t)n + 256);
+        for (int32_t k = 0; k < n; ++k) issued[k].store(0, std::memory_order_relaxed);
+        error.store(0);
+        failed_cmd.store(-1);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (n_streams > 1 && hipEventRecord(rt.ev_start, main_s) != hipSuccess) return DYK_ERR_HIP;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            while ((int)threads.size() < 7) { const int idx = (int)threads.size() + 1; threads.emplace_back([this, idx] { worker(idx); }); }
+            job.rt = &rt; job.cmds = cmds; job.sched = sched; job.n = n; job.n_streams = n_streams; job.lp = lp; job.device = dev;
+            pending = (int)threads.size();
+            ++generation;
+        }
+        cv_go.notify_all();
+        int rc0 = run_stream(0, main_s);
+        if (rc0 < 0) error.store(rc0);
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return pending == 0; });
+        }
+        const int err = error.load();
+        if (err) {
+            if (failed_index) *failed_index = failed_cmd.load();
+            return err;
+        }
+        for (int s = 1; s < n_streams; ++s)
+            if (worker_status[s] == DYK_OK && hipStreamWaitEvent(main_s, rt.ev_join[s], 0) != hipSuccess) return DYK_ERR_HIP;
+        return DYK_OK;
+    }
+};
+
 struct SchedGraph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -421,6 +516,12 @@ extern "C" int dyk_run_schedule(const DykCommand* cmds, const DykSchedEntry* sch
                                 int32_t low_priority_last, void* stream, int32_t* failed_index) {
     if (!cmds || !sched || n < 0 || n_streams < 1 || n_streams > 8) return DYK_ERR_ARG;
     static SchedRuntime rt;
+    // DYK_ISSUE_THREADS=0: everything is issued by the calling thread (one launch at a time)
+    static const bool threaded = !(getenv("DYK_ISSUE_THREADS") && getenv("DYK_ISSUE_THREADS")[0] == '0');
+    if (threaded && n_streams > 1) {
+        static IssuePool* pool = new IssuePool();        // (leaked on purpose: worker threads outlive static destruction)
+        return pool->run(rt, cmds, sched, n, n_streams, low_priority_last ? 1 : 0, (hipStream_t)stream, failed_index);
+    }
     return sched_replay(rt, cmds, sched, n, n_streams, low_priority_last, (hipStream_t)stream, failed_index);
 }
 

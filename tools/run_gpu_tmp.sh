@@ -1,5 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-python tools/dw_probe.py 2>&1 | grep -v amdgpu
-python -m pytest tests/test_gpu_conv.py tests/test_gpu_layers.py -m gpu -q 2>&1 | tail -2
+python -m pytest tests/test_gpu_ddp.py tests/test_gpu_model.py -m gpu -q -x 2>&1 | grep -vE "RCCL|HIP version|ROCm version|Hostname|Librccl|amdgpu" | tail -4
+bash tools/ab.sh "DYK_ISSUE_THREADS=0" "DYK_ISSUE_THREADS=1"
+export AB_ARGS="--batch 1"
+bash tools/ab.sh "DYK_ISSUE_THREADS=0" "DYK_ISSUE_THREADS=1"
 export AB_ARGS="--cfg kaist_dyolov4_mobilenetv3_fshare_global_cse3 --batch 32"
-bash tools/ab.sh "A=1"
+bash tools/ab.sh "DYK_ISSUE_THREADS=0" "DYK_ISSUE_THREADS=1"
