@@ -587,6 +587,7 @@ __global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(3))) v
     const T* __restrict__ wg = (const T*)a.w;
     // bits 16.. of `tune` are ablation switches for kernel analysis (tools/gpu_probe.py ablate): never set by the plan
     const bool abl_nostore = (a.tune >> 16) & 1, abl_noloop = (a.tune >> 17) & 1;
+    const bool abl_nobar = (a.tune >> 22) & 1;      // analysis: K loop without its workgroup barrier (WRONG results: timing only)
     // K-groups split the input-channel chunks; the step count of group 0 (the larger half) drives the common barriers
     const int nchunks = a.Cin / BK;
     const int c_begin = (KG > 1 && grp) ? (nchunks + 1) / 2 : 0;
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(3))) v
                 if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                if (!abl_nobar) __builtin_amdgcn_s_barrier();
                 cur = (cur == PIPE - 1) ? 0 : cur + 1;
                 nxt = (nxt == PIPE - 1) ? 0 : nxt + 1;
             }
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(3))) v
                     compute(sA + (s & 1) * A_BYTES, sB + (s & 1) * B_BYTES, [&]() { if (s + 1 < S) stage_next((s + 1) & 1); });
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                if (!abl_nobar) __builtin_amdgcn_s_barrier();
             }
         }
     }

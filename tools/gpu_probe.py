@@ -125,6 +125,39 @@ if "ablate" in what:
             print(rows[-1], flush=True)
     res["ablate"] = rows
 
+if "nobar" in what:
+    # upper bound of a barrier-free K loop: the autotuned best configuration with / without its per-step s_barrier
+    import ctypes as C
+    from dyk import lib as L
+    from dyk.plan import _conv_candidates
+    for (ci, co, H, W, k) in [(128, 128, 64, 80, 3), (256, 256, 32, 40, 3), (512, 512, 16, 20, 3), (128, 128, 64, 80, 1), (512, 256, 32, 40, 1), (64, 64, 256, 320, 1)]:
+        B, dt = 16, torch.bfloat16
+        x = torch.randn(B, H, W, ci, device="cuda").to(dt)
+        w = torch.randn(co, ci, k, k, device="cuda") * 0.05
+        wp = ops.pack_weight(w, dt)
+        out = torch.empty(B, H, W, co, device="cuda", dtype=dt)
+        stats = torch.zeros(64 * co, dtype=torch.float64, device="cuda")
+        d = ops.make_conv_desc(x, wp, out, Hi=H, Wi=W, Cin=ci, Cout=co, Hg=H, Wg=W, Ho=H, Wo=W, taps=ops.fwd_taps(k, k // 2), stats=stats)
+        d.stats_slots = 32
+        fn = L.load().dyk_conv_igemm
+        def t(tune, n=10):
+            d.tune = tune
+            for _ in range(3):
+                fn(C.byref(d), None)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn(C.byref(d), None)
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n * 1e3
+        cands = [c for c in _conv_candidates(d) if ((c >> 12) & 0xf) < 3 and not (c >> 28)]
+        best = min(cands, key=t)
+        fl = 2.0 * B * H * W * ci * co * k * k
+        tb, tn, te, tl = t(best), t(best | (1 << 22)), t(best | (1 << 20)), t(best | (1 << 17))
+        print((ci, co, H, k), "best tune %x: %.1f us (%.0f TF) | no barrier %.1f us (%.0f TF) | no epilogue %.1f us | no K loop %.1f us" % (
+            best, tb, fl / tb / 1e6, tn, fl / tn / 1e6, te, tl), flush=True)
+
 if "tunes" in what:
     import ctypes as C
     from dyk import lib as L
