@@ -148,28 +148,30 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(DykEwDesc d) {   //
 // (torch CPU max_pool2d keeps the first element for which val > max, so ties go to the earliest).
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(DykEwDesc d, uint8_t* __restrict__ idx) {
+    // nn.MaxPool2d(k, stride, padding=(k-1)//2) (reference models.py:91-94); stride = d.slots (0 / 1: stride 1, the SPP pools)
     constexpr int EPV = ElemTraits<T>::EPV;
     const int CV = d.C / EPV;
-    const int k = d.k, pad = (k - 1) / 2;
-    const long total = (long)d.B * d.H * d.W * CV;
+    const int k = d.k, pad = (k - 1) / 2, st = d.slots > 1 ? d.slots : 1;
+    const int Ho = (d.H + 2 * pad - k) / st + 1, Wo = (d.W + 2 * pad - k) / st + 1;
+    const long total = (long)d.B * Ho * Wo * CV;
     const T* __restrict__ a = (const T*)d.a;
     T* __restrict__ o = (T*)d.out;
     for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
         const long p = v / CV;
         const int c = (int)(v - p * CV) * EPV;
-        const int x = (int)(p % d.W);
-        const long q = p / d.W;
-        const int y = (int)(q % d.H);
-        const int b = (int)(q / d.H);
+        const int x = (int)(p % Wo);
+        const long q = p / Wo;
+        const int y = (int)(q % Ho);
+        const int b = (int)(q / Ho);
         float m[EPV]; int mi[EPV];
 #pragma unroll
         for (int j = 0; j < EPV; ++j) { m[j] = -INFINITY; mi[j] = 0; }
         bool first = true;
         for (int dy = 0; dy < k; ++dy) {
-            const int yy = y + dy - pad;
+            const int yy = y * st + dy - pad;
             if (yy < 0 || yy >= d.H) continue;
             for (int dx = 0; dx < k; ++dx) {
-                const int xx = x + dx - pad;
+                const int xx = x * st + dx - pad;
                 if (xx < 0 || xx >= d.W) continue;
                 float t[EPV];
                 vec_unpack<T>(*(const uint4*)(a + (((long)b * d.H + yy) * d.W + xx) * d.lda + c), t);
@@ -186,12 +188,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(DykEwDesc d, uint8_t* 
         }
     }
 }
-// a = dout [B,H,W,C], out = din; gather form (no atomics, deterministic)
+
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(DykEwDesc d, const uint8_t* __restrict__ idx) {
+    // a = dout [B,Ho,Wo,C], out = din [B,H,W,C]; every input pixel gathers from the outputs whose window holds it
     constexpr int EPV = ElemTraits<T>::EPV;
     const int CV = d.C / EPV;
-    const int k = d.k, pad = (k - 1) / 2;
+    const int k = d.k, pad = (k - 1) / 2, st = d.slots > 1 ? d.slots : 1;
+    const int Ho = (d.H + 2 * pad - k) / st + 1, Wo = (d.W + 2 * pad - k) / st + 1;
     const long total = (long)d.B * d.H * d.W * CV;
     const T* __restrict__ a = (const T*)d.a;
     T* __restrict__ o = (T*)d.out;
@@ -207,12 +211,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(DykEwDesc d, const uin
 #pragma unroll
         for (int j = 0; j < EPV; ++j) s[j] = 0.f;
         for (int dy = 0; dy < k; ++dy) {
-            const int yo = y - dy + pad;          // output row whose window position dy is this row
-            if (yo < 0 || yo >= d.H) continue;
+            const int ty = y - dy + pad;          // = yo * stride for the output row whose window position dy is this row
+            if (ty < 0 || ty % st) continue;
+            const int yo = ty / st;
+            if (yo >= Ho) continue;
             for (int dx = 0; dx < k; ++dx) {
-                const int xo = x - dx + pad;
-                if (xo < 0 || xo >= d.W) continue;
-                const long po = ((long)b * d.H + yo) * d.W + xo;
+                const int tx = x - dx + pad;
+                if (tx < 0 || tx % st) continue;
+                const int xo = tx / st;
+                if (xo >= Wo) continue;
+                const long po = ((long)b * Ho + yo) * Wo + xo;
                 const int code = dy * k + dx;
                 float g[EPV];
                 vec_unpack<T>(*(const uint4*)(a + po * d.lda + c), g);
@@ -610,7 +618,7 @@ extern "C" int dyk_upsample2x_bwd(const DykEwDesc* d, void* stream) {
 extern "C" int dyk_maxpool_fwd(const DykEwDesc* d, uint8_t* argmax, void* stream) {
     const int rc = check_ew(d, false);
     if (rc) return rc;
-    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0 || d->k > 15 || !(d->k & 1)) return DYK_ERR_ARG;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0 || d->k > 15 || d->slots < 0 || d->slots > 8) return DYK_ERR_ARG;
     const int grid = ew_grid((long)d->B * d->H * d->W * (d->C / epv_of(d->dtype)));
     DISPATCH_T(maxpool_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, argmax);
     return DYK_OK;
@@ -619,7 +627,7 @@ extern "C" int dyk_maxpool_fwd(const DykEwDesc* d, uint8_t* argmax, void* stream
 extern "C" int dyk_maxpool_bwd(const DykEwDesc* d, const uint8_t* argmax, void* stream) {
     const int rc = check_ew(d, false);
     if (rc) return rc;
-    if (!argmax || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0 || d->k > 15 || !(d->k & 1)) return DYK_ERR_ARG;
+    if (!argmax || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0 || d->k > 15 || d->slots < 0 || d->slots > 8) return DYK_ERR_ARG;
     const int grid = ew_grid((long)d->B * d->H * d->W * (d->C / epv_of(d->dtype)));
     DISPATCH_T(maxpool_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, argmax);
     return DYK_OK;

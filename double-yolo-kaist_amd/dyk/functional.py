@@ -128,11 +128,14 @@ def conv_bn_act(x, conv, bn, act, training):
     return ops.to_nchw(z, C=cout)
 
 
-def maxpool(x, k):
+def maxpool(x, k, stride=1):
     xd = _nhwc(x)
     B, H, W, C = xd.shape
-    z = torch.empty_like(xd)
-    ops.call("dyk_maxpool_fwd", ops.ew_desc(a=xd, out=z, B=B, H=H, W=W, k=k), None)
+    pad = (k - 1) // 2
+    z = torch.empty((B, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, C), dtype=xd.dtype, device=xd.device)
+    d = ops.ew_desc(a=xd, out=z, B=B, H=H, W=W, k=k)
+    d.slots = stride
+    ops.call("dyk_maxpool_fwd", d, None)
     return ops.to_nchw(z)
 
 

@@ -643,15 +643,18 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             x_in = cur
             consume(x_in)
             k, stride = m["size"], m["stride"]
-            if stride != 1:
-                raise NotImplementedError("[maxpool] stride %d" % stride)
-            z = alloc_out(i, B, x_in.H, x_in.W, x_in.C)
+            if not (1 <= k <= 15 and 1 <= stride <= 8):
+                raise NotImplementedError("[maxpool] size %s stride %s" % (k, stride))
+            mp = (k - 1) // 2                                   # nn.MaxPool2d(k, stride, padding=(k-1)//2), models.py:91-94
+            Hp, Wp = (x_in.H + 2 * mp - k) // stride + 1, (x_in.W + 2 * mp - k) // stride + 1
+            z = alloc_out(i, B, Hp, Wp, x_in.C)
             amax = new_ws(x_in.npix * x_in.C) if training else None
             pd = ew_desc(a=x_in, out=z, Bn=B, Hn=x_in.H, Wn=x_in.W, k=k)
+            pd.slots = stride
             if amax is not None:
                 later(lambda pd=pd, amax=amax: setattr(pd, "aux", ws.ptr(amax)))
             plan.fwd.append((L.OP_MAXPOOL_FWD, pd))
-            rec.update(x=x_in, z=z, amax=amax, k=k)
+            rec.update(x=x_in, z=z, amax=amax, k=k, stride=stride)
             cur = z
         elif t == "upsample":
             x_in = cur
@@ -1067,6 +1070,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 x_in = rec["x"]
                 gx = gref(x_in)
                 pd = ew_desc(a=dz, out=gx, Bn=B, Hn=x_in.H, Wn=x_in.W, k=rec["k"], flags=acc_flag(x_in))
+                pd.slots = rec["stride"]
                 later(lambda pd=pd, rec=rec: setattr(pd, "aux", ws.ptr(rec["amax"])))
                 plan.bwd.append((L.OP_MAXPOOL_BWD, pd))
             elif t == "upsample":

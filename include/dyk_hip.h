@@ -275,9 +275,10 @@ int dyk_wfuse_bwd_params(const float* w, const double* red, float* dw, int32_t n
 int dyk_upsample2x_fwd(const DykEwDesc* desc, void* stream);
 int dyk_upsample2x_bwd(const DykEwDesc* desc, void* stream);
 
-/* nn.MaxPool2d(k, stride=1, padding=(k-1)//2) (models.py:91-94), k odd <= 15.  argmax is a
- * uint8 [B*H*W][C] map of the window position (dy*k+dx) of the first maximum in scan order
- * (torch CPU tie rule); backward gathers dout through it (deterministic, no atomics). */
+/* nn.MaxPool2d(k, stride, padding=(k-1)//2) (models.py:91-94), k <= 15; the stride travels in `slots` (0 / 1 = stride 1,
+ * the SPP pools of the shipped cfgs).  H, W are the INPUT extents; the output is [(H+2p-k)/stride+1, (W+2p-k)/stride+1].
+ * argmax is a uint8 [B*Ho*Wo][C] map of the window position (dy*k+dx) of the first maximum in scan order
+ * (torch CPU tie rule); backward (a = dout, out = din) gathers dout through it (deterministic, no atomics). */
 int dyk_maxpool_fwd(const DykEwDesc* desc, uint8_t* argmax, void* stream);
 int dyk_maxpool_bwd(const DykEwDesc* desc, const uint8_t* argmax, void* stream);
 

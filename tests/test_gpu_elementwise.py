@@ -179,6 +179,28 @@ def test_upsample_maxpool(dtype):
         dxp = torch.empty_like(xqd)
         ops.call("dyk_maxpool_bwd", ops.ew_desc(a=dmpd, out=dxp, B=B, H=H, W=W, k=k), amax)
         _close(ops.to_nchw(dxp).cpu(), xr.grad, 4 * tol, "maxpool bwd k=%d (tie rule)" % k)
+    # strided pools (nn.MaxPool2d(k, stride, padding=(k-1)//2), models.py:91-94): stride travels in `slots`
+    for k, st in ((2, 2), (3, 2), (5, 2), (4, 1)):
+        pad = (k - 1) // 2
+        xr = xq.clone().requires_grad_(True)
+        mp_ref = F.max_pool2d(xr, k, st, pad)
+        dmp = torch.randn(mp_ref.shape, generator=g)
+        if dtype == torch.bfloat16:
+            dmp = dmp.bfloat16().float()
+        mp_ref.backward(dmp)
+        Ho, Wo = mp_ref.shape[2:]
+        mp = torch.empty((B, Ho, Wo, C), dtype=dtype, device="cuda")
+        amax = torch.zeros(B * H * W * C, dtype=torch.uint8, device="cuda")
+        fd = ops.ew_desc(a=xqd, out=mp, B=B, H=H, W=W, k=k)
+        fd.slots = st
+        ops.call("dyk_maxpool_fwd", fd, amax)
+        assert torch.equal(ops.to_nchw(mp).cpu(), mp_ref.detach()), "maxpool k=%d s=%d" % (k, st)
+        dmpd = ops.to_nhwc(dmp.cuda(), dtype)
+        dxp = torch.empty_like(xqd)
+        bd = ops.ew_desc(a=dmpd, out=dxp, B=B, H=H, W=W, k=k)
+        bd.slots = st
+        ops.call("dyk_maxpool_bwd", bd, amax)
+        _close(ops.to_nchw(dxp).cpu(), xr.grad, 4 * tol, "maxpool bwd k=%d s=%d" % (k, st))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -123,13 +123,7 @@ def test_plan_compiles_consistently(name, training):
             assert a.ptr() <= d.y < a.ptr() + a.size
 
 
-def test_unsupported_sections_fail_loudly(tmp_path):
-    """cfg features outside the built path (here: a stride-2 [maxpool]) raise instead of computing something else"""
-    from dyk.params import ParamStore
-    from dyk.plan import compile_plan
-    from models import YOLO
-    cfg = tmp_path / "tiny_kaist.cfg"
-    cfg.write_text("""[net]
+TINY_MAXPOOL_CFG = """[net]
 channels=3
 
 [convolutional]
@@ -145,6 +139,19 @@ size=2
 stride=2
 
 [convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[maxpool]
+size=3
+stride=2
+
+%s
+[convolutional]
 size=1
 stride=1
 pad=1
@@ -156,12 +163,34 @@ mask = 0,1,2
 anchors = 10,13, 16,30, 33,23
 classes=1
 num=3
-""")
+"""
+
+
+def test_strided_maxpool_compiles_and_unsupported_sections_fail_loudly(tmp_path):
+    """stride-2 [maxpool] (models.py:91-94: MaxPool2d(k, stride, padding=(k-1)//2)) is built; cfg features outside the
+    built path (here: a [shortcut] between tensors of different channel counts, layers.py:78-83) raise instead of
+    computing something else"""
+    from dyk import lib as L
+    from dyk.params import ParamStore
+    from dyk.plan import compile_plan
+    from models import YOLO
+    cfg = tmp_path / "tiny_kaist_pool.cfg"
+    cfg.write_text(TINY_MAXPOOL_CFG % "")
     m = YOLO(str(cfg))
     st = ParamStore(m)
     st.adopt(torch.device("cpu"))
+    plan = compile_plan(m, st, 1, 64, 96, torch.bfloat16, True, torch.device("cpu"), dry=True)
+    pools = [d for op, d in plan.fwd if op == L.OP_MAXPOOL_FWD]
+    assert [(d.k, d.slots, d.H, d.W) for d in pools] == [(2, 2, 64, 96), (3, 2, 32, 48)]
+    assert tuple(plan.p_out[0].shape) == (1, 3, 16, 24, 6)
+    assert [op for op, _ in plan.bwd].count(L.OP_MAXPOOL_BWD) == 2
+    bad = tmp_path / "tiny_kaist_badshortcut.cfg"
+    bad.write_text(TINY_MAXPOOL_CFG % "[convolutional]\nbatch_normalize=1\nfilters=32\nsize=1\nstride=1\npad=1\nactivation=leaky\n\n[shortcut]\nfrom=-2\nactivation=linear\n")
+    m2 = YOLO(str(bad))
+    st2 = ParamStore(m2)
+    st2.adopt(torch.device("cpu"))
     with pytest.raises(NotImplementedError):
-        compile_plan(m, st, 1, 64, 64, torch.bfloat16, False, torch.device("cpu"), dry=True)
+        compile_plan(m2, st2, 1, 64, 64, torch.bfloat16, False, torch.device("cpu"), dry=True)
 
 
 @pytest.mark.parametrize("name", [C5, MNV2])
