@@ -67,7 +67,7 @@ def conv_flops(plan, stems=True):
     return total
 
 
-def profile_plan(plan, stream, dump=None):
+def profile_plan(plan, stream, dump=None, cmds_out=None):
     """per-op-kind kernel time (ms) of one forward and one backward pass, HIP events on `stream`"""
     from dyk import lib as L
     res = {}
@@ -82,6 +82,10 @@ def profile_plan(plan, stream, dump=None):
             a = agg.setdefault(op, [0, 0.0])
             a[0] += 1
             a[1] += float(t)
+            if cmds_out is not None:
+                from cmd_roofline import cmd_model
+                label, by, fl = cmd_model(L, op, desc, plan)
+                cmds_out.append({"pass": which, "label": label, "us": float(t) * 1e3, "bytes": by, "flops": fl})
             if dump is not None and op in (L.OP_CONV, L.OP_WGRAD):
                 if op == L.OP_CONV:
                     rows.append(dict(pass_=which, op="conv", Cin=desc.Cin, Cout=desc.Cout, Hg=desc.Hg, Wg=desc.Wg, taps=desc.ntaps,
@@ -222,6 +226,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-layers", default=None, help="write per-conv-launch timings to this JSON file")
+    ap.add_argument("--dump-cmds", default=None, help="write every command's isolated time + algorithmic bytes / flops "
+                                                      "to this JSON file (tools/cmd_roofline.py reads it)")
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="train: the BASELINE metric (default).  eval: forward + decode + NMS of --cfg (SURVEY 8d, config C2)")
     args = ap.parse_args()
@@ -356,7 +362,21 @@ def main():
         if not args.no_roofline:
             plan = model.engine.plans[(B, H, W, torch.bfloat16 if args.dtype == "bf16" else torch.float32, True)]
             from dyk import lib as L
-            prof = profile_plan(plan, torch.cuda.current_stream().cuda_stream, args.dump_layers)
+            cmds_out = [] if args.dump_cmds else None
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            prof = profile_plan(plan, torch.cuda.current_stream().cuda_stream, args.dump_layers, cmds_out)
+            if cmds_out is not None:
+                # dependency lists (indices within the pass) for the critical-path figure of tools/cmd_roofline.py
+                from dyk import sched
+                mem = sched.Memory(plan, plan.store)
+                k = 0
+                for which in ("fwd", "bwd"):
+                    cmds = plan.fwd if which == "fwd" else plan.bwd
+                    for dl in sched.dependencies(cmds, mem, plan):
+                        cmds_out[k]["deps"] = dl
+                        k += 1
+                with open(args.dump_cmds, "w") as f:
+                    json.dump(cmds_out, f)
             f1_all = conv_flops(plan)
             f1 = conv_flops(plan, stems=False)          # what the implicit-GEMM family computes
             ig_ms = prof["fwd"].get(L.OP_CONV, [0, 0.0])[1] + prof["bwd"].get(L.OP_CONV, [0, 0.0])[1]

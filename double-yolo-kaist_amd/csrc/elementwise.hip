@@ -146,12 +146,16 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(DykEwDesc d) {   //
 // ------------------------------------------------------------------ max pool k x k, stride 1, pad (k-1)/2
 // idx (uint8, [npix][C]) holds the window position dy*k+dx of the first maximum in scan order
 // (torch CPU max_pool2d keeps the first element for which val > max, so ties go to the earliest).
-template <typename T>
+// K = compile-time window (0: runtime d.k).  The taps of one window row are loaded in one batch of K unconditional
+// loads (clamped addresses, a validity bit per tap): a load behind a bounds branch is waited for on the spot, which made
+// the 13 x 13 pool of the SPP block a chain of 169 dependent memory latencies (90 us for a 10 MB tensor).
+template <typename T, int K>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(DykEwDesc d, uint8_t* __restrict__ idx) {
     // nn.MaxPool2d(k, stride, padding=(k-1)//2) (reference models.py:91-94); stride = d.slots (0 / 1: stride 1, the SPP pools)
     constexpr int EPV = ElemTraits<T>::EPV;
+    constexpr int KB = K > 0 ? K : 1;
     const int CV = d.C / EPV;
-    const int k = d.k, pad = (k - 1) / 2, st = d.slots > 1 ? d.slots : 1;
+    const int k = K > 0 ? K : d.k, pad = (k - 1) / 2, st = d.slots > 1 ? d.slots : 1;
     const int Ho = (d.H + 2 * pad - k) / st + 1, Wo = (d.W + 2 * pad - k) / st + 1;
     const long total = (long)d.B * Ho * Wo * CV;
     const T* __restrict__ a = (const T*)d.a;
@@ -170,15 +174,25 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(DykEwDesc d, uint8_t* 
         for (int dy = 0; dy < k; ++dy) {
             const int yy = y * st + dy - pad;
             if (yy < 0 || yy >= d.H) continue;
-            for (int dx = 0; dx < k; ++dx) {
-                const int xx = x * st + dx - pad;
-                if (xx < 0 || xx >= d.W) continue;
-                float t[EPV];
-                vec_unpack<T>(*(const uint4*)(a + (((long)b * d.H + yy) * d.W + xx) * d.lda + c), t);
+            const T* row = a + ((long)b * d.H + yy) * d.W * d.lda + c;
+            for (int dx0 = 0; dx0 < k; dx0 += KB) {
+                uint4 raw[KB];
 #pragma unroll
-                for (int j = 0; j < EPV; ++j)
-                    if (first || t[j] > m[j] || t[j] != t[j]) { m[j] = t[j]; mi[j] = dy * k + dx; }
-                first = false;
+                for (int u = 0; u < KB; ++u) {
+                    const int xx = x * st + dx0 + u - pad;
+                    raw[u] = *(const uint4*)(row + (long)(xx < 0 ? 0 : (xx >= d.W ? d.W - 1 : xx)) * d.lda);
+                }
+#pragma unroll
+                for (int u = 0; u < KB; ++u) {
+                    const int xx = x * st + dx0 + u - pad;
+                    if (xx < 0 || xx >= d.W) continue;
+                    float t[EPV];
+                    vec_unpack<T>(raw[u], t);
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j)
+                        if (first || t[j] > m[j] || t[j] != t[j]) { m[j] = t[j]; mi[j] = dy * k + dx0 + u; }
+                    first = false;
+                }
             }
         }
         *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(m);
@@ -189,12 +203,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(DykEwDesc d, uint8_t* 
     }
 }
 
-template <typename T>
+template <typename T, int K>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(DykEwDesc d, const uint8_t* __restrict__ idx) {
     // a = dout [B,Ho,Wo,C], out = din [B,H,W,C]; every input pixel gathers from the outputs whose window holds it
+    // (window rows in batches of K gradient + K argmax loads, as in the forward kernel)
     constexpr int EPV = ElemTraits<T>::EPV;
+    constexpr int KB = K > 0 ? K : 1;
     const int CV = d.C / EPV;
-    const int k = d.k, pad = (k - 1) / 2, st = d.slots > 1 ? d.slots : 1;
+    const int k = K > 0 ? K : d.k, pad = (k - 1) / 2, st = d.slots > 1 ? d.slots : 1;
     const int Ho = (d.H + 2 * pad - k) / st + 1, Wo = (d.W + 2 * pad - k) / st + 1;
     const long total = (long)d.B * d.H * d.W * CV;
     const T* __restrict__ a = (const T*)d.a;
@@ -215,19 +231,33 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(DykEwDesc d, const uin
             if (ty < 0 || ty % st) continue;
             const int yo = ty / st;
             if (yo >= Ho) continue;
-            for (int dx = 0; dx < k; ++dx) {
-                const int tx = x - dx + pad;
-                if (tx < 0 || tx % st) continue;
-                const int xo = tx / st;
-                if (xo >= Wo) continue;
-                const long po = ((long)b * Ho + yo) * Wo + xo;
-                const int code = dy * k + dx;
-                float g[EPV];
-                vec_unpack<T>(*(const uint4*)(a + po * d.lda + c), g);
-                const uint8_t* ip = idx + po * d.C + c;
+            const long prow = ((long)b * Ho + yo) * Wo;
+            for (int dx0 = 0; dx0 < k; dx0 += KB) {
+                uint4 graw[KB];
+                uint32_t iraw[KB][EPV / 4];
 #pragma unroll
-                for (int j = 0; j < EPV; ++j)
-                    if (ip[j] == code) s[j] += g[j];
+                for (int u = 0; u < KB; ++u) {
+                    const int tx = x - (dx0 + u) + pad;
+                    const int xo = tx / st;
+                    const bool ok = tx >= 0 && tx % st == 0 && xo < Wo;
+                    const long po = prow + (ok ? xo : 0);
+                    graw[u] = *(const uint4*)(a + po * d.lda + c);
+                    const uint32_t* ip = (const uint32_t*)(idx + po * d.C + c);
+#pragma unroll
+                    for (int w = 0; w < EPV / 4; ++w) iraw[u][w] = ip[w];
+                }
+#pragma unroll
+                for (int u = 0; u < KB; ++u) {
+                    const int tx = x - (dx0 + u) + pad;
+                    const int xo = tx / st;
+                    if (!(tx >= 0 && tx % st == 0 && xo < Wo)) continue;
+                    const uint32_t code = (uint32_t)(dy * k + dx0 + u);
+                    float g[EPV];
+                    vec_unpack<T>(graw[u], g);
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j)
+                        if (((iraw[u][j / 4] >> (8 * (j % 4))) & 0xffu) == code) s[j] += g[j];
+                }
             }
         }
         if (accum) {
@@ -241,7 +271,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(DykEwDesc d, const uin
 }
 
 // ------------------------------------------------------------------ squeeze-excitation
-// pooled[b][c] = alpha * sum_hw a[b,p,c] * (b ? b[b,p,c] : 1)        grid (CV groups, B)
+// pooled[b][c] = alpha * sum_hw a[b,p,c] * (b ? b[b,p,c] : 1)        grid (CV groups, B, HS)
+// HS = gridDim.z > 1: the pixels of an image are split over HS workgroups which store unscaled partial sums
+// part[z][b][c]; se_pool_fold_kernel adds them in z order (bit-reproducible, no atomics).  A (C = 120, 64 x 80, B = 32)
+// tensor is otherwise reduced by 32 workgroups -- 0.7 TB/s.
 template <typename T>
 __global__ __launch_bounds__(256) void se_pool_kernel(DykEwDesc d, float* __restrict__ pooled, int CVB) {
     constexpr int EPV = ElemTraits<T>::EPV;
@@ -264,13 +297,16 @@ __global__ __launch_bounds__(256) void se_pool_kernel(DykEwDesc d, float* __rest
         // (32..192 workgroups per launch: nothing else hides it)
         constexpr int U = 4;
         const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-        for (int p0 = ty; p0 < HW; p0 += PY * U) {
+        const int chunk = (HW + (int)gridDim.z - 1) / (int)gridDim.z;
+        const int pbeg = (int)blockIdx.z * chunk, pend = min(HW, pbeg + chunk);
+        for (int p0 = pbeg + ty; p0 < pend; p0 += PY * U) {
             uint4 va[U], vb[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int p = p0 + u * PY;
-                const long pp = (long)b * HW + (p < HW ? p : 0);
-                va[u] = p < HW ? *(const uint4*)(a + pp * d.lda + c) : z4;          // (zero contributes nothing)
+                const long pp = (long)b * HW + (p < pend ? p : pbeg);
+                va[u] = *(const uint4*)(a + pp * d.lda + c);
+                if (p >= pend) va[u] = z4;                                          // (zero contributes nothing)
                 if (bb) vb[u] = *(const uint4*)(bb + pp * d.ldb + c);
             }
 #pragma unroll
@@ -299,21 +335,48 @@ __global__ __launch_bounds__(256) void se_pool_kernel(DykEwDesc d, float* __rest
 #pragma unroll
             for (int j = 0; j < EPV; ++j) s[j] += o[j];
         }
+        if (gridDim.z > 1) {
+            float* part = (float*)d.aux2 + ((long)blockIdx.z * d.B + b) * d.C + c;
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) pooled[(long)b * d.C + c + j] = s[j] * d.alpha;
+            for (int j = 0; j < EPV; ++j) part[j] = s[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) pooled[(long)b * d.C + c + j] = s[j] * d.alpha;
+        }
     }
+}
+__global__ __launch_bounds__(256) void se_pool_fold_kernel(const float* __restrict__ part, float* __restrict__ pooled, int n,
+                                                           int HS, float alpha) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v[DYK_SE_POOL_SPLITS];
+#pragma unroll
+    for (int z = 0; z < DYK_SE_POOL_SPLITS; ++z) v[z] = part[(long)(z < HS ? z : 0) * n + i];
+    float t = 0.f;
+#pragma unroll
+    for (int z = 0; z < DYK_SE_POOL_SPLITS; ++z) t += z < HS ? v[z] : 0.f;
+    pooled[i] = t * alpha;
 }
 
 // dot(W[row], v) for the SE matrix-vector products: a 16-lane group per output row (4 rows per wave in flight),
 // float4 loads, DPP row reduction -- the wave-per-row version spent its time in 6-step ds_bpermute reductions.
 // n is a multiple of 4 (channel counts are multiples of 8); every lane of the group returns the sum.
 __device__ inline float dot16(const float* __restrict__ wrow, const float* v, int n, int l16) {
-    float acc = 0.f;
-    for (int i = l16 * 4; i < n; i += 64) {
-        const float4 w4 = *(const float4*)(wrow + i);
-        acc += w4.x * v[i] + w4.y * v[i + 1] + w4.z * v[i + 2] + w4.w * v[i + 3];
+    // four 16-byte weight loads in flight per lane and trip (clamped address, zero weight past the end): the one-load
+    // loop was a chain of n/64 dependent L2 latencies per output row
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int i = l16 * 4; i < n; i += 256) {
+        const int i1 = i + 64, i2 = i + 128, i3 = i + 192;
+        const int j1 = i1 < n ? i1 : i, j2 = i2 < n ? i2 : i, j3 = i3 < n ? i3 : i;
+        const float4 w0 = *(const float4*)(wrow + i), w1 = *(const float4*)(wrow + j1), w2 = *(const float4*)(wrow + j2),
+                     w3 = *(const float4*)(wrow + j3);
+        const float m1 = i1 < n ? 1.f : 0.f, m2 = i2 < n ? 1.f : 0.f, m3 = i3 < n ? 1.f : 0.f;
+        a0 += w0.x * v[i] + w0.y * v[i + 1] + w0.z * v[i + 2] + w0.w * v[i + 3];
+        a1 += m1 * (w1.x * v[j1] + w1.y * v[j1 + 1] + w1.z * v[j1 + 2] + w1.w * v[j1 + 3]);
+        a2 += m2 * (w2.x * v[j2] + w2.y * v[j2 + 1] + w2.z * v[j2 + 2] + w2.w * v[j2 + 3]);
+        a3 += m3 * (w3.x * v[j3] + w3.y * v[j3 + 1] + w3.z * v[j3 + 2] + w3.w * v[j3 + 3]);
     }
-    return row16_sum(acc);
+    return row16_sum((a0 + a1) + (a2 + a3));
 }
 
 // one block per image: h = relu(W1 pooled + b1); s = hardsigmoid(W2 h + b2)   (layers.py:185-189)
@@ -370,6 +433,7 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(DykSeFcDesc d) {
         const int jt = threadIdx.x & 255, rg = threadIdx.x >> 8, nrg = blockDim.x >> 8;
         for (int j = jt; j < d.Cs; j += 256) {
             float acc = 0.f;
+#pragma unroll 8
             for (int c = rg; c < d.C; c += nrg) acc += d.w2[(long)c * d.Cs + j] * dt2[c];
             atomicAdd(dt1 + j, acc);               // LDS, 4-way
         }
@@ -388,6 +452,7 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(DykSeFcDesc d) {
     for (int c = threadIdx.x; c < d.C; c += blockDim.x) wsd2[c] = dt2[c];
     for (int c = threadIdx.x; c < d.C; c += blockDim.x) {      // coalesced over c, short loop over Cs
         float acc = 0.f;
+#pragma unroll 8
         for (int j = 0; j < d.Cs; ++j) acc += d.w1[(long)j * d.C + c] * dt1[j];
         d.dpooled[(long)b * d.C + c] = acc;
     }
@@ -424,33 +489,60 @@ __global__ __launch_bounds__(256) void se_fc_wgrad_kernel(DykSeFcDesc d) {
 }
 
 // out[b,p,c] = a[b,p,c]*p0[b*C+c] (+ p1[b*C+c]*alpha)      (SE scale; backward apply with p1 = dpooled, alpha = 1/HW)
+// block = (CVB channel vectors) x (PY pixel lanes), grid (channel groups, pixel groups, B): the per-(image, channel)
+// factors sit in registers, no integer division per element, four pixels in flight per thread (clamped addresses).
 template <typename T>
-__global__ __launch_bounds__(256) void se_scale_kernel(DykEwDesc d) {
+__global__ __launch_bounds__(256) void se_scale_kernel(DykEwDesc d, int CVB) {
     constexpr int EPV = ElemTraits<T>::EPV;
-    const int CV = d.C / EPV;
+    const int PY = 256 / CVB;
+    const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
+    const int cv = blockIdx.x * CVB + tx;
+    if (cv * EPV >= d.C) return;
+    const int c = cv * EPV;
+    const int b = blockIdx.z;
     const int HW = d.H * d.W;
-    const long total = (long)d.B * HW * CV;
-    const T* __restrict__ a = (const T*)d.a;
-    T* __restrict__ o = (T*)d.out;
+    float f0[EPV], f1[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; j += 4) {
+        const float4 q = *(const float4*)(d.p0 + (long)b * d.C + c + j);
+        f0[j] = q.x; f0[j + 1] = q.y; f0[j + 2] = q.z; f0[j + 3] = q.w;
+        if (d.p1) {
+            const float4 r = *(const float4*)(d.p1 + (long)b * d.C + c + j);
+            f1[j] = r.x * d.alpha; f1[j + 1] = r.y * d.alpha; f1[j + 2] = r.z * d.alpha; f1[j + 3] = r.w * d.alpha;
+        } else {
+            f1[j] = f1[j + 1] = f1[j + 2] = f1[j + 3] = 0.f;
+        }
+    }
+    const T* __restrict__ a = (const T*)d.a + (long)b * HW * d.lda + c;
+    T* __restrict__ o = (T*)d.out + (long)b * HW * d.ldo + c;
     const bool accum = d.flags & DYK_EW_ACCUM;
-    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
-        const long p = v / CV;
-        const int c = (int)(v - p * CV) * EPV;
-        const int b = (int)(p / HW);
-        float x[EPV];
-        vec_unpack<T>(*(const uint4*)(a + p * d.lda + c), x);
+    constexpr int U = 4;
+    const int pstep = (int)gridDim.y * PY;
+    for (int p0 = (int)blockIdx.y * PY + ty; p0 < HW; p0 += pstep * U) {
+        uint4 va[U], vo[U];
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) {
-            x[j] *= d.p0[(long)b * d.C + c + j];
-            if (d.p1) x[j] += d.p1[(long)b * d.C + c + j] * d.alpha;
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + u * pstep;
+            const long pp = p < HW ? p : p0;
+            va[u] = *(const uint4*)(a + pp * d.lda);
+            if (accum) vo[u] = *(const uint4*)(o + pp * d.ldo);
         }
-        if (accum) {
-            float y[EPV];
-            vec_unpack<T>(*(const uint4*)(o + p * d.ldo + c), y);
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) x[j] += y[j];
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + u * pstep;
+            if (p >= HW) break;
+            float x[EPV];
+            vec_unpack<T>(va[u], x);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) x[j] = x[j] * f0[j] + f1[j];
+            if (accum) {
+                float y[EPV];
+                vec_unpack<T>(vo[u], y);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) x[j] += y[j];
+            }
+            *(uint4*)(o + (long)p * d.ldo) = vec_pack<T>(x);
         }
-        *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(x);
     }
 }
 
@@ -489,22 +581,34 @@ __global__ void head_permute_bwd_kernel(const float* __restrict__ dp, T* __restr
     }
 }
 // bias gradient of the head conv: db[c] += sum_{b,y,x} dp[b, c/no, y, x, c%no]
-__global__ __launch_bounds__(256) void head_bias_grad_kernel(const float* __restrict__ dp, float* __restrict__ db, int B,
-                                                             int ny, int nx, int na, int no) {
+// One 1024-thread workgroup per channel (fixed summation order: bit-reproducible), four independent loads per thread and
+// trip -- the 256-thread form with a 64-bit division per element took 140 us for the 64 x 80 head at batch 32.
+__global__ __launch_bounds__(1024) void head_bias_grad_kernel(const float* __restrict__ dp, float* __restrict__ db, int B,
+                                                              int ny, int nx, int na, int no) {
     const int c = blockIdx.x;
     const int a = c / no, o = c - a * no;
-    const long cells = (long)ny * nx;
-    float s = 0.f;
-    for (long i = threadIdx.x; i < (long)B * cells; i += blockDim.x) {
-        const int b = (int)(i / cells);
-        const long r = i - b * cells;
-        s += dp[(((long)b * na + a) * cells + r) * no + o];
+    const int cells = ny * nx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* src = dp + ((long)b * na + a) * cells * no + o;
+        int r = threadIdx.x;
+        for (; r + 3072 < cells; r += 4096) {
+            const float v0 = src[(long)r * no], v1 = src[(long)(r + 1024) * no], v2 = src[(long)(r + 2048) * no],
+                        v3 = src[(long)(r + 3072) * no];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; r < cells; r += 1024) s0 += src[(long)r * no];
     }
-    __shared__ float ws[4];
-    s = wave_sum(s);
+    __shared__ float ws[16];
+    const float s = wave_sum((s0 + s1) + (s2 + s3));
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) db[c] += ws[0] + ws[1] + ws[2] + ws[3];
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += ws[w];
+        db[c] += t;
+    }
 }
 
 // ------------------------------------------------------------------ first-layer patch gather
@@ -615,12 +719,30 @@ extern "C" int dyk_upsample2x_bwd(const DykEwDesc* d, void* stream) {
     return DYK_OK;
 }
 
+#define MAXPOOL_K(kern, KK, arg)                                                                                  \
+    do {                                                                                                         \
+        if (d->dtype == DYK_BF16) hipLaunchKernelGGL((kern<bf16_t, KK>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, arg); \
+        else hipLaunchKernelGGL((kern<float, KK>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, arg);      \
+    } while (0)
+#define MAXPOOL_DISPATCH(kern, arg)                                                                               \
+    do {                                                                                                         \
+        switch (d->k) {                                                                                          \
+        case 2: MAXPOOL_K(kern, 2, arg); break;                                                                  \
+        case 3: MAXPOOL_K(kern, 3, arg); break;                                                                  \
+        case 5: MAXPOOL_K(kern, 5, arg); break;                                                                  \
+        case 9: MAXPOOL_K(kern, 9, arg); break;                                                                  \
+        case 13: MAXPOOL_K(kern, 13, arg); break;                                                                \
+        default: MAXPOOL_K(kern, 0, arg); break;                                                                 \
+        }                                                                                                        \
+        DYK_LAUNCH_CHECK();                                                                                      \
+    } while (0)
+
 extern "C" int dyk_maxpool_fwd(const DykEwDesc* d, uint8_t* argmax, void* stream) {
     const int rc = check_ew(d, false);
     if (rc) return rc;
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0 || d->k > 15 || d->slots < 0 || d->slots > 8) return DYK_ERR_ARG;
     const int grid = ew_grid((long)d->B * d->H * d->W * (d->C / epv_of(d->dtype)));
-    DISPATCH_T(maxpool_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, argmax);
+    MAXPOOL_DISPATCH(maxpool_fwd_kernel, argmax);
     return DYK_OK;
 }
 
@@ -629,7 +751,7 @@ extern "C" int dyk_maxpool_bwd(const DykEwDesc* d, const uint8_t* argmax, void* 
     if (rc) return rc;
     if (!argmax || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0 || d->k > 15 || d->slots < 0 || d->slots > 8) return DYK_ERR_ARG;
     const int grid = ew_grid((long)d->B * d->H * d->W * (d->C / epv_of(d->dtype)));
-    DISPATCH_T(maxpool_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d, argmax);
+    MAXPOOL_DISPATCH(maxpool_bwd_kernel, argmax);
     return DYK_OK;
 }
 
@@ -640,7 +762,21 @@ extern "C" int dyk_se_pool(const DykEwDesc* d, float* pooled, void* stream) {
     const int CV = d->C / epv_of(d->dtype);
     int CVB = 1;
     while (CVB < CV && CVB < 16) CVB <<= 1;
-    DISPATCH_T(se_pool_kernel, dim3((CV + CVB - 1) / CVB, d->B), dim3(256), 0, (hipStream_t)stream, *d, pooled, CVB);
+    const int gx = (CV + CVB - 1) / CVB, PY = 256 / CVB;
+    // split the pixels of an image when the (channel groups x images) grid leaves the chip idle and a scratch buffer
+    // (aux2: DYK_SE_POOL_SPLITS * B * C floats) is there; >= 8 pixel rows per thread stay in every part
+    int HS = 1;
+    if (d->aux2) {
+        const long hw = (long)d->H * d->W;
+        while (HS < DYK_SE_POOL_SPLITS && (long)gx * d->B * HS < 1024 && hw / (HS * 2) >= (long)PY * 8) HS <<= 1;
+    }
+    DISPATCH_T(se_pool_kernel, dim3(gx, d->B, HS), dim3(256), 0, (hipStream_t)stream, *d, pooled, CVB);
+    if (HS > 1) {
+        const int n = d->B * d->C;
+        hipLaunchKernelGGL(se_pool_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)d->aux2,
+                           pooled, n, HS, d->alpha);
+        DYK_LAUNCH_CHECK();
+    }
     return DYK_OK;
 }
 
@@ -670,8 +806,16 @@ extern "C" int dyk_se_scale(const DykEwDesc* d, void* stream) {
     const int rc = check_ew(d, false);
     if (rc) return rc;
     if (!d->p0 || d->B <= 0 || d->H <= 0 || d->W <= 0) return DYK_ERR_ARG;
-    const int grid = ew_grid((long)d->B * d->H * d->W * (d->C / epv_of(d->dtype)));
-    DISPATCH_T(se_scale_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    const int CV = d->C / epv_of(d->dtype);
+    int CVB = 1;
+    while (CVB < CV && CVB < 32) CVB <<= 1;
+    const int PY = 256 / CVB, gx = (CV + CVB - 1) / CVB;
+    const long hw = (long)d->H * d->W;
+    long gy = (hw + (long)PY * 8 - 1) / ((long)PY * 8);          // >= 8 pixels per thread
+    const long cap = 4096 / ((long)gx * d->B) > 0 ? 4096 / ((long)gx * d->B) : 1;
+    if (gy > cap) gy = cap;
+    if (gy < 1) gy = 1;
+    DISPATCH_T(se_scale_kernel, dim3(gx, (int)gy, d->B), dim3(256), 0, (hipStream_t)stream, *d, CVB);
     return DYK_OK;
 }
 
@@ -696,7 +840,7 @@ extern "C" int dyk_head_permute_bwd(const float* dp, void* dy, float* dbias, int
         return DYK_ERR_ARG;
     DYK_LAUNCH_CHECK();
     if (dbias) {
-        hipLaunchKernelGGL(head_bias_grad_kernel, dim3(na * no), dim3(256), 0, (hipStream_t)stream, dp, dbias, B, ny, nx, na, no);
+        hipLaunchKernelGGL(head_bias_grad_kernel, dim3(na * no), dim3(1024), 0, (hipStream_t)stream, dp, dbias, B, ny, nx, na, no);
         DYK_LAUNCH_CHECK();
     }
     return DYK_OK;

@@ -15,6 +15,7 @@ ACT_CODES = {"linear": 0, "leaky": 1, "mish": 2, "relu": 3, "relu6": 4, "hard-si
 EPI_AFFINE, EPI_RESIDUAL, EPI_STATS, EPI_ACCUM, EPI_OUT_F32, EPI_BNBWD, EPI_ADDEND = 1, 2, 4, 8, 16, 32, 64
 EW_ACCUM = 1
 MAX_TAPS = 25
+SE_POOL_SPLITS = 16        # DYK_SE_POOL_SPLITS (include/dyk_hip.h): partial-sum planes of the pixel-split SE pool
 
 # op codes of DykCommand (include/dyk_hip.h)
 (OP_CONV, OP_WGRAD, OP_BN_FINALIZE, OP_BN_ACT_FWD, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_AXPBY, OP_DOT,

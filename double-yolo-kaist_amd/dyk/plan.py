@@ -624,7 +624,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             scale = new_ws(B * C * 4)
             z = alloc_out(i, B, x_in.H, x_in.W, C)
             pd = ew_desc(a=x_in, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W, alpha=1.0 / (x_in.H * x_in.W))
-            later(lambda pd=pd, pooled=pooled: setattr(pd, "aux", ws.ptr(pooled)))
+            pparts = new_ws(L.SE_POOL_SPLITS * B * C * 4)     # partial sums of the pixel-split reduction (dyk_se_pool)
+            later(lambda pd=pd, pooled=pooled, pparts=pparts: (setattr(pd, "aux", ws.ptr(pooled)), setattr(pd, "aux2", ws.ptr(pparts))))
             plan.fwd.append((L.OP_SE_POOL, pd))
             pre = "module_list.%d." % i
             fd = L.DykSeFcDesc()
@@ -1044,7 +1045,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 dpooled = new_ws(B * C * 4)
                 fcws = new_ws(B * (C + 2 * Cs) * 4)
                 pd = ew_desc(a=dz, b=x_in, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W, alpha=1.0)
-                later(lambda pd=pd, dscale=dscale: setattr(pd, "aux", ws.ptr(dscale)))
+                pparts = new_ws(L.SE_POOL_SPLITS * B * C * 4)
+                later(lambda pd=pd, dscale=dscale, pparts=pparts: (setattr(pd, "aux", ws.ptr(dscale)), setattr(pd, "aux2", ws.ptr(pparts))))
                 plan.bwd.append((L.OP_SE_POOL, pd))
                 pre = "module_list.%d." % i
                 fd = L.DykSeFcDesc()
@@ -1098,6 +1100,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         stats_memset.n, stats_memset.i[0] = max(st_arena.size, 256), 0
     for fn in pending:
         fn()
+    plan.training = training
     if not dry and os.environ.get("DYK_AUTOTUNE", "1") != "0":
         autotune(plan, _TUNE_CACHE)
     plan.part = None
@@ -1297,6 +1300,7 @@ def autotune(plan, cache=None):
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     cache = cache if cache is not None else {}
     groups = {}
+    scratch = [None]                      # partial planes of the weight-gradient trials
     for (op, d) in plan.fwd + plan.bwd:
         if op == L.OP_CONV:
             key = ("c", d.dtype, d.B, d.Cin, d.Cout, d.Hg, d.Wg, d.ntaps, d.isy, d.osy,
@@ -1318,8 +1322,26 @@ def autotune(plan, cache=None):
                 if os.environ.get("DYK_WGRAD_CANDS"):
                     cands = [int(c, 0) for c in os.environ["DYK_WGRAD_CANDS"].split(",")]
             times = []
+            planes_on = (key[0] == "w" and plan.training and os.environ.get("DYK_WGRAD_PARTIALS", "1") != "0"
+                         and not os.environ.get("DYK_WGRAD_TUNE_ATOMIC"))    # (analysis: the round-1 way)
             for c in cands:
                 d.tune = c
+                if planes_on:
+                    # time the configuration the way the step runs it: every K split stores its own partial plane
+                    # (_setup_wgrad_partials below) -- the atomic form penalises exactly the many-split shapes the
+                    # plane form is good at -- plus the cost of folding that many planes (dyk_grad_reduce, ~2.7 TB/s)
+                    splits = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
+                    plane = d.ntaps * d.Cout * (d.lddw if d.lddw > 0 else d.Cin)
+                    if splits >= 2 and plane % 4 == 0:
+                        need = splits * plane
+                        if scratch[0] is None or scratch[0].numel() < need:
+                            scratch[0] = None
+                            scratch[0] = torch.empty(need, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+                        d.part, d.part_stride, d.splits = scratch[0].data_ptr(), plane, splits
+                        t = _time_launch(fn, d, stream) + (splits + 1) * plane * 4 / 2.7e9
+                        d.part, d.part_stride, d.splits = None, 0, 0
+                        times.append(t)
+                        continue
                 times.append(_time_launch(fn, d, stream))
             best = cands[times.index(min(times))]
             cache[key] = best

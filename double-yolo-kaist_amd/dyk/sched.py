@@ -210,6 +210,8 @@ def accesses(op, d, mem, plan):
             wr(mem.interval(_v(d.aux), d.C * 4)); wr(mem.interval(_v(d.aux2), d.C * 4))
         elif op in (L.OP_MAXPOOL_FWD, L.OP_SE_POOL):
             wr(V(d.aux))
+            if op == L.OP_SE_POOL:
+                wr(V(d.aux2))
         elif op == L.OP_MAXPOOL_BWD:
             rd(V(d.aux))
         if d.out:

@@ -285,7 +285,9 @@ int dyk_maxpool_bwd(const DykEwDesc* desc, const uint8_t* argmax, void* stream);
 /* SqueezeExcitation (layers.py:175-190).
  *   dyk_se_pool : pooled[b][c] = alpha * sum_hw a[b,hw,c] * (b ? b[b,hw,c] : 1)
  *                 (alpha = 1/HW gives adaptive_avg_pool2d; with b = dz it is the gradient of the
- *                 per-channel scale)
+ *                 per-channel scale).  desc->aux2 (optional): scratch of DYK_SE_POOL_SPLITS * B * C floats;
+ *                 with it the pixels of an image are reduced by up to DYK_SE_POOL_SPLITS workgroups whose
+ *                 partial sums are folded in a fixed order (same result from run to run)
  *   dyk_se_fc_fwd : scale = hardsigmoid(W2 relu(W1 pooled + b1) + b2), one block per image
  *   dyk_se_scale  : out[b,hw,c] = a[b,hw,c]*p0[b*C+c] (+ alpha*p1[b*C+c])
  *   dyk_se_fc_bwd : from dscale = d(loss)/d(scale) produce dpooled and accumulate dW1,db1,dW2,db2.  Two launches:
@@ -304,6 +306,7 @@ typedef struct DykSeFcDesc {
     float* ws;             /* bwd scratch, B*(C + 2*Cs) floats: h [B][Cs] | dt1 [B][Cs] | dt2 [B][C] */
     int32_t B, C, Cs;
 } DykSeFcDesc;
+#define DYK_SE_POOL_SPLITS 16
 int dyk_se_pool(const DykEwDesc* desc, float* pooled, void* stream);
 int dyk_se_fc_fwd(const DykSeFcDesc* desc, void* stream);
 int dyk_se_fc_bwd(const DykSeFcDesc* desc, void* stream);

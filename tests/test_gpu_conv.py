@@ -173,6 +173,10 @@ DW_CASES = [
     (2, 200, 9, 11, 3, 2, 1),       # odd size stride 2
     (1, 960, 4, 5, 5, 1, 2),
     (1, 40, 10, 10, 5, 1, 1),       # DepthwiseSeparableConv2d keeps padding 1 for any kernel size (layers.py:223)
+    (2, 16, 40, 36, 3, 1, 1),       # LDS-tiled kernel: 2 channel vectors, 32-row tiles, ragged tile grid
+    (1, 24, 50, 37, 5, 1, 2),       # 3 channel vectors per workgroup (odd group width), several tiles per image
+    (1, 184, 20, 19, 5, 1, 2),      # 23 channel vectors: three groups of 8, the last one partly filled
+    (2, 8, 70, 18, 3, 1, 1),        # a single channel vector (64-row tiles)
 ]
 
 

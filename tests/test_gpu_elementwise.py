@@ -252,6 +252,35 @@ def test_squeeze_excitation_fwd_bwd(dtype):
     _close(ops.to_nchw(dx).cpu(), xr.grad, tol, "se dx")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_se_pool_pixel_split_matches_single_stage(dtype):
+    """dyk_se_pool with the aux2 scratch splits the pixels of an image over several workgroups (partial sums folded in a
+    fixed order): same values as the one-workgroup reduction up to fp32 summation order, identical from run to run"""
+    from dyk import ops
+    from dyk.lib import SE_POOL_SPLITS
+    B, C, H, W = 4, 120, 64, 80
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(B, C, H, W, generator=g)
+    y = torch.randn(B, C, H, W, generator=g)
+    xd, yd = ops.to_nhwc(x.cuda(), dtype), ops.to_nhwc(y.cuda(), dtype)
+    xq, yq = ops.to_nchw(xd).cpu().double(), ops.to_nchw(yd).cpu().double()
+    for second, ref, alpha in ((None, xq.mean((2, 3)), 1.0 / (H * W)), (yd, (xq * yq).sum((2, 3)), 1.0)):
+        outs = []
+        for split in (False, True, True):
+            pooled = torch.full((B, C), float("nan"), device="cuda")
+            d = ops.ew_desc(a=xd, b=second, B=B, H=H, W=W, alpha=alpha)
+            scratch = torch.full((SE_POOL_SPLITS * B * C,), float("nan"), device="cuda")
+            if split:
+                d.aux2 = scratch.data_ptr()
+            ops.call("dyk_se_pool", d, pooled)
+            outs.append(pooled.cpu())
+            if split:
+                assert not bool(torch.isnan(scratch[:2 * B * C]).any())      # the split path ran
+        _close(outs[0], ref.float(), 2e-5 * max(1.0, float(ref.abs().max())), "se pool single")
+        _close(outs[1], ref.float(), 2e-5 * max(1.0, float(ref.abs().max())), "se pool split")
+        assert torch.equal(outs[1], outs[2])
+
+
 def test_head_permute_patch_gather_decode():
     from dyk import ops
     from dyk.lib import DYK_BF16, DYK_F32, DykDecodeDesc, check, load

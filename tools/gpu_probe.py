@@ -223,6 +223,49 @@ if "bnbench" in what:
         print((H, W, c), "  ".join(out), flush=True)
     res["bnbench"] = rows
 
+if "bnbwdablate" in what:
+    # data gradient with the fused BN-backward-reduce epilogue against the same GEMM with the plain epilogue, per activation
+    import ctypes as C
+    from dyk import lib as L
+    from dyk.plan import _conv_candidates
+    for (ci, co, H, W, k) in [(64, 32, 256, 320, 3), (128, 64, 128, 160, 3), (128, 128, 64, 80, 3), (256, 256, 32, 40, 3), (128, 128, 64, 80, 1)]:
+        B, dt = 16, torch.bfloat16
+        x = torch.randn(B, H, W, ci, device="cuda").to(dt)
+        w = torch.randn(co, ci, k, k, device="cuda") * 0.05
+        wp = ops.pack_weight(w, dt)
+        out = torch.empty(B, H, W, co, device="cuda", dtype=dt)
+        yprev = torch.randn(B, H, W, co, device="cuda").to(dt)
+        slots = 32
+        red = torch.zeros(slots * 2 * co, dtype=torch.float64, device="cuda")
+        vec = [torch.rand(co, device="cuda") + 0.5 for _ in range(4)]
+        fn = L.load().dyk_conv_igemm
+        def mk(flags, act):
+            d = ops.make_conv_desc(x, wp, out, Hi=H, Wi=W, Cin=ci, Cout=co, Hg=H, Wg=W, Ho=H, Wo=W, taps=ops.fwd_taps(k, k // 2), act=act)
+            d.flags = flags
+            if flags:
+                d.res, d.ldr = yprev.data_ptr(), co
+                d.scale, d.shift, d.aux0, d.aux1 = (t.data_ptr() for t in vec)
+                d.stats, d.stats_slots = red.data_ptr(), slots
+            return d
+        def t(d, tune, n=10):
+            d.tune = tune
+            for _ in range(2):
+                fn(C.byref(d), None)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn(C.byref(d), None)
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n * 1e3
+        line = []
+        for name, flags, act in [("plain", 0, "linear"), ("bnbwd linear", L.EPI_BNBWD, "linear"), ("bnbwd leaky", L.EPI_BNBWD, "leaky"), ("bnbwd mish", L.EPI_BNBWD, "mish")]:
+            d = mk(flags, act)
+            cands = _conv_candidates(d)
+            ts = sorted((t(d, c, 5), c) for c in cands)
+            line.append("%s %.1f us (tune %x; 2nd %.1f %x)" % (name, ts[0][0], ts[0][1], ts[1][0], ts[1][1]))
+        print((ci, co, H, k), " | ".join(line), flush=True)
+
 if "wgablate" in what:
     import ctypes as C
     from dyk import lib as L
@@ -232,7 +275,9 @@ if "wgablate" in what:
         x = torch.randn(B, H, W, ci, device="cuda").to(dt)
         dy = torch.randn(B, H, W, co, device="cuda").to(dt)
         dw = torch.zeros(k * k, co, ci, device="cuda")
-        for name, tune, splits in [("default", 0, 0), ("pipe3", 3, 0), ("kg2", 2 | (2 << 8), 0), ("kg2s.5", 2 | (2 << 8), -2), ("kg2s2", 2 | (2 << 8), -3), ("noatomic", 1 << 16, 0), ("noloop", 1 << 17, 0),
+        plane_sp = {(128, 128, 64, 3): 28, (256, 256, 32, 3): 6, (512, 512, 16, 3): 6, (128, 128, 64, 1): 80, (64, 64, 256, 1): 512}[(ci, co, H, k)]
+        part = torch.zeros(plane_sp * k * k * co * ci, device="cuda")
+        for name, tune, splits in [("plane", 0, -10), ("plane kg2", 2 | (2 << 8), -10), ("plane noloop", 1 << 17, -10), ("plane noatomic", 1 << 16, -10), ("default", 0, 0), ("pipe3", 3, 0), ("kg2", 2 | (2 << 8), 0), ("kg2s.5", 2 | (2 << 8), -2), ("kg2s2", 2 | (2 << 8), -3), ("noatomic", 1 << 16, 0), ("noloop", 1 << 17, 0),
                                    ("noloop+noatomic", 3 << 16, 0), ("splits16", 0, 16), ("splits32", 0, 32)]:
             d = L.DykWgradDesc()
             d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
@@ -244,7 +289,10 @@ if "wgablate" in what:
             d.ntaps = len(taps)
             for i, (ty, tx, wt) in enumerate(taps):
                 d.tdy[i], d.tdx[i], d.twt[i] = ty, tx, wt
-            if splits < 0:       # relative to the K-grouped default: -2 = half, -3 = double
+            if splits == -10:
+                d.part, d.part_stride = part.data_ptr(), k * k * co * ci
+                splits = plane_sp
+            elif splits < 0:       # relative to the K-grouped default: -2 = half, -3 = double
                 tiles = ((co + 127) // 128) * ((ci + 127) // 128) * k * k
                 base = max(1, -(-256 // tiles))
                 splits = max(1, base // 2) if splits == -2 else base * 2
