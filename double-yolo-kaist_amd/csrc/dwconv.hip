@@ -307,7 +307,8 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DykDwDesc d, int CT, i
     const int strip = sl % SPR, r = sl / SPR;
     const bool active = r < RT && cv0 + ct < CV;
     const bool accum = d.flags & DYK_EW_ACCUM;
-    const bool stats = (!GRAD) && d.stats != nullptr;
+    const bool bnbwd = GRAD && d.res != nullptr;               // fused BatchNorm-backward reduce of the producer of x
+    const bool stats = ((!GRAD) && d.stats != nullptr) || bnbwd;
     float s1[EPV], s2[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) s1[j] = s2[j] = 0.f;
@@ -317,6 +318,28 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DykDwDesc d, int CT, i
         for (int o = 0; o < XT; ++o)
 #pragma unroll
             for (int j = 0; j < EPV; ++j) acc[o][j] = 0.f;
+        // the producer's raw conv output at this thread's four pixels: requested now, needed after the tap loop
+        uint4 uraw[XT];
+        float bsc[EPV], bsh[EPV], bmu[EPV], brs[EPV];
+        if (GRAD && bnbwd) {
+            const int c = (cv0 + ct) * EPV;
+#pragma unroll
+            for (int j = 0; j < EPV; j += 4) {
+                const float4 q0 = *(const float4*)(d.bn + c + j), q1 = *(const float4*)(d.bn + d.C + c + j);
+                const float4 q2 = *(const float4*)(d.bn + 2 * d.C + c + j), q3 = *(const float4*)(d.bn + 3 * d.C + c + j);
+                bsc[j] = q0.x; bsc[j + 1] = q0.y; bsc[j + 2] = q0.z; bsc[j + 3] = q0.w;
+                bsh[j] = q1.x; bsh[j + 1] = q1.y; bsh[j + 2] = q1.z; bsh[j + 3] = q1.w;
+                bmu[j] = q2.x; bmu[j + 1] = q2.y; bmu[j + 2] = q2.z; bmu[j + 3] = q2.w;
+                brs[j] = q3.x; brs[j + 1] = q3.y; brs[j + 2] = q3.z; brs[j + 3] = q3.w;
+            }
+            const int yo = y0 + r < Hout ? y0 + r : Hout - 1;
+#pragma unroll
+            for (int o = 0; o < XT; ++o) {
+                const int xo = x0 + strip * XT + o;
+                uraw[o] = *(const uint4*)((const T*)d.res + (((long)b * Hout + yo) * Wout + (xo < Wout ? xo : Wout - 1)) * d.ldr +
+                                          (long)(cv0 + ct) * EPV);
+            }
+        }
         // (kernel rows NOT unrolled: hoisted together their LDS reads need 500 VGPRs -- one wave per SIMD)
 #pragma unroll 1
         for (int kh = 0; kh < K; ++kh) {
@@ -348,7 +371,20 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DykDwDesc d, int CT, i
             for (int o = 0; o < XT; ++o) {
                 const int xo = x0 + strip * XT + o;
                 if (xo >= Wout) break;
-                if (stats) {
+                if (GRAD && bnbwd) {
+                    float u[EPV];
+                    vec_unpack<T>(uraw[o], u);
+                    // the gradient is rounded to the storage dtype first (what an unfused reduce pass would read back)
+                    const uint4 pk = vec_pack<T>(acc[o]);
+                    vec_unpack<T>(pk, acc[o]);
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) {
+                        const float da = acc[o][j] * act_bwd(d.act, u[j] * bsc[j] + bsh[j]);
+                        s1[j] += da;
+                        s2[j] += da * ((u[j] - bmu[j]) * brs[j]);
+                        acc[o][j] = da;
+                    }
+                } else if (stats) {
 #pragma unroll
                     for (int j = 0; j < EPV; ++j) { s1[j] += acc[o][j]; s2[j] += acc[o][j] * acc[o][j]; }
                 }
@@ -701,6 +737,13 @@ extern "C" int dyk_dwconv_dgrad(const DykDwDesc* d, void* stream) {
     const int rc = check_dw(d);
     if (rc) return rc;
     if (!d->w) return DYK_ERR_ARG;
+    if (d->res) {                    // fused BatchNorm-backward reduce: LDS-tiled kernel only
+        if (!d->bn || !d->stats || d->stats_slots <= 0 || d->ldr < d->C || d->ldr % 8 || ((uintptr_t)d->res % 16)) return DYK_ERR_ARG;
+        if (d->stride != 1 || (d->k != 3 && d->k != 5) || d->dtype != DYK_BF16 || (d->flags & DYK_EW_ACCUM)) return DYK_ERR_UNSUPPORTED;
+        const int rt = d->k == 3 ? launch_dw_tile<3, true>(d, (hipStream_t)stream) : launch_dw_tile<5, true>(d, (hipStream_t)stream);
+        if (rt == DYK_OK) DYK_LAUNCH_CHECK();
+        return rt;
+    }
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     int gx, gy;
     const int CVB = grid2d(d->C / epv, (long)d->B * d->Hi, &gx, &gy, 4096);

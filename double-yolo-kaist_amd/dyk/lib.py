@@ -98,7 +98,8 @@ class DykDwDesc(ctypes.Structure):
     _fields_ = [("x", _vp), ("y", _vp), ("w", _vp), ("dw", _vp), ("stats", _vp), ("part", _vp),
                 ("dtype", _i32), ("ldx", _i32), ("ldy", _i32),
                 ("B", _i32), ("Hi", _i32), ("Wi", _i32), ("Ho", _i32), ("Wo", _i32), ("C", _i32),
-                ("k", _i32), ("stride", _i32), ("pad", _i32), ("flags", _i32), ("stats_slots", _i32)]
+                ("k", _i32), ("stride", _i32), ("pad", _i32), ("flags", _i32), ("stats_slots", _i32),
+                ("res", _vp), ("bn", _vp), ("ldr", _i32), ("act", _i32)]
 
 
 class DykGradReduceEntry(ctypes.Structure):

@@ -791,8 +791,23 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 gd.B, gd.Hi, gd.Wi, gd.Ho, gd.Wo, gd.C = B, x_in.H, x_in.W, dy.H, dy.W, cout
                 gd.k, gd.stride, gd.pad = k, stride, pad
                 gd.ldx, gd.ldy = gx.ld, dy.ld
+                first = x_in.tid not in ginit
                 gd.flags = acc_flag(x_in)
                 later(lambda gd=gd, gx=gx, dy=dy: (setattr(gd, "x", ptr_of(gx)), setattr(gd, "y", ptr_of(dy))))
+                # BatchNorm-backward reduce of the layer that produced x_in (the expansion conv of a MobileNet block) folded
+                # into this data gradient, under the conditions of the MFMA conv's DYK_EPI_BNBWD (sole reader, first
+                # writer of the gradient) -- LDS-tiled kernel only: stride 1, 3x3 / 5x5, bf16
+                prod = producer_of.get(x_in.tid)
+                if (first and prod is not None and prod is not rec and tcons.get(x_in.tid, 0) == 1
+                        and stride == 1 and k in (3, 5) and code == L.DYK_BF16 and "vecs" in prod
+                        and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
+                        and os.environ.get("DYK_DW_TILE", "1") != "0" and os.environ.get("DYK_DW_BNBWD", "1") != "0"):
+                    prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
+                    prod["keep_dz"] = False
+                    gd.act, gd.stats_slots, gd.ldr = prod["act"], STAT_SLOTS, prod["y_raw"].ld
+                    later(lambda gd=gd, prod=prod: (
+                        setattr(gd, "res", ptr_of(prod["y_raw"])), setattr(gd, "bn", ws.ptr(prod["vecs"])),
+                        setattr(gd, "stats", ws.ptr(prod["red_fused"]))))
                 plan.bwd.append((L.OP_DW_DGRAD, gd))
                 return
             if "stem_direct" in rec:

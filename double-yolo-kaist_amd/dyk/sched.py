@@ -169,6 +169,10 @@ def accesses(op, d, mem, plan):
             rd(T(d.x, d.ldx, d.C, es)); wr(T(d.y, d.ldy, d.C, es)); wr(V(d.stats))
         elif op == L.OP_DW_DGRAD:
             rd(T(d.y, d.ldy, d.C, es)); wr(T(d.x, d.ldx, d.C, es))
+            if d.flags & L.EW_ACCUM:
+                rd(T(d.x, d.ldx, d.C, es))
+            if d.res:                      # fused BatchNorm-backward reduce of the producer
+                rd(T(d.res, d.ldr, d.C, es)); rd(V(d.bn)); wr(V(d.stats))
         else:
             rd(T(d.x, d.ldx, d.C, es)); rd(T(d.y, d.ldy, d.C, es))
             ext = getattr(plan, "_part_extent", {}).get(ctypes.addressof(d))

@@ -374,6 +374,14 @@ typedef struct DykDwDesc {
     int32_t B, Hi, Wi, Ho, Wo, C;
     int32_t k, stride, pad;
     int32_t flags, stats_slots;
+    /* dyk_dwconv_dgrad only, res != NULL: the BatchNorm-backward reduce of the layer that produced the conv input is
+     * folded into this data gradient (as DYK_EPI_BNBWD does for dyk_conv_igemm): with u = res (the producer's raw conv
+     * output, row length ldr), da = dx * act'(scale*u + shift) is stored instead of dx and sum(da), sum(da * (u-mean)*rstd)
+     * are added to the fp64 replicas stats[stats_slots][2][C].  bn = scale | shift | mean | rstd, C floats each.
+     * Stride 1, k in {3, 5}, bf16, no DYK_EW_ACCUM. */
+    const void* res;
+    const float* bn;
+    int32_t ldr, act;
 } DykDwDesc;
 int dyk_dwconv_fwd(const DykDwDesc* desc, void* stream);
 int dyk_dwconv_dgrad(const DykDwDesc* desc, void* stream);

@@ -265,6 +265,56 @@ def test_conv_every_tile_configuration(case):
         assert err <= 1.5e-2 * max(1.0, z_ref.abs().max().item()), (hex(tune), err)
 
 
+@pytest.mark.parametrize("act", ["hard-swish", "relu", "linear"])
+@pytest.mark.parametrize("case", [(2, 72, 17, 23, 3), (1, 120, 12, 20, 5), (2, 16, 40, 36, 3)])
+def test_depthwise_dgrad_with_fused_batchnorm_backward_reduce(case, act):
+    """DykDwDesc.res: the depthwise data gradient stores da = dx * act'(u*scale + shift) (u = raw output of the conv that
+    produced the depthwise input) and accumulates sum(da), sum(da * xhat) -- the MobileNet expansion conv's BN backward
+    reduce, folded into the launch that produces its dz (bf16, LDS-tiled kernel)."""
+    import ctypes
+    from dyk import lib as L
+    from dyk import ops
+    acts = {"hard-swish": F.hardswish, "relu": F.relu, "linear": lambda t: t}
+    B, C, H, W, k = case
+    pad = k // 2
+    g = torch.Generator().manual_seed(21)
+    w = torch.randn(C, 1, k, k, generator=g) / k
+    dy = torch.randn(B, C, H, W, generator=g).bfloat16().float()
+    u = (torch.randn(B, C, H, W, generator=g) * 2).bfloat16().float()
+    scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    mean, rstd = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    dz = torch.nn.grad.conv2d_input((B, C, H, W), w, dy, padding=pad, groups=C).bfloat16().float()
+    t = (u * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).requires_grad_(True)
+    acts[act](t).backward(dz)
+    da_ref = t.grad
+    xhat = (u - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1)
+    s1_ref, s2_ref = da_ref.double().sum((0, 2, 3)), (da_ref.double() * xhat.double()).sum((0, 2, 3))
+    cpad = (C + 31) // 32 * 32
+    dyd = ops.to_nhwc(dy.cuda(), torch.bfloat16, cpad=cpad)
+    ud = ops.to_nhwc(u.cuda(), torch.bfloat16, cpad=cpad)
+    wt = w.reshape(C, k * k).t().contiguous().cuda()
+    out = torch.zeros((B, H, W, cpad), dtype=torch.bfloat16, device="cuda")
+    slots = 4
+    red = torch.zeros(slots, 2, C, dtype=torch.float64, device="cuda")
+    bn = torch.cat([scale, shift, mean, rstd]).cuda().contiguous()
+    d = ops._dw_desc(out, dyd, wt, k, 1, pad, C)
+    d.res, d.ldr, d.bn, d.act = ud.data_ptr(), cpad, bn.data_ptr(), ops.ACT_CODES[act]
+    d.stats, d.stats_slots = red.data_ptr(), slots
+    L.check(L.load().dyk_dwconv_dgrad(ctypes.byref(d), None), "dyk_dwconv_dgrad(fused BN reduce)")
+    got = ops.to_nchw(out, C=C).cpu()
+    err = (got - da_ref).abs().max().item()
+    assert err <= 1.5e-2 * max(1.0, da_ref.abs().max().item()), err
+    st = red.sum(0).cpu()
+    n = B * H * W
+    assert torch.allclose(st[0], s1_ref, rtol=2e-3, atol=2e-2 * n ** 0.5 * 0.1), (st[0] - s1_ref).abs().max()
+    assert torch.allclose(st[1], s2_ref, rtol=2e-3, atol=2e-2 * n ** 0.5 * 0.1), (st[1] - s2_ref).abs().max()
+    # the sums are those of the STORED (rounded) gradient times act', in fp32: compare against exactly that
+    da_st = ops.to_nchw(out, C=C).cpu().double()
+    assert torch.allclose(st[0], da_st.sum((0, 2, 3)), rtol=1e-2, atol=0.5)
+    d.flags = 1
+    assert L.load().dyk_dwconv_dgrad(ctypes.byref(d), None) == -3      # DYK_ERR_UNSUPPORTED: no accumulate form
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act", ["mish", "leaky", "linear", "relu6"])
 def test_dgrad_with_fused_batchnorm_backward_reduce(dtype, act):

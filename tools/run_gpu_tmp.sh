@@ -1,9 +1,4 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-python -m pytest tests/test_gpu_conv.py -q -k "depthwise" 2>&1 | tail -15 > gpurun_out/pytest_sel.log
+python -m pytest tests/test_gpu_model.py tests/test_all_cfgs.py tests/test_gpu_layers.py -m gpu -q -k "not baseline_size" 2>&1 | grep -vE "RCCL|HIP version|ROCm version|Hostname|Librccl|amdgpu.ids" | tail -30 > gpurun_out/pytest_sel.log
 cat gpurun_out/pytest_sel.log
-AB_ARGS="--cfg kaist_dyolov4_mobilenetv3_fshare_global_cse3 --batch 32" bash tools/ab.sh "A=1" "DYK_DW_TILE=0" > gpurun_out/ab_dwtile.log 2>&1
-cat gpurun_out/ab_dwtile.log
-python bench.py --cfg kaist_dyolov4_mobilenetv3_fshare_global_cse3 --batch 32 --steps 5 --warmup 3 --no-cpu-baseline --dump-cmds gpurun_out/cmds_c5.json > gpurun_out/b_c5.json 2> gpurun_out/b_c5.err
-python tools/cmd_roofline.py gpurun_out/cmds_c5.json > gpurun_out/cmds_c5.txt
-head -16 gpurun_out/cmds_c5.txt
