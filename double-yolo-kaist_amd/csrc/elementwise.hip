@@ -426,22 +426,23 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(DykSeFcDesc d) {
         }
     }
     __syncthreads();
-    // dh[j] = sum_c W2[c][j] dt2[c]: column sums, coalesced over j; 4 row groups of the block split c, folded in dt1
-    for (int j = threadIdx.x; j < d.Cs; j += blockDim.x) dt1[j] = 0.f;
-    __syncthreads();
+    // dh[j] = sum_c W2[c][j] dt2[c]: column sums, coalesced over j; the 4 row groups of the block split c and park their
+    // partial sums in dtp[rg][j], folded in a FIXED order (LDS float atomics made the order -- and the last bit of the
+    // gradients -- depend on which wave arrived first)
+    float* dtp = dt1 + d.Cs;                 // [4][Cs]
     {
         const int jt = threadIdx.x & 255, rg = threadIdx.x >> 8, nrg = blockDim.x >> 8;
         for (int j = jt; j < d.Cs; j += 256) {
             float acc = 0.f;
 #pragma unroll 8
             for (int c = rg; c < d.C; c += nrg) acc += d.w2[(long)c * d.Cs + j] * dt2[c];
-            atomicAdd(dt1 + j, acc);               // LDS, 4-way
+            dtp[rg * d.Cs + j] = acc;
         }
     }
     __syncthreads();
     for (int j = threadIdx.x; j < d.Cs; j += blockDim.x) {
-        const float g = t1[j] > 0.f ? dt1[j] : 0.f;
-        dt1[j] = g;
+        const float sum = (dtp[j] + dtp[d.Cs + j]) + (dtp[2 * d.Cs + j] + dtp[3 * d.Cs + j]);
+        dt1[j] = t1[j] > 0.f ? sum : 0.f;
     }
     __syncthreads();
     // park what the weight-gradient kernel needs: h | dt1 | dt2
@@ -793,7 +794,7 @@ extern "C" int dyk_se_fc_bwd(const DykSeFcDesc* d, void* stream) {
     if (!d || !d->pooled || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->dscale || !d->dpooled || !d->dw1 || !d->db1 ||
         !d->dw2 || !d->db2 || !d->ws || d->B <= 0 || d->C <= 0 || d->Cs <= 0)
         return DYK_ERR_ARG;
-    const size_t lds = (size_t)(2 * d->C + 3 * d->Cs) * sizeof(float);
+    const size_t lds = (size_t)(2 * d->C + 7 * d->Cs) * sizeof(float);
     hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(d->B), dim3(1024), lds, (hipStream_t)stream, *d);
     const long n2 = 2L * d->C * d->Cs + d->C + d->Cs;
     hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3((unsigned)((n2 + 255) / 256 < 4096 ? (n2 + 255) / 256 : 4096)), dim3(256), 0,

@@ -60,7 +60,7 @@ class Arena:
         return off
 
     def materialize(self, device, zero=True):
-        n = max(self.size, 256)
+        n = max(self.size, 256) + 256          # (spare zero bytes: tight-row K steps of the very last pixel read them)
         self.tensor = torch.zeros(n, dtype=torch.uint8, device=device) if zero else \
             torch.empty(n, dtype=torch.uint8, device=device)
         return self.tensor
@@ -203,8 +203,16 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     second = net.get("second_index", None)
     v4 = "yolov4" in model.cfg
 
+    # Row length of an activation / gradient tensor.  The MFMA conv reads its K dimension in 32-channel (64-byte) steps;
+    # rows used to be padded to that step, which doubles the HBM traffic of EVERY kernel touching a 16-channel tensor
+    # (MobileNet stem / first block at 256 x 320: 64 bytes fetched per pixel for 32 used) and adds 25-60 % on 24- / 40- /
+    # 72-channel ones.  Tight rows (a multiple of the 16-byte vector): the last K step of a pixel then runs into the
+    # NEXT pixel's first channels -- finite values that meet the zero rows of the padded weight matrix (Wc_pad / Wt_pad),
+    # so they contribute exactly 0; every arena ends in 256 spare zero bytes for the last pixel of the last tensor.
+    tight = os.environ.get("DYK_TIGHT_ROWS", "1") != "0"
+
     def new_act(Bn, Hn, Wn, C, ld=None, esize=None):
-        ld = ld or _ru(C, 32)        # rows padded (with zeros that no kernel ever overwrites) to the GEMM K step
+        ld = ld or (_ru(C, 8) if tight else _ru(C, 32))
         esize = esize or es
         return TRef("act", act_arena.alloc(Bn * Hn * Wn * ld * esize), Bn, Hn, Wn, C, ld, esize)
 
@@ -351,7 +359,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             Ho, Wo = conv_out_size(Hi, k, stride, pad), conv_out_size(Wi, k, stride, pad)
             e = store.by_name[wname]
             cin_k = _ru(x_in.C, 32)
-            if x_in.ld < cin_k:
+            if x_in.ld < cin_k and not tight:
                 raise NotImplementedError("conv input rows narrower than the padded K (layer %d)" % i)
             if cin_k != x_in.C:
                 wfwd_ptr = cw["Wc_pad"].data_ptr() + cw["fwd_pad_off"][wname] * es
@@ -849,7 +857,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             first = x_in.tid not in ginit
             e = store.by_name[wname]
             kpad = _ru(cout, 32)
-            if dy.ld < kpad:
+            if dy.ld < kpad and not tight:
                 raise NotImplementedError("gradient rows narrower than the padded K (layer %d)" % rec["i"])
             if kpad != cout:
                 wt_ptr = cw["Wt_pad"].data_ptr() + cw["bwd_pad_off"][wname] * es

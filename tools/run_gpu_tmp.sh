@@ -1,4 +1,8 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-python -m pytest tests/test_gpu_model.py tests/test_all_cfgs.py tests/test_gpu_layers.py -m gpu -q -k "not baseline_size" 2>&1 | grep -vE "RCCL|HIP version|ROCm version|Hostname|Librccl|amdgpu.ids" | tail -30 > gpurun_out/pytest_sel.log
-cat gpurun_out/pytest_sel.log
+T="tests/test_gpu_model.py::test_baseline_size_train_step_is_bit_reproducible"
+for v in 1 2 3 4; do
+  python -m pytest "$T" -q 2>&1 | grep -E "passed|failed|^FAILED" | tail -3
+done > gpurun_out/bisect.log 2>&1
+python -m pytest tests/test_gpu_ddp.py tests/test_gpu_elementwise.py -q 2>&1 | grep -E "passed|failed|^FAILED" | tail -5 >> gpurun_out/bisect.log
+cat gpurun_out/bisect.log
