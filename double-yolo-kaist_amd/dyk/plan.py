@@ -394,7 +394,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 # (about 32 workgroups per replica), few enough that the consumer folds them cheaply
                 slots = min(256, max(4, 1 << max(0, (tiles * max(1, (cout + 127) // 128) // 32 - 1).bit_length())))
                 if dw:
-                    slots = max(slots, 32)           # the depthwise kernel spreads up to 4096 workgroups over them
+                    slots = 32                       # 32 replicas: the finalize then rides on the normalise pass (measured
+                                                     # -0.3 ms per MobileNetV3 step against up to 256 replicas + own launch)
                 stats = st_arena.alloc(slots * 2 * cout * 8)   # fp64 replicas; the whole arena is zeroed at the start of a pass
                 vecs = new_ws(4 * cout * 4)          # scale | shift | mean | rstd
                 d.ldy, d.stats_slots = y_raw.ld, slots
@@ -1124,6 +1125,10 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     for fn in pending:
         fn()
     plan.training = training
+    plan.store = store
+    if training and os.environ.get("DYK_BNBWD_FUSE", "1") != "0" and os.environ.get("DYK_LATE_FUSE", "1") != "0" \
+            and not os.environ.get("DYK_DEBUG_PLAN"):
+        _fuse_late_reduces(plan, store)
     if not dry and os.environ.get("DYK_AUTOTUNE", "1") != "0":
         autotune(plan, _TUNE_CACHE)
     plan.part = None
@@ -1185,6 +1190,59 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
 
 
 # ======================================================================================
+def _fuse_late_reduces(plan, store):
+    """BatchNorm-backward reduce passes whose dz has SEVERAL contributors (CSP splits, routes, weighted fusions): the LAST
+    contribution, when it is an accumulating MFMA data gradient covering the whole tensor in one launch, takes the reduce
+    into its epilogue in chain mode -- DYK_EPI_BNBWD | DYK_EPI_ADDEND with `add` = its own output: y = acc + y exactly
+    as the accumulate epilogue would leave it, and sum(da), sum(da * xhat) of that final dz go to the replicas the apply
+    pass folds.  Decided on the RESOLVED command list (who writes the region last is read off the descriptors' access
+    sets, dyk/sched.py), independent of how the commands were emitted; the reduce command is dropped."""
+    from . import sched
+    mem = sched.Memory(plan, store)
+    cmds = plan.bwd
+    acc = [sched.accesses(op, d, mem, plan) for op, d in cmds]
+    removed = []
+    for ri, (op, r) in enumerate(cmds):
+        if op != L.OP_BN_BWD_REDUCE:
+            continue
+        es = 2 if r.dtype == L.DYK_BF16 else 4
+        target = mem.block(r.a, r.lda * es, r.C * es)
+        if target is None:
+            continue
+        wi = None
+        for j in range(ri - 1, -1, -1):
+            if acc[j][2]:
+                break
+            if any(w.overlaps(target) for w in acc[j][1]):
+                wi = j
+                break
+        if wi is None:
+            continue
+        wop, w = cmds[wi]
+        if wop != L.OP_CONV or w.flags != L.EPI_ACCUM or w.ncls > 1 or w.dtype != r.dtype:
+            continue
+        if w.y != r.a or w.ldy != r.lda or w.Cout != r.C or w.B * w.Ho * w.Wo != r.npix:
+            continue
+        if w.osy != 1 or w.osx != 1 or w.ooy or w.oox or w.Hg != w.Ho or w.Wg != w.Wo:
+            continue
+        if w.Cout % (16 // es) or (w.ldy * es) % 16 or (r.ldb * es) % 16 or w.y % 16 or r.b % 16:
+            continue
+        w.flags = L.EPI_BNBWD | L.EPI_ADDEND
+        w.add, w.res, w.ldr = w.y, r.b, r.ldb
+        w.scale, w.shift, w.aux0, w.aux1 = r.p0, r.p1, r.p2, r.p3
+        w.stats, w.stats_slots, w.act = r.red, (r.slots if r.slots > 0 else 1), r.act
+        acc[wi] = sched.accesses(wop, w, mem, plan)
+        removed.append(ri)
+    if not removed:
+        return
+    gone = set(removed)
+    plan.bwd = [c for q, c in enumerate(cmds) if q not in gone]
+    removed.sort()
+    import bisect
+    plan.bwd_marks = [(cnt - bisect.bisect_left(removed, cnt), layer) for cnt, layer in plan.bwd_marks]
+    plan.late_fused = len(removed)
+
+
 def _setup_wgrad_partials(plan, store, device, force_layers=()):
     """Atomic-free weight gradients: every K split of a weight-gradient launch gets its own plane of a partial buffer
     (dyk_conv_wgrad_splits planes per layer), and a table-driven dyk_grad_reduce folds the planes into the flat gradient
