@@ -169,6 +169,19 @@ __global__ __launch_bounds__(64) void stem_wgrad_kernel(const DykStemDesc d, int
             for (int u = 0; u < NV; ++u) { const int v = lane + u * 64; t[u] = ((const uint4*)dyseg)[v < nvec ? v : 0]; }
 #pragma unroll
             for (int u = 0; u < NV; ++u) { const int v = lane + u * 64; if (v < nvec) ((uint4*)s_dy)[v] = t[u]; }
+        } else if (d.lddy == 16 && ((uintptr_t)dyseg & 15) == 0) {
+            // tight 16-channel rows: the segment is contiguous, two (bf16) / four (fp32) vectors per pixel go to the first
+            // half of the pixel's 32-channel LDS row (channels >= COUT are masked at the MFMA)
+            constexpr int VPP = 16 / VEC;
+            const int nvec = npx * VPP;
+            uint4 t[NV / 2];
+#pragma unroll
+            for (int u = 0; u < NV / 2; ++u) { const int v = lane + u * 64; t[u] = ((const uint4*)dyseg)[v < nvec ? v : 0]; }
+#pragma unroll
+            for (int u = 0; u < NV / 2; ++u) {
+                const int v = lane + u * 64;
+                if (v < nvec) ((uint4*)s_dy)[(v / VPP) * (32 / VEC) + (v % VPP)] = t[u];
+            }
         } else {
             for (int e = lane; e < npx * 32; e += 64) {
                 const int px = e >> 5, ch = e & 31;

@@ -5,12 +5,17 @@ set -x
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 python -m pytest tests -m gpu -q 2>&1 | grep -vE "RCCL version|HIP version|ROCm version|Hostname|Librccl path|amdgpu.ids" | tail -60 > gpurun_out/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
-python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err
+python bench.py --steps 20 --warmup 5 --dump-cmds gpurun_out/cmds_c3.json > gpurun_out/bench.json 2> gpurun_out/bench.err
+python tools/cmd_roofline.py gpurun_out/cmds_c3.json > gpurun_out/cmd_roofline_c3.txt 2>&1
 tail -c 3000 gpurun_out/bench.json
 # the other BASELINE configs (parity-test cases; kept beside the bench line for reference)
 python bench.py --mode eval --cfg kaist_dyolov3_add_sl --dtype fp32 --steps 10 --warmup 3 > gpurun_out/bench_eval_c2.json 2>/dev/null
 python bench.py --mode eval --steps 10 --warmup 3 > gpurun_out/bench_eval_c3.json 2>/dev/null
-python bench.py --cfg kaist_dyolov4_mobilenetv3_fshare_global_cse3 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/bench_c5.json 2>/dev/null
+python bench.py --cfg kaist_dyolov4_mobilenetv3_fshare_global_cse3 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --dump-cmds gpurun_out/cmds_c5.json > gpurun_out/bench_c5.json 2>/dev/null
+python tools/cmd_roofline.py gpurun_out/cmds_c5.json > gpurun_out/cmd_roofline_c5.txt 2>&1
+python bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --dump-cmds gpurun_out/cmds_b1.json > gpurun_out/bench_b1.json 2>/dev/null
+python tools/cmd_roofline.py gpurun_out/cmds_b1.json > gpurun_out/cmd_roofline_b1.txt 2>&1
+rm -f gpurun_out/cmds_c3.json gpurun_out/cmds_c5.json gpurun_out/cmds_b1.json
 rm -rf gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write && mkdir -p gpurun_out/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r2 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/prof/bench_under_prof.json 2> gpurun_out/prof/err.log
 # counters in their own runs, one pass per counter (TCC slots), kernel trace only
