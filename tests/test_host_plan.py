@@ -359,3 +359,51 @@ num=3
     compile_plan(m, st, 1, 64, 64, torch.bfloat16, False, torch.device("cpu"), dry=True)     # inference: identity
     with pytest.raises(NotImplementedError):
         compile_plan(m, st, 1, 64, 64, torch.bfloat16, True, torch.device("cpu"), dry=True)
+
+
+@pytest.mark.parametrize("name", [C3, C5, C1])
+def test_every_batchnorm_backward_apply_has_exactly_one_reduce(name):
+    """The BN-backward reduce of a layer runs in one of four places: its own pass, the epilogue of the data gradient that
+    produces dz (DYK_EPI_BNBWD), the depthwise data gradient (DykDwDesc.res), or -- dz with several contributors -- the
+    LAST accumulating data gradient in chain mode (add == its own output, plan._fuse_late_reduces).  Whatever the form:
+    the replicas an apply pass folds are written by exactly one earlier command, and a chain-mode launch is the last
+    writer of its gradient tensor before that apply pass."""
+    from dyk import lib as L, sched
+    from dyk.params import ParamStore
+    from dyk.plan import compile_plan
+    m = _model(name)
+    st = ParamStore(m)
+    st.adopt(torch.device("cpu"))
+    plan = compile_plan(m, st, 2, 64, 96, torch.bfloat16, True, torch.device("cpu"), dry=True)
+    mem = sched.Memory(plan, st)
+    writers = {}                                   # red pointer -> [(index, kind)]
+    for q, (op, d) in enumerate(plan.bwd):
+        if op == L.OP_BN_BWD_REDUCE:
+            writers.setdefault(d.red, []).append((q, "pass"))
+        elif op == L.OP_CONV and d.flags & L.EPI_BNBWD:
+            writers.setdefault(d.stats, []).append((q, "chain" if d.flags & L.EPI_ADDEND and d.add == d.y else "epilogue"))
+        elif op == L.OP_DW_DGRAD and d.res:
+            writers.setdefault(d.stats, []).append((q, "depthwise"))
+    kinds = []
+    n_apply = 0
+    for q, (op, d) in enumerate(plan.bwd):
+        if op != L.OP_BN_BWD_APPLY:
+            continue
+        n_apply += 1
+        w = writers.get(d.red, [])
+        # (a strided conv's data gradient may be several parity-class launches sharing one set of replicas)
+        assert w and all(i < q for i, _ in w) and len({k for _, k in w}) == 1, (q, w)
+        assert len(w) == 1 or w[0][1] == "epilogue", (q, w)
+        kinds.append(w[0][1])
+        if w[0][1] == "chain":
+            wi = w[0][0]
+            cd = plan.bwd[wi][1]
+            tgt = mem.block(cd.y, cd.ldy * 2, cd.Cout * 2)
+            for j in range(wi + 1, q):
+                _, W, _ = sched.accesses(*plan.bwd[j], mem, plan)
+                assert not any(r.overlaps(tgt) for r in W), "command %d writes dz after its chain-mode reduce %d" % (j, wi)
+    assert n_apply > 0 and kinds.count("epilogue") > 0
+    if name == C3:
+        assert kinds.count("chain") >= 10 and getattr(plan, "late_fused", 0) == kinds.count("chain")
+    if name == C5:
+        assert kinds.count("depthwise") >= 30
