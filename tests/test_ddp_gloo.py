@@ -36,6 +36,14 @@ def _worker(rank, world, port, q):
         assert segs[0][3] == eng.store.total and segs[-1][2] == 0
         assert all(a[2] == b[3] for a, b in zip(segs, segs[1:]))
         assert 2 <= len(segs) <= 8
+        # the default: geometric buckets (50 | 30 | 15 | 4 | 1 % of the gradient buffer in backward order) -- the same
+        # partition properties, and the bucket that is exchanged after the last layer is a small one
+        geo = GradAllReduce(m, dist).segments(plan)
+        assert geo[0][0] == 0 and geo[-1][1] == len(plan.bwd) and geo[0][3] == eng.store.total and geo[-1][2] == 0
+        assert all(a[1] == b[0] and a[2] == b[3] for a, b in zip(geo, geo[1:]))
+        assert 2 <= len(geo) <= 5 and geo[-1][3] - geo[-1][2] <= 0.2 * eng.store.total
+        assert geo[0][3] - geo[0][2] >= 0.45 * eng.store.total
+        red = GradAllReduce(m, dist, n_buckets=6)
         G = eng.store.G
         G.fill_(-7.0)
         ran = []
