@@ -630,6 +630,15 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(float* __restrict__ G,
     const float* p = part + e.part_off + i;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int s = 0;
+    for (; s + 8 <= e.splits; s += 8) {                 // eight planes in flight (early layers fold up to 512 planes: the
+        float4 v[8];                                    //  four-at-a-time loop was a chain of 128 dependent round trips)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(p + (long)(s + u) * e.plane);
+        acc.x += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+        acc.y += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
+        acc.z += ((v[0].z + v[1].z) + (v[2].z + v[3].z)) + ((v[4].z + v[5].z) + (v[6].z + v[7].z));
+        acc.w += ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
+    }
     for (; s + 4 <= e.splits; s += 4) {                 // four planes in flight
         const float4 v0 = *(const float4*)(p + (long)s * e.plane), v1 = *(const float4*)(p + (long)(s + 1) * e.plane);
         const float4 v2 = *(const float4*)(p + (long)(s + 2) * e.plane), v3 = *(const float4*)(p + (long)(s + 3) * e.plane);

@@ -1402,33 +1402,63 @@ def autotune(plan, cache=None):
                 cands, fn = _WGRAD_CANDIDATES, lib.dyk_conv_wgrad
                 if os.environ.get("DYK_WGRAD_CANDS"):
                     cands = [int(c, 0) for c in os.environ["DYK_WGRAD_CANDS"].split(",")]
-            times = []
             planes_on = (key[0] == "w" and plan.training and os.environ.get("DYK_WGRAD_PARTIALS", "1") != "0"
                          and not os.environ.get("DYK_WGRAD_TUNE_ATOMIC"))    # (analysis: the round-1 way)
-            for c in cands:
-                d.tune = c
-                if planes_on:
-                    # time the configuration the way the step runs it: every K split stores its own partial plane
-                    # (_setup_wgrad_partials below) -- the atomic form penalises exactly the many-split shapes the
-                    # plane form is good at -- plus the cost of folding that many planes (dyk_grad_reduce, ~2.7 TB/s)
-                    splits = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
-                    plane = d.ntaps * d.Cout * (d.lddw if d.lddw > 0 else d.Cin)
-                    if splits >= 2 and plane % 4 == 0:
-                        need = splits * plane
-                        if scratch[0] is None or scratch[0].numel() < need:
-                            scratch[0] = None
-                            scratch[0] = torch.empty(need, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
-                        d.part, d.part_stride, d.splits = scratch[0].data_ptr(), plane, splits
-                        t = _time_launch(fn, d, stream) + (splits + 1) * plane * 4 / 2.7e9
-                        d.part, d.part_stride, d.splits = None, 0, 0
-                        times.append(t)
+            if planes_on:
+                # Weight gradients are timed the way the step runs them: every K split stores its own partial plane
+                # (_setup_wgrad_partials below; the atomic form penalises exactly the many-split shapes the plane form is
+                # good at) plus the cost of folding that many planes (dyk_grad_reduce, ~2.7 TB/s).  The NUMBER of K splits
+                # is a tuning dimension too: the kernel's own count fills ~3 workgroups per CU, which on the deep layers
+                # (16x20 maps: 5 120 pixels) writes and re-reads several times the operand bytes as planes (512->512 3x3:
+                # 6 planes of 9.4 MB against 10.5 MB of operands) -- half / a quarter of the splits trade idle CUs for
+                # that traffic; one split means no plane at all (single writer, plain accumulation).
+                plane = d.ntaps * d.Cout * (d.lddw if d.lddw > 0 else d.Cin)
+                dev = torch.device("cuda", torch.cuda.current_device())
+                saved_dw = d.dw
+
+                def room(n):
+                    if scratch[0] is None or scratch[0].numel() < n:
+                        scratch[0] = None
+                        scratch[0] = torch.empty(n, dtype=torch.float32, device=dev)
+                    return scratch[0].data_ptr()
+
+                fold_w = float(os.environ.get("DYK_WGRAD_FOLD_W", "1"))
+                combos, times = [], []
+                for c in cands:
+                    d.tune, d.part, d.part_stride, d.splits = c, None, 0, 0
+                    auto = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
+                    if auto < 1:
                         continue
-                times.append(_time_launch(fn, d, stream))
-            best = cands[times.index(min(times))]
+                    opts = {auto}
+                    if os.environ.get("DYK_WGRAD_TUNE_SPLITS", "1") != "0" and plane % 4 == 0:
+                        opts |= {max(1, auto // 2), max(1, auto // 4), max(1, auto // 8)}
+                    for o in sorted(opts, reverse=True):
+                        d.part, d.part_stride, d.splits = None, 0, (0 if o == auto else o)
+                        n = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
+                        if n >= 2 and plane % 4 == 0:
+                            d.part, d.part_stride, d.splits = room(n * plane), plane, n
+                            t = _time_launch(fn, d, stream) + fold_w * (n + 1) * plane * 4 / 2.7e9
+                        else:
+                            d.dw = room(plane)                     # (trial sums must not land in the gradient buffer)
+                            t = _time_launch(fn, d, stream)
+                            d.dw = saved_dw
+                        combos.append((c, 0 if o == auto else o))
+                        times.append(t)
+                d.part, d.part_stride, d.splits, d.dw = None, 0, 0, saved_dw
+                best = combos[times.index(min(times))]
+            else:
+                times = []
+                for c in cands:
+                    d.tune = c
+                    times.append(_time_launch(fn, d, stream))
+                best = cands[times.index(min(times))]
             cache[key] = best
             _TUNE_MS[key] = min(times)
         for d in descs:
-            d.tune = best
+            if isinstance(best, tuple):
+                d.tune, d.splits = best             # (tile configuration, K splits: 0 = the kernel's own count)
+            else:
+                d.tune = best
             if key[0] == "c" and os.environ.get("DYK_EPI_OLD"):
                 d.tune |= 1 << 21                   # analysis: one raw-output load per trip in the fused BN-backward epilogue
             if key in _TUNE_MS:

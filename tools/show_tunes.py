@@ -15,5 +15,7 @@ for k, v in sorted(plan.tuned.items(), key=lambda kv: str(kv[0])):
         print("conv  Cin %4d Cout %4d %3dx%-3d taps %2d isy %d osy %d flags %2d ncls %d -> bkb %3d pipe %d tile %d bm %d" % (
             k[3], k[4], k[5], k[6], k[7], k[8], k[9], k[10], k[11], v & 0xff, (v >> 8) & 0xf, (v >> 12) & 0xf, (v >> 24) & 0xf) + (" KG" if (v >> 28) & 7 else ""))
     else:
+        v, sp = v if isinstance(v, tuple) else (v, 0)
+        print("splits %3s " % (sp or "auto"), end="")
         print("wgrad Cin %4d Cout %4d %3dx%-3d taps %2d isy %d -> stages %d kg %d cap %d mt %d" % (
             k[3], k[4], k[5], k[6], k[7], k[8], v & 0xff, (v >> 8) & 0xff, (v >> 24) & 0xf, (v >> 28) & 7))
