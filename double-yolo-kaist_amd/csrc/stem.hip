@@ -234,6 +234,116 @@ __global__ __launch_bounds__(64) void stem_wgrad_kernel(const DykStemDesc d, int
     }
 }
 
+// The loader's uint8 batches with bf16 gradients (the path a training step takes): same MFMA scheme as above, but
+//  * the image patch is fetched as aligned 32-bit words -- 9 rows x <= 2 words per lane and segment instead of 19 / 37
+//    single-byte loads, each behind two integer divisions -- (W % 4 == 0: a word is inside or outside the image as a whole);
+//  * dy and the patch of the NEXT segment are requested before the MFMAs of the current one (registers as the second
+//    buffer), so a segment costs one exposed memory round trip per workgroup instead of ~5 per segment.
+template <int COUT>
+__global__ __launch_bounds__(64) void stem_wgrad_u8_kernel(const DykStemDesc d, int segs_per_wg, int segs_per_row, int nsegs) {
+    using T = bf16_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const int Wseg = STEM_SEG * d.stride + 2;
+    T* s_dy = (T*)smem;                                           // [SEG][32]
+    float* s_img = (float*)(smem + STEM_SEG * 32 * sizeof(T));    // [3 ky][3 c][Wseg]
+    const int i = lane & 31, kk = lane >> 5;
+    const int tc = i;
+    const int c = tc % 3, kx = (tc / 3) % 3, ky = tc / 9;
+    const bool tc_ok = tc < 27;
+    const long plane = (long)d.H * d.W;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* s_b = s_img + (ky * 3 + c) * Wseg + kx;
+    constexpr int VPP = COUT / 8;                                 // 16-byte vectors per pixel (tight rows: lddy == COUT)
+    constexpr int NV = STEM_SEG * VPP / 64;                       // per lane and segment: 4 (16 channels) | 8 (32)
+    const int wpr = (Wseg + 3 + 3) / 4;                           // words per patch row, from the aligned start x0 - 4
+    uint4 t[NV];
+    uint32_t iw[9][2];
+    const uint8_t* img8 = (const uint8_t*)d.img;
+    auto fetch = [&](int sg) {
+        const int row = sg / segs_per_row, x_begin = (sg - row * segs_per_row) * STEM_SEG;
+        const int b = row / d.Ho, yo = row - b * d.Ho;
+        const int npx = min(STEM_SEG, d.Wo - x_begin);
+        const T* dyseg = (const T*)d.dy + ((long)row * d.Wo + x_begin) * d.lddy;
+        const int nvec = npx * VPP;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) { const int v = lane + u * 64; t[u] = ((const uint4*)dyseg)[v < nvec ? v : 0]; }
+        const int a0 = x_begin * d.stride - 4;                   // aligned start: the patch begins at a0 + 3
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) {
+            const int kyy = rr / 3, cc = rr - kyy * 3;
+            const int yi = yo * d.stride - 1 + kyy;
+            const bool rok = (unsigned)yi < (unsigned)d.H;
+            const uint8_t* rp = img8 + ((long)b * 3 + cc) * plane + (long)(rok ? yi : 0) * d.W;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int w = lane + h * 64;
+                const int xw = a0 + 4 * w;
+                const bool ok = rok && w < wpr && xw >= 0 && xw < d.W;
+                const uint32_t v = *(const uint32_t*)(rp + (ok ? xw : 0));
+                iw[rr][h] = ok ? v : 0u;
+            }
+        }
+    };
+    auto park = [&](int sg) {
+        const int row = sg / segs_per_row, x_begin = (sg - row * segs_per_row) * STEM_SEG;
+        const int npx = min(STEM_SEG, d.Wo - x_begin);
+        const int nvec = npx * VPP;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int v = lane + u * 64;
+            if (v < nvec) ((uint4*)s_dy)[(v / VPP) * 4 + (v % VPP)] = t[u];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int w = lane + h * 64;
+                if (w >= wpr) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int xp = 4 * w + j - 3;
+                    if (xp >= 0 && xp < Wseg) s_img[rr * Wseg + xp] = (float)((iw[rr][h] >> (8 * j)) & 0xffu) / 255.0f;
+                }
+            }
+    };
+    const int seg0 = blockIdx.x * segs_per_wg;
+    const int seg1 = min(nsegs, seg0 + segs_per_wg);
+    if (seg0 < seg1) fetch(seg0);
+    for (int sg = seg0; sg < seg1; ++sg) {
+        const int row = sg / segs_per_row, x_begin = (sg - row * segs_per_row) * STEM_SEG;
+        const int npx = min(STEM_SEG, d.Wo - x_begin);
+        __syncthreads();                                          // previous segment consumed
+        park(sg);
+        __syncthreads();
+        if (sg + 1 < seg1) fetch(sg + 1);                         // in flight during the MFMAs below
+        for (int x0 = 0; x0 < npx; x0 += 8) {
+            float a[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int xo = x0 + u * 2 + kk;
+                const bool live = xo < npx;
+                const float av = ElemTraits<T>::to_f32(s_dy[(live ? xo : 0) * 32 + i]);
+                const float xv = s_b[(live ? xo : 0) * d.stride];
+                a[u] = (live && i < COUT) ? av : 0.f;
+                bv[u] = (live && tc_ok) ? xv : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u], acc, 0, 0, 0);
+        }
+    }
+    float* out = d.part + (size_t)blockIdx.x * COUT * 27;
+    if (tc_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (co < COUT) out[co * 27 + tc] = acc[r];
+        }
+    }
+}
+
 // dw[e] += sum over planes, fixed order: one wave per element, lane l takes planes l, l + 64, ... (eight independent
 // loads in flight per lane), then a fixed xor-shuffle tree.  (With 8 lanes per element every lane walked hundreds of
 // planes through dependent loads: 250-500 us, several times the MFMA kernel it follows.)
@@ -332,6 +442,13 @@ extern "C" int dyk_stem_conv_wgrad(const DykStemDesc* d, void* stream) {
     const size_t es = d->dtype == DYK_BF16 ? 2 : 4;
     const size_t lds = (size_t)STEM_SEG * 32 * es + (size_t)9 * (STEM_SEG * d->stride + 2) * 4;
     (void)npix;
+    static int fast = -1;
+    if (fast < 0) { const char* e = getenv("DYK_STEM_WGRAD_U8"); fast = (e && e[0] == '0') ? 0 : 1; }
+    if (fast && d->in_u8 && d->dtype == DYK_BF16 && d->lddy == d->Cout && d->W % 4 == 0 && ((uintptr_t)d->img % 4) == 0 &&
+        ((uintptr_t)d->dy % 16) == 0 && STEM_SEG * d->stride + 2 + 6 <= 4 * 128) {
+        if (d->Cout == 32) hipLaunchKernelGGL((stem_wgrad_u8_kernel<32>), grid, dim3(64), lds, s, *d, spw, segs_per_row, (int)nsegs);
+        else hipLaunchKernelGGL((stem_wgrad_u8_kernel<16>), grid, dim3(64), lds, s, *d, spw, segs_per_row, (int)nsegs);
+    } else
     STEM_DISPATCH_W(stem_wgrad_kernel, grid, lds, *d, spw, segs_per_row, (int)nsegs);
     DYK_LAUNCH_CHECK();
     const int n = d->Cout * 27;

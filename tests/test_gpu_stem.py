@@ -28,13 +28,16 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-CASES = [(32, 1, torch.bfloat16, False, (2, 40, 56)), (32, 1, torch.float32, True, (3, 33, 47)),
-         (16, 2, torch.bfloat16, True, (2, 64, 96)), (32, 2, torch.float32, False, (1, 31, 45)),
-         (32, 1, torch.bfloat16, True, (16, 128, 160))]
+CASES = [(32, 1, torch.bfloat16, False, (2, 40, 56), False), (32, 1, torch.float32, True, (3, 33, 47), False),
+         (16, 2, torch.bfloat16, True, (2, 64, 96), False), (32, 2, torch.float32, False, (1, 31, 45), False),
+         (32, 1, torch.bfloat16, True, (16, 128, 160), False),
+         # tight rows (ld == cout) + uint8 + bf16: the word-load / prefetching weight-gradient kernel
+         (16, 2, torch.bfloat16, True, (2, 64, 96), True), (16, 2, torch.bfloat16, True, (3, 70, 600), True),
+         (32, 1, torch.bfloat16, True, (2, 37, 300), True), (16, 1, torch.bfloat16, True, (1, 9, 12), True)]
 
 
-@pytest.mark.parametrize("cout,stride,dtype,u8,shape", CASES)
-def test_stem_forward_statistics_and_weight_gradient(cout, stride, dtype, u8, shape):
+@pytest.mark.parametrize("cout,stride,dtype,u8,shape,tight", CASES)
+def test_stem_forward_statistics_and_weight_gradient(cout, stride, dtype, u8, shape, tight):
     from dyk import lib as L
     lib = L.load()
     B, H, W = shape
@@ -48,7 +51,7 @@ def test_stem_forward_statistics_and_weight_gradient(cout, stride, dtype, u8, sh
     wt = w_store.view(cout, 27).t().contiguous()
     d = _desc(img, w, stride, dtype)
     Ho, Wo = d.Ho, d.Wo
-    ld = 32
+    ld = cout if tight else 32
     y = torch.zeros((B, Ho, Wo, ld), dtype=dtype, device="cuda")
     slots = 4
     stats = torch.zeros((slots, 2 * cout), dtype=torch.float64, device="cuda")
