@@ -241,12 +241,19 @@ __global__ __launch_bounds__(64) void stem_wgrad_kernel(const DykStemDesc d, int
 //    buffer), so a segment costs one exposed memory round trip per workgroup instead of ~5 per segment.
 template <int COUT>
 __global__ __launch_bounds__(64) void stem_wgrad_u8_kernel(const DykStemDesc d, int segs_per_wg, int segs_per_row, int nsegs) {
+    // bf16 MFMA (v_mfma_f32_32x32x16_bf16, 16 pixels per instruction instead of 2): a uint8 pixel value is an integer
+    // <= 255 and EXACT in bf16, dy is bf16 already, products and sums are fp32 -- sum(dy * x) / 255 in place of
+    // sum(dy * (x / 255)) differs by one rounding of the final scale.  A[i = co][k], B[k][j = tc]: lane (i | j = lane & 31,
+    // g = lane >> 5) supplies k = 8 g .. 8 g + 7 of both operands = pixels x0 + 8 g + (0..7) (the same pixels on both
+    // sides, so the sum over k is right whatever order the hardware walks them in).
     using T = bf16_t;
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int Wseg = STEM_SEG * d.stride + 2;
-    T* s_dy = (T*)smem;                                           // [SEG][32]
-    float* s_img = (float*)(smem + STEM_SEG * 32 * sizeof(T));    // [3 ky][3 c][Wseg]
+    constexpr int RS = STEM_SEG + 8;                              // dy^T row: 128 pixels + 16 bytes (bank spread)
+    uint16_t* s_dyT = (uint16_t*)smem;                            // [32 co][RS]
+    uint16_t* s_img = (uint16_t*)(smem + 32 * RS * 2);            // [3 ky][3 c][Wseg] pixel values as bf16 integers
     const int i = lane & 31, kk = lane >> 5;
     const int tc = i;
     const int c = tc % 3, kx = (tc / 3) % 3, ky = tc / 9;
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(64) void stem_wgrad_u8_kernel(const DykStemDesc d, 
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* s_b = s_img + (ky * 3 + c) * Wseg + kx;
+    const uint16_t* s_b = s_img + (ky * 3 + c) * Wseg + kx;
     constexpr int VPP = COUT / 8;                                 // 16-byte vectors per pixel (tight rows: lddy == COUT)
     constexpr int NV = STEM_SEG * VPP / 64;                       // per lane and segment: 4 (16 channels) | 8 (32)
     const int wpr = (Wseg + 3 + 3) / 4;                           // words per patch row, from the aligned start x0 - 4
@@ -292,10 +299,18 @@ __global__ __launch_bounds__(64) void stem_wgrad_u8_kernel(const DykStemDesc d, 
         const int npx = min(STEM_SEG, d.Wo - x_begin);
         const int nvec = npx * VPP;
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
+        for (int u = 0; u < NV; ++u) {                            // transpose on the way in: [pixel][co] -> [co][pixel]
             const int v = lane + u * 64;
-            if (v < nvec) ((uint4*)s_dy)[(v / VPP) * 4 + (v % VPP)] = t[u];
+            if (v < nvec) {
+                const int px = v / VPP, c0 = (v % VPP) * 8;
+                const uint32_t w4[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s_dyT[(c0 + j) * RS + px] = (uint16_t)(w4[j >> 1] >> (16 * (j & 1)));
+            }
         }
+        // pixels [npx, next multiple of 16) take part in the last MFMA: zero gradient
+        const int ntail = ((npx + 15) & ~15) - npx;
+        for (int e = lane; e < COUT * ntail; e += 64) s_dyT[(e / ntail) * RS + npx + e % ntail] = 0;
 #pragma unroll
         for (int rr = 0; rr < 9; ++rr)
 #pragma unroll
@@ -305,7 +320,8 @@ __global__ __launch_bounds__(64) void stem_wgrad_u8_kernel(const DykStemDesc d, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int xp = 4 * w + j - 3;
-                    if (xp >= 0 && xp < Wseg) s_img[rr * Wseg + xp] = (float)((iw[rr][h] >> (8 * j)) & 0xffu) / 255.0f;
+                    if (xp >= 0 && xp < Wseg)
+                        s_img[rr * Wseg + xp] = (uint16_t)(__float_as_uint((float)((iw[rr][h] >> (8 * j)) & 0xffu)) >> 16);
                 }
             }
     };
@@ -319,19 +335,17 @@ __global__ __launch_bounds__(64) void stem_wgrad_u8_kernel(const DykStemDesc d, 
         park(sg);
         __syncthreads();
         if (sg + 1 < seg1) fetch(sg + 1);                         // in flight during the MFMAs below
-        for (int x0 = 0; x0 < npx; x0 += 8) {
-            float a[4], bv[4];
+        for (int x0 = 0; x0 < npx; x0 += 16) {
+            uint4 av = *(const uint4*)(s_dyT + i * RS + x0 + 8 * kk);
+            if (i >= COUT) av = make_uint4(0u, 0u, 0u, 0u);
+            uint32_t bw[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int xo = x0 + u * 2 + kk;
-                const bool live = xo < npx;
-                const float av = ElemTraits<T>::to_f32(s_dy[(live ? xo : 0) * 32 + i]);
-                const float xv = s_b[(live ? xo : 0) * d.stride];
-                a[u] = (live && i < COUT) ? av : 0.f;
-                bv[u] = (live && tc_ok) ? xv : 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = s_b[(x0 + 8 * kk + 2 * j) * d.stride], hi = s_b[(x0 + 8 * kk + 2 * j + 1) * d.stride];
+                bw[j] = tc_ok ? (lo | (hi << 16)) : 0u;
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u], acc, 0, 0, 0);
+            const uint4 bv = make_uint4(bw[0], bw[1], bw[2], bw[3]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, av), __builtin_bit_cast(bf16x8_v, bv), acc, 0, 0, 0);
         }
     }
     float* out = d.part + (size_t)blockIdx.x * COUT * 27;
@@ -339,7 +353,7 @@ __global__ __launch_bounds__(64) void stem_wgrad_u8_kernel(const DykStemDesc d, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = (r & 3) + 8 * (r >> 2) + 4 * kk;
-            if (co < COUT) out[co * 27 + tc] = acc[r];
+            if (co < COUT) out[co * 27 + tc] = acc[r] * (1.0f / 255.0f);
         }
     }
 }
