@@ -1,8 +1,4 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err
-python - <<'P'
-import json
-d=json.loads(open("gpurun_out/bench.json").read().strip().splitlines()[-1])
-r=d["roofline"]; print(d["ms_per_step"], d["value"], r["frac"], r["traffic"], (r["in_step"] or {}).get("tflops"), d["cpu_baseline"]["value"], d["cpu_baseline"]["c1"]["value"])
-P
+bash tools/ab.sh "DYK_FWD_SLOTS_CAP=256" "DYK_FWD_SLOTS_CAP=32" "DYK_FWD_SLOTS_CAP=64" > gpurun_out/ab_slots3.log 2>&1; cat gpurun_out/ab_slots3.log
+AB_ARGS="--cfg kaist_dyolov4_mobilenetv3_fshare_global_cse3 --batch 32" bash tools/ab.sh "DYK_FWD_SLOTS_CAP=256" "DYK_FWD_SLOTS_CAP=32" > gpurun_out/ab_slots2.log 2>&1; cat gpurun_out/ab_slots2.log
