@@ -1,4 +1,8 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-bash tools/ab.sh "A=1" "DYK_TUNE_COLD=1" > gpurun_out/ab_cold.log 2>&1; cat gpurun_out/ab_cold.log
-AB_ARGS="--cfg kaist_dyolov4_mobilenetv3_fshare_global_cse3 --batch 32" bash tools/ab.sh "A=1" "DYK_TUNE_COLD=1" >> gpurun_out/ab_cold.log 2>&1; tail -4 gpurun_out/ab_cold.log
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err
+python - <<'P'
+import json
+d=json.loads(open("gpurun_out/bench.json").read().strip().splitlines()[-1])
+r=d["roofline"]; print(d["ms_per_step"], d["value"], r["frac"], r["traffic"], (r["in_step"] or {}).get("tflops"), d["cpu_baseline"]["value"], d["cpu_baseline"]["c1"]["value"])
+P
