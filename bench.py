@@ -29,7 +29,7 @@ import torch  # noqa: E402
 CFG = "kaist_dyolov4_fshare_global_concat_se3"
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
-PROFILE_TAG = "r02"            # profiles/<tag>_*.json written by tools/run_gpu_round.sh for this round
+PROFILE_TAG = "r03"            # profiles/<tag>_*.json written by tools/run_gpu_round.sh for this round
 
 
 def synth_batch(B, H, W, rank, device):
@@ -68,33 +68,41 @@ def conv_flops(plan, stems=True):
 
 
 def profile_plan(plan, stream, dump=None, cmds_out=None):
-    """per-op-kind kernel time (ms) of one forward and one backward pass, HIP events on `stream`"""
+    """per-op-kind kernel time (ms) of one forward and one backward pass: every LAUNCH of the step -- the entries of
+    the plan's schedule, two-problem launches of the twin sections included as the single launches they are -- timed
+    alone on the chip with HIP events on `stream` (dyk_run_schedule_timed)"""
     from dyk import lib as L
     res = {}
     rows = []
     for which in ("fwd", "bwd"):
         cmds = plan.fwd if which == "fwd" else plan.bwd
         arr = plan._cfwd if which == "fwd" else plan._cbwd
-        ms = (ctypes.c_float * len(cmds))()
-        L.check(L.load().dyk_run_commands_timed(arr, len(cmds), ctypes.c_void_p(stream), ms), "dyk_run_commands_timed")
+        sc = plan.schedule(which, 0, len(cmds))
+        ms = (ctypes.c_float * max(sc.n, 1))()
+        L.check(L.load().dyk_run_schedule_timed(arr, sc.array, sc.n, ctypes.c_void_p(stream), ms), "dyk_run_schedule_timed")
         agg = {}
-        for (op, desc), t in zip(cmds, ms):
-            a = agg.setdefault(op, [0, 0.0])
+        base = len(cmds_out) if cmds_out is not None else 0
+        for k, (e, t) in enumerate(zip(sc.entries, ms)):
+            op, desc = cmds[e["cmd"]]
+            nprob = 2 if e.get("cmd2", -1) >= 0 else 1
+            a = agg.setdefault(op, [0, 0.0, 0])
             a[0] += 1
             a[1] += float(t)
+            a[2] += nprob
             if cmds_out is not None:
                 from cmd_roofline import cmd_model
                 label, by, fl = cmd_model(L, op, desc, plan)
-                cmds_out.append({"pass": which, "label": label, "us": float(t) * 1e3, "bytes": by, "flops": fl})
+                cmds_out.append({"pass": which, "label": label + (" x2" if nprob == 2 else ""), "us": float(t) * 1e3,
+                                 "bytes": by * nprob, "flops": fl * nprob, "deps": sc.entry_deps[k]})
             if dump is not None and op in (L.OP_CONV, L.OP_WGRAD):
                 if op == L.OP_CONV:
                     rows.append(dict(pass_=which, op="conv", Cin=desc.Cin, Cout=desc.Cout, Hg=desc.Hg, Wg=desc.Wg, taps=desc.ntaps,
-                                     isy=desc.isy, osy=desc.osy, flags=desc.flags, ms=float(t),
-                                     tflops=2.0 * desc.B * desc.Hg * desc.Wg * desc.Cin * desc.Cout * desc.ntaps / max(float(t), 1e-6) / 1e9))
+                                     isy=desc.isy, osy=desc.osy, flags=desc.flags, ms=float(t), problems=nprob,
+                                     tflops=2.0 * nprob * desc.B * desc.Hg * desc.Wg * desc.Cin * desc.Cout * desc.ntaps / max(float(t), 1e-6) / 1e9))
                 else:
                     rows.append(dict(pass_=which, op="wgrad", Cin=desc.Cin, Cout=desc.Cout, Hg=desc.Ho, Wg=desc.Wo, taps=desc.ntaps,
-                                     isy=desc.isy, ms=float(t),
-                                     tflops=2.0 * desc.B * desc.Ho * desc.Wo * desc.Cin * desc.Cout * desc.ntaps / max(float(t), 1e-6) / 1e9))
+                                     isy=desc.isy, ms=float(t), problems=nprob,
+                                     tflops=2.0 * nprob * desc.B * desc.Ho * desc.Wo * desc.Cin * desc.Cout * desc.ntaps / max(float(t), 1e-6) / 1e9))
         res[which] = agg
     if dump is not None:
         os.makedirs(os.path.dirname(dump), exist_ok=True)
@@ -342,17 +350,26 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(args.steps):
+    # per-step durations from HIP events on the step's stream (no host synchronisation inside the timed region): median_ms
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    evs[0].record()
+    for q in range(args.steps):
         loss = step()
+        evs[q + 1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.time() - t0
+    rccl_ranks = None
     if dist is not None:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # proof that the collective saw every rank: a SUM of ones over the job's communicator
+        one = torch.ones(1, device=device, dtype=torch.float64)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(round(float(one.item())))
     final_loss = float(loss.item())
 
     out = None
@@ -365,7 +382,8 @@ def main():
                "config": {"workload": "%s.cfg train step (fwd+loss+bwd+Adam%s), 640x512 pairs, batch %d/GPU"
                                       % (args.cfg, "+RCCL grad all-reduce" if world > 1 else "", B),
                           "global_batch": B * world, "parallelism": "dp%d" % world},
-               "final_loss": final_loss}
+               "final_loss": final_loss, "rccl_ranks": rccl_ranks,
+               "median_ms": sorted(evs[q].elapsed_time(evs[q + 1]) for q in range(args.steps))[args.steps // 2]}
         if not args.no_roofline:
             plan = model.engine.plans[(B, H, W, torch.bfloat16 if args.dtype == "bf16" else torch.float32, True)]
             from dyk import lib as L
@@ -373,25 +391,31 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             prof = profile_plan(plan, torch.cuda.current_stream().cuda_stream, args.dump_layers, cmds_out)
             if cmds_out is not None:
-                # dependency lists (indices within the pass) for the critical-path figure of tools/cmd_roofline.py
-                from dyk import sched
-                mem = sched.Memory(plan, plan.store)
-                k = 0
-                for which in ("fwd", "bwd"):
-                    cmds = plan.fwd if which == "fwd" else plan.bwd
-                    for dl in sched.dependencies(cmds, mem, plan):
-                        cmds_out[k]["deps"] = dl
-                        k += 1
+                # (rows carry their dependency lists -- launch positions within the pass -- for the critical-path figure
+                # of tools/cmd_roofline.py)
                 with open(args.dump_cmds, "w") as f:
                     json.dump(cmds_out, f)
             f1_all = conv_flops(plan)
             f1 = conv_flops(plan, stems=False)          # what the implicit-GEMM family computes
-            ig_ms = prof["fwd"].get(L.OP_CONV, [0, 0.0])[1] + prof["bwd"].get(L.OP_CONV, [0, 0.0])[1]
-            ig_n = prof["fwd"].get(L.OP_CONV, [0, 0.0])[0] + prof["bwd"].get(L.OP_CONV, [0, 0.0])[0]
-            wg_n, wg_ms = prof["bwd"].get(L.OP_WGRAD, [0, 0.0])
+            ig_ms = prof["fwd"].get(L.OP_CONV, [0, 0.0, 0])[1] + prof["bwd"].get(L.OP_CONV, [0, 0.0, 0])[1]
+            ig_n = prof["fwd"].get(L.OP_CONV, [0, 0.0, 0])[0] + prof["bwd"].get(L.OP_CONV, [0, 0.0, 0])[0]
+            wg_n, wg_ms = prof["bwd"].get(L.OP_WGRAD, [0, 0.0, 0])[:2]
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = 2.0 * f1 / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0      # forward + data-gradient launches
             tot_ms = sum(a[1] for w in prof.values() for a in w.values())
+            # composite roofline -- every command at max(HBM time, MFMA time) of its algorithmic work
+            # (forward + data gradient + weight gradient of every layer) over the measured step
+            comp = None
+            try:
+                from cmd_roofline import cmd_model
+                fl_ms = 0.0
+                for which in ("fwd", "bwd"):
+                    for op, desc in (plan.fwd if which == "fwd" else plan.bwd):
+                        _, by, fl = cmd_model(L, op, desc, plan)
+                        fl_ms += max(by / 8.0e12, fl / (PEAK_BF16_TFLOPS * 1e12 if args.dtype == "bf16" else PEAK_F32_TFLOPS * 1e12)) * 1e3
+                comp = {"floor_ms": fl_ms, "frac": fl_ms / ms}
+            except Exception:
+                pass
             # HBM-side bytes per launch and the IN-STEP durations of the same kernel come from rocprofv3 runs of this very
             # command (tools/run_gpu_round.sh -> profiles/): they are reported only when those files were produced by
             # the code that is running now (hash over the kernel sources and the plan compiler), otherwise null
@@ -429,6 +453,9 @@ def main():
                     "wgrad_tflops": (f1 / (wg_ms * 1e-3) / 1e12) if wg_ms > 0 else 0.0, "wgrad_ms": wg_ms, "wgrad_launches": wg_n,
                     "igemm_ms": ig_ms, "all_kernels_ms": tot_ms,
                     "step_mfma_frac": 3.0 * f1_all / (ms * 1e-3) / 1e12 / peak,
+                    "composite_roofline": comp,
+                    "launches_per_step": sum(a[0] for w in prof.values() for a in w.values()),
+                    "commands_per_step": sum(a[2] for w in prof.values() for a in w.values()),
                     "per_op_ms": {w: {str(k): [a[0], round(a[1], 4)] for k, a in prof[w].items()} for w in prof}}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cfg)

@@ -47,10 +47,19 @@ def _on_device(t):
 def _dyk_rows(t, what):
     """(data pointer, row count, row stride in floats) of a 2-D fp32 device tensor whose rows are contiguous"""
     from dyk import lib as L
-    if t.dim() != 2 or t.shape[1] < 4 or t.dtype != torch.float32 or (t.shape[0] > 1 and t.stride(1) != 1):
+    if t.dim() != 2 or t.shape[1] < 4 or t.dtype != torch.float32 or (t.shape[0] > 0 and t.stride(1) != 1):
         raise L.DykError("%s expects an fp32 [n, >=4] device tensor with unit column stride, got %s %s strides %s"
                          % (what, t.dtype, tuple(t.shape), t.stride()))
     return t.data_ptr(), int(t.shape[0]), int(t.stride(0)) if t.shape[0] > 1 else int(t.shape[1])
+
+
+def _kernel_view(t):
+    """the tensor the box kernels can work on: `t` itself when it is fp32 with unit column stride, else an fp32 copy
+    with contiguous rows (the reference's tensor expressions accept any dtype / view: half or double boxes, column
+    views -- the kernels compute in fp32, the result is cast back by the caller)"""
+    if t.dtype == torch.float32 and (t.shape[0] == 0 or t.stride(1) == 1):
+        return t
+    return t.to(torch.float32).contiguous()
 
 
 def _stream():
@@ -60,11 +69,13 @@ def _stream():
 def _convert(x, to_xyxy):
     if _on_device(x):
         from dyk.lib import check, load
-        out = torch.zeros_like(x)                  # columns past the box stay 0, as with the reference's zeros_like
-        src, n, ld = _dyk_rows(x, "xywh2xyxy" if to_xyxy else "xyxy2xywh")
+        xk = _kernel_view(x)
+        out = torch.zeros(x.shape, dtype=torch.float32, device=x.device)   # columns past the box stay 0 (reference: zeros_like)
+        src, n, ld = _dyk_rows(xk, "xywh2xyxy" if to_xyxy else "xyxy2xywh")
         dst, _, ldo = _dyk_rows(out, "box conversion output")
-        check(load().dyk_box_convert(src, dst, n, ld, ldo, 1 if to_xyxy else 0, _stream()), "dyk_box_convert")
-        return out
+        if n:
+            check(load().dyk_box_convert(src, dst, n, ld, ldo, 1 if to_xyxy else 0, _stream()), "dyk_box_convert")
+        return out if x.dtype == torch.float32 else out.to(x.dtype)
     out = torch.zeros_like(x) if isinstance(x, torch.Tensor) else np.zeros_like(x)
     first, second = x[:, 0:2], x[:, 2:4]
     if to_xyxy:                                    # centre / size -> corners
@@ -91,9 +102,13 @@ def _clip_scale(boxes, img0_shape, pad=(0.0, 0.0), gain=1.0, scale=False):
     h0, w0 = float(img0_shape[0]), float(img0_shape[1])
     if _on_device(boxes):
         from dyk.lib import check, load
-        ptr, n, ld = _dyk_rows(boxes, "scale_coords")
-        check(load().dyk_scale_coords(ptr, n, ld, float(pad[0]), float(pad[1]), float(gain), w0, h0, 1 if scale else 0,
-                                      _stream()), "dyk_scale_coords")
+        bk = _kernel_view(boxes)
+        ptr, n, ld = _dyk_rows(bk, "scale_coords")
+        if n:
+            check(load().dyk_scale_coords(ptr, n, ld, float(pad[0]), float(pad[1]), float(gain), w0, h0, 1 if scale else 0,
+                                          _stream()), "dyk_scale_coords")
+        if bk is not boxes:
+            boxes.copy_(bk)                        # in place, like the reference (dtype / view of the caller kept)
         return
     for cols, off, hi in (((0, 2), pad[0], w0), ((1, 3), pad[1], h0)):
         for c in cols:

@@ -13,7 +13,8 @@
 namespace {
 
 // 32 lanes per channel: lane r sums replicas r, r+32, ... , a 5-step xor-shuffle folds them, lane 0 finalises
-__global__ __launch_bounds__(256) void bn_finalize_kernel(DykBnFinalizeDesc d) {
+__global__ __launch_bounds__(256) void bn_finalize_kernel(DykFinPair pr) {
+    const DykBnFinalizeDesc& d = pr.d[blockIdx.z];
     const int sub = threadIdx.x & 31;
     const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (c >= d.C) return;
@@ -60,7 +61,8 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
 // loop, per-channel parameters live in registers, and a wave touches CVB*16 contiguous bytes per pixel
 // row (whole rows for C <= 256 bf16), i.e. fully coalesced when ld == C.
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwDesc d, int CVB) {
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwPair pr, int CVB) {
+    const DykEwDesc& d = pr.d[blockIdx.z];
     constexpr int EPV = ElemTraits<T>::EPV;
     const int PY = 256 / CVB;
     const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
@@ -110,7 +112,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwDesc d, int CVB) {
 // for the backward pass and update the running statistics.  The replicas are NOT re-armed here (other workgroups
 // may still be reading them): the caller zeroes the statistics arena once per forward pass.
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void bn_fused_fwd_kernel(DykBnFinalizeDesc f, DykEwDesc d, int CVB) {
+__global__ __launch_bounds__(256) void bn_fused_fwd_kernel(DykFinPair fp, DykEwPair pr, int CVB) {
+    const DykBnFinalizeDesc& f = fp.d[blockIdx.z];
+    const DykEwDesc& d = pr.d[blockIdx.z];
     constexpr int EPV = ElemTraits<T>::EPV;
     __shared__ float s_aff[2][256];
     const int PY = 256 / CVB;
@@ -194,7 +198,8 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(DykBnFinalizeDesc f, 
 
 // block = (CVB channel vectors) x (PY pixel lanes); grid.x over channel-vector groups, grid.y over pixels
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(DykEwDesc d, int CVB) {
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(DykEwPair pr, int CVB) {
+    const DykEwDesc& d = pr.d[blockIdx.z];
     constexpr int EPV = ElemTraits<T>::EPV;
     __shared__ float red[256 * 2 * 8];
     const int PY = 256 / CVB;
@@ -276,7 +281,8 @@ __global__ __launch_bounds__(256) void bn_bwd_params_kernel(double* red, float* 
 // channels through LDS -- 2 x 32 coalesced fp64 loads per thread), and the workgroups of grid row 0 add them to
 // dgamma / dbeta (aux / aux2): no separate parameter-gradient launch on the critical chain of the backward pass.
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwDesc d, int CVB) {
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwPair pr, int CVB) {
+    const DykEwDesc& d = pr.d[blockIdx.z];
     constexpr int EPV = ElemTraits<T>::EPV;
     __shared__ float s_tot[2][256];
     const int PY = 256 / CVB;
@@ -403,7 +409,10 @@ inline int ew_check(const DykEwDesc* d, bool need_b) {
 
 extern "C" int dyk_bn_finalize(const DykBnFinalizeDesc* d, void* stream) {
     if (!d || !d->stats || !d->scale || !d->shift || d->C <= 0 || d->count <= 0) return DYK_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 7) / 8), dim3(256), 0, (hipStream_t)stream, *d);
+    DykFinPair fp;
+    const int nz = dyk_fill_fin_pair(fp, d);
+    if (!nz) return DYK_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 7) / 8, 1, nz), dim3(256), 0, (hipStream_t)stream, fp);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -424,7 +433,10 @@ extern "C" int dyk_bn_act_fwd(const DykEwDesc* d, void* stream) {
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     int gx, gy;
     const int CVB = ew_grid2d(d->C / epv, d->npix, &gx, &gy);
-    DYK_BN_LAUNCH(bn_act_fwd_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB)
+    DykEwPair pr;
+    const int nz = dyk_fill_ew_pair(pr, d);
+    if (!nz) return DYK_ERR_ARG;
+    DYK_BN_LAUNCH(bn_act_fwd_kernel, dim3(gx, gy, nz), dim3(256), 0, (hipStream_t)stream, pr, CVB)
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -437,7 +449,11 @@ extern "C" int dyk_bn_finalize_act_fwd(const DykBnFinalizeDesc* f, const DykEwDe
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     int gx, gy;
     const int CVB = ew_grid2d(d->C / epv, d->npix, &gx, &gy);
-    DYK_BN_LAUNCH(bn_fused_fwd_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *f, *d, CVB)
+    DykEwPair pr;
+    DykFinPair fp;
+    const int nz = dyk_fill_ew_pair(pr, d);
+    if (!nz || dyk_fill_fin_pair(fp, f) != nz) return DYK_ERR_ARG;       // both descriptors paired, or neither
+    DYK_BN_LAUNCH(bn_fused_fwd_kernel, dim3(gx, gy, nz), dim3(256), 0, (hipStream_t)stream, fp, pr, CVB)
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -456,7 +472,10 @@ extern "C" int dyk_bn_act_bwd_reduce(const DykEwDesc* d, void* stream) {
     const long cap = 2048 / gx > 0 ? 2048 / gx : 1;
     if (gy > cap) gy = cap;
     if (gy < 1) gy = 1;
-    DYK_BN_LAUNCH(bn_act_bwd_reduce_kernel, dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, *d, CVB)
+    DykEwPair pr;
+    const int nz = dyk_fill_ew_pair(pr, d);
+    if (!nz) return DYK_ERR_ARG;
+    DYK_BN_LAUNCH(bn_act_bwd_reduce_kernel, dim3(gx, (int)gy, nz), dim3(256), 0, (hipStream_t)stream, pr, CVB)
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -476,7 +495,10 @@ extern "C" int dyk_bn_act_bwd_apply(const DykEwDesc* d, void* stream) {
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     int gx, gy;
     const int CVB = ew_grid2d(d->C / epv, d->npix, &gx, &gy);
-    DYK_BN_LAUNCH(bn_act_bwd_apply_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB)
+    DykEwPair pr;
+    const int nz = dyk_fill_ew_pair(pr, d);
+    if (!nz) return DYK_ERR_ARG;
+    DYK_BN_LAUNCH(bn_act_bwd_apply_kernel, dim3(gx, gy, nz), dim3(256), 0, (hipStream_t)stream, pr, CVB)
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

@@ -1,5 +1,7 @@
 // C-ABI front end of the implicit-GEMM convolution: argument validation and the choice of the pixel-tile
 // instantiation (conv_igemm_n{80,128,160}.hip; kernel in conv_igemm_kernel.h).
+#include <stddef.h>
+#include <string.h>
 #include "dyk_common.h"
 
 int dyk_conv_launch_n128(const DykConvDesc* d, hipStream_t s);
@@ -8,7 +10,7 @@ int dyk_conv_launch_n160(const DykConvDesc* d, hipStream_t s);
 int dyk_conv_launch_halo(const DykConvDesc* d, hipStream_t s, int th);
 int dyk_conv_launch_kg(const DykConvDesc* d, hipStream_t s);
 
-extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
+static int conv_validate(const DykConvDesc* d) {
     if (!d || !d->x || !d->w || !d->y) return DYK_ERR_ARG;
     if (d->ntaps < 0 || d->ntaps > DYK_MAX_TAPS) return DYK_ERR_ARG;
     if (d->B <= 0 || d->Hg <= 0 || d->Wg <= 0 || d->Cout <= 0 || d->Cin <= 0) return DYK_ERR_ARG;
@@ -36,6 +38,18 @@ extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
     if ((long)d->B * d->Hi * d->Wi * d->ldx >= (1L << 31)) return DYK_ERR_ARG;
     if ((long)d->B * d->Ho * d->Wo * d->ldy >= (1L << 31)) return DYK_ERR_ARG;
     if (d->Hi > 16000 || d->Wi > 16000) return DYK_ERR_ARG;
+    return DYK_OK;
+}
+
+extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
+    int rc0 = conv_validate(d);
+    if (rc0 != DYK_OK) return rc0;
+    if (d->twin) {
+        // two-problem launch: the twin must be a valid problem of its own and agree in every non-pointer field
+        if ((rc0 = conv_validate(d->twin)) != DYK_OK) return rc0;
+        const size_t lo = offsetof(DykConvDesc, dtype), hi = offsetof(DykConvDesc, twin);
+        if (memcmp((const char*)d + lo, (const char*)d->twin + lo, hi - lo) != 0) return DYK_ERR_ARG;
+    }
     hipStream_t s = (hipStream_t)stream;
     const int tile = d->dtype == DYK_BF16 ? (d->tune >> 12) & 0xf : 0;      // 80 / 160 pixel tiles are built for bf16 only
     if (((d->tune >> 28) & 7) == 1) {      // K-grouped workgroups (conv_igemm_kg.hip); generic tiles where they do not apply

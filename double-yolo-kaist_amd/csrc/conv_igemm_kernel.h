@@ -24,9 +24,22 @@
 
 namespace {
 
+// d[1] = the twin problem of a two-problem launch (DykConvDesc.twin: pointer fields differ only); pair_tiles = workgroups
+// per problem rounded up to a multiple of 8 (so that both halves see the same block -> XCD relation), 0 = single problem
 struct ConvArgs {
-    DykConvDesc d;
+    DykConvDesc d[2];
+    int pair_tiles;
 };
+
+// workgroup -> (problem, block id within the problem, blocks per problem)
+__device__ inline int conv_pick_problem(const ConvArgs& args, int& blk, int& nblk) {
+    blk = blockIdx.x; nblk = gridDim.x;
+    if (args.pair_tiles == 0) return 0;
+    const int sel = blk >= args.pair_tiles ? 1 : 0;
+    blk -= sel * args.pair_tiles;
+    nblk = args.pair_tiles;
+    return sel;
+}
 
 // set by the launcher when y / ldy allow 8/16-byte vector stores
 constexpr int EPI_INTERNAL_VEC = 1 << 30;
@@ -91,7 +104,7 @@ template <int BN> constexpr int table_bytes() { return BN * (3 * 4 + 2 * 2) + 10
 // coalesced stores.  Called by every thread after the K loop's last barrier (the operand ring is free: sC overlays it).
 template <typename T, int BM, int BN>
 __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&acc)[(BM / WaveGrid<BM, BN>::WM) / 16][(BN / WaveGrid<BM, BN>::WN) / 16],
-                                              char* sC, float* s_stat, const int* t_out, const int* t_res, int m0) {
+                                              char* sC, float* s_stat, const int* t_out, const int* t_res, int m0, int blk) {
     constexpr int WM = WaveGrid<BM, BN>::WM, WN = WaveGrid<BM, BN>::WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = WTM / 16, NI = WTN / 16;
@@ -141,7 +154,7 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
                 float tot = 0.f;
 #pragma unroll
                 for (int q = 0; q < WN; ++q) tot += s_stat[(q * 2 + which) * BM + ml];
-                double* st = a.stats + (size_t)(blockIdx.x % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
+                double* st = a.stats + (size_t)((unsigned)blk % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
                 atomicAdd(st + which * a.Cout + m0 + ml, (double)tot);
             }
         }
@@ -405,7 +418,7 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
                 if (m0 + ml < a.Cout) {
                     const float tot = (s_stat[(0 * 2 + which) * BM + ml] + s_stat[(1 * 2 + which) * BM + ml]) +
                                       (s_stat[(2 * 2 + which) * BM + ml] + s_stat[(3 * 2 + which) * BM + ml]);
-                    double* st = a.stats + (size_t)(blockIdx.x % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
+                    double* st = a.stats + (size_t)((unsigned)blk % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
                     atomicAdd(st + which * a.Cout + m0 + ml, (double)tot);
                 }
             }
@@ -494,7 +507,8 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
 template <typename T, int BM, int BN, int BKB, int PIPE, int KG = 1>
 __global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_kernel(const ConvArgs args) {
     static_assert(KG == 1 || PIPE == 2, "K-groups use the 2-stage ring");
-    const DykConvDesc& a = args.d;
+    int blk, nblk;
+    const DykConvDesc& a = args.d[conv_pick_problem(args, blk, nblk)];
     constexpr int TABLE_BYTES = table_bytes<BN>();
     constexpr int EPV = 16 / (int)sizeof(T);
     constexpr int BK = BKB / (int)sizeof(T);
@@ -537,7 +551,8 @@ __global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(3))) v
     const int HWg = a.Hg * a.Wg;
     const int Ntot = a.B * HWg;
     const int tiles_n = (Ntot + BN - 1) / BN;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid = xcd_remap(blk, nblk);
+    if (bid >= tiles_n * ((a.Cout + BM - 1) / BM) * (a.ncls > 1 ? a.ncls : 1)) return;    // padding blocks of a two-problem launch
     // output-parity classes of a strided data gradient in one launch: class fastest, so the classes of a pixel tile
     // run side by side on one XCD (shared gradient tile, interleaved output lines merge in its L2)
     int ntaps = a.ntaps, tap0 = 0, ooy = a.ooy, oox = a.oox;
@@ -746,7 +761,7 @@ __global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(3))) v
     }
 
     // ------------------------------------------------------------------ epilogue
-    conv_epilogue<T, BM, BN>(a, acc, sC, s_stat, t_out, t_res, m0);
+    conv_epilogue<T, BM, BN>(a, acc, sC, s_stat, t_out, t_res, m0, blk);
 }
 
 // ======================================================================================
@@ -766,7 +781,8 @@ template <int BM, int TH> constexpr int halo_table_bytes() {
 
 template <typename T, int BM, int TH, int BKB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_halo_kernel(const ConvArgs args) {
-    const DykConvDesc& a = args.d;
+    int blk, nblk;
+    const DykConvDesc& a = args.d[conv_pick_problem(args, blk, nblk)];
     using G = HaloGeom<TH>;
     constexpr int TW = G::TW, HW = G::HW, BN = G::BN, HR = G::HR;
     constexpr int EPV = 16 / (int)sizeof(T);
@@ -802,7 +818,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const int wm = wid / WN, wn = wid % WN;
     const int tiles_x = a.Wi / TW, tiles_y = a.Hi / TH;
     const int tiles_n = a.B * tiles_y * tiles_x;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = xcd_remap(blk, nblk);
+    if (bid >= tiles_n * ((a.Cout + BM - 1) / BM)) return;     // padding blocks of a two-problem launch
     const int m0 = (bid / tiles_n) * BM;
     int nt = bid % tiles_n;
     const int bimg = nt / (tiles_y * tiles_x);
@@ -938,7 +955,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         nxt = (nxt == NA - 1) ? 0 : nxt + 1;
         if (++t == 9) { t = 0; ++c; }
     }
-    conv_epilogue<T, BM, BN>(a, acc, sC, s_stat, t_out, t_res, m0);
+    conv_epilogue<T, BM, BN>(a, acc, sC, s_stat, t_out, t_res, m0, blk);
+}
+
+// fills the kernel arguments of a single- or two-problem launch; returns the grid size.  `vec`: the staged (16-byte
+// vector) epilogue is possible for every problem of the launch
+inline unsigned conv_fill_args(ConvArgs& args, const DykConvDesc* d, int tiles, bool vec) {
+    args.d[0] = *d;
+    args.d[0].twin = nullptr;
+    args.pair_tiles = 0;
+    unsigned grid = (unsigned)tiles;
+    if (d->twin) {
+        args.d[1] = *d->twin;
+        args.d[1].twin = nullptr;
+        args.pair_tiles = (tiles + 7) & ~7;
+        grid = 2u * (unsigned)args.pair_tiles;
+    }
+    for (int q = 0; q < (d->twin ? 2 : 1); ++q) {
+        if (vec) args.d[q].flags |= EPI_INTERNAL_VEC;
+        else args.d[q].flags &= ~EPI_INTERNAL_VEC;
+    }
+    return grid;
+}
+// can the staged epilogue store 16-byte vectors for this problem?
+inline bool conv_vec_ok(const DykConvDesc* d, int eso, size_t elem) {
+    bool vec = ((size_t)d->ldy * eso) % 16 == 0 && ((uintptr_t)d->y % 16) == 0;
+    if ((d->flags & DYK_EPI_RESIDUAL) && (((size_t)d->ldr * elem) % 16 != 0 || ((uintptr_t)d->res % 16) != 0)) vec = false;
+    return vec;
 }
 
 inline bool conv_halo_eligible(const DykConvDesc* d, int TH) {
@@ -974,13 +1017,10 @@ int launch_conv_halo(const DykConvDesc* d, hipStream_t stream) {
     const int tiles_n = d->B * (d->Hi / TH) * (d->Wi / 20);
     const int tiles_m = dyk_div_up(d->Cout, BM);
     ConvArgs args;
-    args.d = *d;
     const int eso = of32 ? 4 : 2;
-    bool vec = ((size_t)d->ldy * eso) % 16 == 0 && ((uintptr_t)d->y % 16) == 0;
-    if ((d->flags & DYK_EPI_RESIDUAL) && (((size_t)d->ldr * sizeof(T)) % 16 != 0 || ((uintptr_t)d->res % 16) != 0)) vec = false;
-    if (vec) args.d.flags |= EPI_INTERNAL_VEC;
-    else args.d.flags &= ~EPI_INTERNAL_VEC;
-    hipLaunchKernelGGL(kfn, dim3(tiles_n * tiles_m), dim3(256), lds, stream, args);
+    const bool vec = conv_vec_ok(d, eso, sizeof(T)) && (!d->twin || conv_vec_ok(d->twin, eso, sizeof(T)));
+    const unsigned grid = conv_fill_args(args, d, tiles_n * tiles_m, vec);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, args);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -1020,17 +1060,14 @@ int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     const int tiles_n = dyk_div_up(Ntot, BN);
     const int tiles_m = dyk_div_up(d->Cout, BM);
     ConvArgs args;
-    args.d = *d;
     // the staged epilogue needs 16-byte aligned pixel rows of the output (and residual)
     const int eso = of32 ? 4 : 2;
-    bool vec = ((size_t)d->ldy * eso) % 16 == 0 && ((uintptr_t)d->y % 16) == 0;
-    if ((d->flags & DYK_EPI_RESIDUAL) && (((size_t)d->ldr * sizeof(T)) % 16 != 0 || ((uintptr_t)d->res % 16) != 0)) vec = false;
+    bool vec = conv_vec_ok(d, eso, sizeof(T)) && (!d->twin || conv_vec_ok(d->twin, eso, sizeof(T)));
     static int force_scatter = -1;
     if (force_scatter < 0) { const char* e = getenv("DYK_CONV_EPI"); force_scatter = (e && e[0] == 's') ? 1 : 0; }
     if (force_scatter) vec = false;
-    if (vec) args.d.flags |= EPI_INTERNAL_VEC;
-    else args.d.flags &= ~EPI_INTERNAL_VEC;
-    hipLaunchKernelGGL(kfn, dim3(tiles_n * tiles_m * (d->ncls > 1 ? d->ncls : 1)), dim3(256 * KG), lds, stream, args);
+    const unsigned grid = conv_fill_args(args, d, tiles_n * tiles_m * (d->ncls > 1 ? d->ncls : 1), vec);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256 * KG), lds, stream, args);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

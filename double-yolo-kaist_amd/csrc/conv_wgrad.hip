@@ -15,10 +15,37 @@
 //
 // Replaces autograd's convolution_backward (weight gradient) for nn.Conv2d at reference
 // models.py:34-42.
+#include <stddef.h>
 #include <stdlib.h>
+#include <string.h>
 #include "dyk_common.h"
 
 namespace {
+
+// d[1] = the twin problem of a two-problem launch (DykWgradDesc.twin: x, dy, dw, part differ only); pair_blocks = workgroups
+// per problem rounded up to a multiple of 8 (both halves see the same block -> XCD relation), 0 = single problem
+struct WgArgs {
+    DykWgradDesc d[2];
+    int pair_blocks;
+};
+__device__ inline int wg_pick_problem(const WgArgs& args, int& blk, int& nblk) {
+    blk = blockIdx.x; nblk = gridDim.x;
+    if (args.pair_blocks == 0) return 0;
+    const int sel = blk >= args.pair_blocks ? 1 : 0;
+    blk -= sel * args.pair_blocks;
+    nblk = args.pair_blocks;
+    return sel;
+}
+inline unsigned wg_fill_args(WgArgs& args, const DykWgradDesc* d, int blocks) {
+    args.d[0] = *d;
+    args.d[0].twin = nullptr;
+    args.pair_blocks = 0;
+    if (!d->twin) return (unsigned)blocks;
+    args.d[1] = *d->twin;
+    args.d[1].twin = nullptr;
+    args.pair_blocks = (blocks + 7) & ~7;
+    return 2u * (unsigned)args.pair_blocks;
+}
 
 typedef short v4i16_t __attribute__((__vector_size__(4 * sizeof(short))));
 #define LDS_AS __attribute__((address_space(3)))
@@ -70,7 +97,9 @@ template <typename T, int C> __device__ inline int wg_logical_ch(int row, int ps
 //       accumulators to group 0 through LDS and only group 0 issues atomics: half the workgroups (and atomics)
 //       at the same number of waves per CU.
 template <typename T, int BM, int BN, int PIPE, int KG>
-__global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc a, const int splits, const int chunk) {
+__global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgArgs args, const int splits, const int chunk) {
+    int blk, nblk;
+    const DykWgradDesc& a = args.d[wg_pick_problem(args, blk, nblk)];
     constexpr int ROWS = WgTraits<T>::ROWS;
     constexpr int EPV = 16 / (int)sizeof(T);
     constexpr int VPR_A = BM / EPV, VPR_B = BN / EPV;          // 16-byte vectors per tile row
@@ -92,7 +121,8 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const DykWgradDesc
     const int tiles_n = (a.Cin + BN - 1) / BN;
     // consecutive remapped ids run on one XCD: the tiles and taps of one pixel range share that XCD's L2, so dy / x
     // of the range are fetched from HBM once instead of once per tap and tile (measured 3.2x over-fetch without)
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid = xcd_remap(blk, nblk);
+    if (bid >= tiles_m * tiles_n * a.ntaps * splits) return;     // padding blocks of a two-problem launch
     const int tm = bid % tiles_m; bid /= tiles_m;
     const int tn = bid % tiles_n; bid /= tiles_n;
     const int tap = bid % a.ntaps;
@@ -374,7 +404,9 @@ int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream, int* query) {
     if (!(d->part && d->splits > 0)) splits = dyk_div_up(Ntot, chunk);  // (plane mode with a given count: exactly that many
                                                                          //  planes are written, trailing empty ones with zeros)
     if (query) { *query = splits; return DYK_OK; }
-    hipLaunchKernelGGL(kfn, dim3(tiles * splits), dim3(256 * KG), lds, stream, *d, splits, chunk);
+    WgArgs args;
+    const unsigned grid = wg_fill_args(args, d, tiles * splits);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256 * KG), lds, stream, args, splits, chunk);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -414,7 +446,9 @@ int dispatch_wgrad(const DykWgradDesc* d, hipStream_t s, int* query) {
 // once per step and feed all nine taps; a workgroup holds the nine [64 x BN] accumulator tiles (72 / 144 VGPRs).
 // bf16 only; taps must be the standard 3x3 / pad 1 table (tdy = t/3 - 1, tdx = t%3 - 1); Wo % KW == 0.
 template <int BN, int SI, int KW>
-__global__ __launch_bounds__(256) void conv_wgrad_mt_kernel(const DykWgradDesc a, const int splits, const int chunk) {
+__global__ __launch_bounds__(256) void conv_wgrad_mt_kernel(const WgArgs args, const int splits, const int chunk) {
+    int blk, nblk;
+    const DykWgradDesc& a = args.d[wg_pick_problem(args, blk, nblk)];
     using T = bf16_t;
     constexpr int BM = 64;
     constexpr int XW = (KW - 1) * SI + 3;                      // halo pixels per input row
@@ -436,7 +470,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_mt_kernel(const DykWgradDesc a
     const int wm = wid >> 1, wn = wid & 1;
     const int tiles_m = (a.Cout + BM - 1) / BM;
     const int tiles_n = (a.Cin + BN - 1) / BN;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid = xcd_remap(blk, nblk);
+    if (bid >= tiles_m * tiles_n * splits) return;               // padding blocks of a two-problem launch
     const int tm = bid % tiles_m; bid /= tiles_m;
     const int tn = bid % tiles_n;
     const int sp = bid / tiles_n;
@@ -602,7 +637,9 @@ int launch_wgrad_mt(const DykWgradDesc* d, hipStream_t stream, int* query) {
     const int chunk = dyk_div_up(nseg, splits);
     if (!(d->part && d->splits > 0)) splits = dyk_div_up(nseg, chunk);
     if (query) { *query = splits; return DYK_OK; }
-    hipLaunchKernelGGL(kfn, dim3(tiles * splits), dim3(256), lds, stream, *d, splits, chunk);
+    WgArgs args;
+    const unsigned grid = wg_fill_args(args, d, tiles * splits);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, args, splits, chunk);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
@@ -657,7 +694,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(float* __restrict__ G,
 
 }  // namespace
 
-extern "C" int dyk_conv_wgrad(const DykWgradDesc* d, void* stream) {
+static int wgrad_validate(const DykWgradDesc* d) {
     if (!d || !d->x || !d->dy || !d->dw) return DYK_ERR_ARG;
     if (d->ntaps <= 0 || d->ntaps > DYK_MAX_TAPS) return DYK_ERR_ARG;
     if (d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0 || d->Cin <= 0) return DYK_ERR_ARG;
@@ -668,6 +705,18 @@ extern "C" int dyk_conv_wgrad(const DykWgradDesc* d, void* stream) {
     if (((uintptr_t)d->x % 16) || ((uintptr_t)d->dy % 16)) return DYK_ERR_ARG;
     if ((long)d->B * d->Ho * d->Wo >= (1L << 31)) return DYK_ERR_ARG;
     if (d->part && (d->part_stride < (int64_t)d->Cout * (d->lddw > 0 ? d->lddw : d->Cin))) return DYK_ERR_ARG;
+    return DYK_OK;
+}
+
+extern "C" int dyk_conv_wgrad(const DykWgradDesc* d, void* stream) {
+    int rc0 = wgrad_validate(d);
+    if (rc0 != DYK_OK) return rc0;
+    if (d->twin) {
+        // two-problem launch: equal in every non-pointer field (part_stride included), both with or both without planes
+        if ((rc0 = wgrad_validate(d->twin)) != DYK_OK) return rc0;
+        const size_t lo = offsetof(DykWgradDesc, part_stride), hi = offsetof(DykWgradDesc, twin);
+        if (memcmp((const char*)d + lo, (const char*)d->twin + lo, hi - lo) != 0 || (!d->part) != (!d->twin->part)) return DYK_ERR_ARG;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (((d->tune >> 28) & 7) == 1 && mt_eligible(d)) return dispatch_wgrad_mt(d, s, nullptr);    // multi-tap 3x3 variant
     if (d->dtype == DYK_BF16) return dispatch_wgrad<bf16_t>(d, s, nullptr);

@@ -7,6 +7,7 @@
 // are the unit of every global and LDS access.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include "../../include/dyk_hip.h"
 
@@ -172,3 +173,38 @@ __device__ inline int xcd_remap(int bid, int nblk) {
 }
 
 static inline int dyk_div_up(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Two-problem launches of the elementwise / BatchNorm kernels (DykEwDesc.twin, DykBnFinalizeDesc.twin): the kernel takes
+// both descriptors and blockIdx.z selects the problem.  fill_* return the number of problems (1 | 2), 0 when the twin
+// differs in a non-pointer field.
+struct DykEwPair { DykEwDesc d[2]; };
+struct DykFinPair { DykBnFinalizeDesc d[2]; };
+static inline int dyk_fill_ew_pair(DykEwPair& p, const DykEwDesc* d) {
+    p.d[0] = *d;
+    p.d[0].twin = nullptr;
+    if (!d->twin) return 1;
+    const size_t lo = offsetof(DykEwDesc, dtype), hi = offsetof(DykEwDesc, twin);
+    const DykEwDesc* t = d->twin;
+    if (__builtin_memcmp((const char*)d + lo, (const char*)t + lo, hi - lo) != 0) return 0;
+    // the same optional operands on both sides
+    if ((!d->b) != (!t->b) || (!d->out) != (!t->out) || (!d->p0) != (!t->p0) || (!d->p1) != (!t->p1) || (!d->p2) != (!t->p2) ||
+        (!d->p3) != (!t->p3) || (!d->red) != (!t->red) || (!d->aux) != (!t->aux) || (!d->aux2) != (!t->aux2) || !t->a)
+        return 0;
+    p.d[1] = *t;
+    p.d[1].twin = nullptr;
+    return 2;
+}
+static inline int dyk_fill_fin_pair(DykFinPair& p, const DykBnFinalizeDesc* d) {
+    p.d[0] = *d;
+    p.d[0].twin = nullptr;
+    if (!d->twin) return 1;
+    const size_t lo = offsetof(DykBnFinalizeDesc, C), hi = offsetof(DykBnFinalizeDesc, twin);
+    const DykBnFinalizeDesc* t = d->twin;
+    if (__builtin_memcmp((const char*)d + lo, (const char*)t + lo, hi - lo) != 0) return 0;
+    if (!t->stats || !t->scale || !t->shift || (!d->gamma) != (!t->gamma) || (!d->beta) != (!t->beta) ||
+        (!d->running_mean) != (!t->running_mean) || (!d->save_mean) != (!t->save_mean) || (!d->save_rstd) != (!t->save_rstd))
+        return 0;
+    p.d[1] = *t;
+    p.d[1].twin = nullptr;
+    return 2;
+}

@@ -14,7 +14,8 @@ inline int epv_of(int dtype) { return dtype == DYK_BF16 ? 8 : 4; }
 // ------------------------------------------------------------------ axpby
 // out = sa*a (+ sb*b), sa = alpha * (p0 ? p0[0] : 1), sb = beta * (p1 ? p1[0] : 1)
 template <typename T>
-__global__ __launch_bounds__(256) void axpby_kernel(DykEwDesc d) {
+__global__ __launch_bounds__(256) void axpby_kernel(DykEwPair pr) {
+    const DykEwDesc& d = pr.d[blockIdx.z];
     constexpr int EPV = ElemTraits<T>::EPV;
     const int CV = d.C / EPV;
     const long total = (long)d.npix * CV;
@@ -651,8 +652,9 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restri
     }
 }
 
-int check_ew(const DykEwDesc* d, bool need_b, bool need_out = true) {
+int check_ew(const DykEwDesc* d, bool need_b, bool need_out = true, bool twin_ok = false) {
     if (!d || !d->a || (need_out && !d->out) || (need_b && !d->b)) return DYK_ERR_ARG;
+    if (d->twin && !twin_ok) return DYK_ERR_UNSUPPORTED;      // two-problem launches: BatchNorm passes and axpby only
     if (d->dtype != DYK_BF16 && d->dtype != DYK_F32) return DYK_ERR_ARG;
     const int epv = epv_of(d->dtype);
     if (d->C <= 0 || d->C % epv || d->lda % epv || (need_out && d->ldo % epv) || (d->b && d->ldb % epv)) return DYK_ERR_ARG;
@@ -669,11 +671,14 @@ int check_ew(const DykEwDesc* d, bool need_b, bool need_out = true) {
     } while (0)
 
 extern "C" int dyk_axpby(const DykEwDesc* d, void* stream) {
-    const int rc = check_ew(d, false);
+    const int rc = check_ew(d, false, true, true);
     if (rc) return rc;
     if (d->npix <= 0) return DYK_ERR_ARG;
     const int grid = ew_grid((long)d->npix * (d->C / epv_of(d->dtype)));
-    DISPATCH_T(axpby_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    DykEwPair pr;
+    const int nz = dyk_fill_ew_pair(pr, d);
+    if (!nz) return DYK_ERR_ARG;
+    DISPATCH_T(axpby_kernel, dim3(grid, 1, nz), dim3(256), 0, (hipStream_t)stream, pr);
     return DYK_OK;
 }
 

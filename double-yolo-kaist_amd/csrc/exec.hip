@@ -231,6 +231,56 @@ extern "C" int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream,
     return DYK_OK;
 }
 
+// Two commands of the same op on shape-identical, mutually independent problems (the RGB / LWIR twin backbones of a
+// dual-stream net, reference models.py:288,299-303) as ONE two-problem launch: a copy of a's descriptor gets `twin` = b's.
+extern "C" int dyk_run_command_pair(const DykCommand* a, const DykCommand* b, void* stream) {
+    if (!a || !b || !a->desc || !b->desc || a->op != b->op) return DYK_ERR_ARG;
+    switch (a->op) {
+    case DYK_OP_CONV: {
+        DykConvDesc t = *(const DykConvDesc*)a->desc;
+        t.twin = (const DykConvDesc*)b->desc;
+        return dyk_conv_igemm(&t, stream);
+    }
+    case DYK_OP_WGRAD: {
+        DykWgradDesc t = *(const DykWgradDesc*)a->desc;
+        t.twin = (const DykWgradDesc*)b->desc;
+        return dyk_conv_wgrad(&t, stream);
+    }
+    case DYK_OP_BN_FINALIZE: {
+        DykBnFinalizeDesc t = *(const DykBnFinalizeDesc*)a->desc;
+        t.twin = (const DykBnFinalizeDesc*)b->desc;
+        return dyk_bn_finalize(&t, stream);
+    }
+    case DYK_OP_BN_FWD_FUSED: {
+        const DykMiscDesc* ma = (const DykMiscDesc*)a->desc;
+        const DykMiscDesc* mb = (const DykMiscDesc*)b->desc;
+        if (!ma->p[0] || !ma->p[1] || !mb->p[0] || !mb->p[1]) return DYK_ERR_ARG;
+        DykBnFinalizeDesc f = *(const DykBnFinalizeDesc*)ma->p[0];
+        DykEwDesc e = *(const DykEwDesc*)ma->p[1];
+        f.twin = (const DykBnFinalizeDesc*)mb->p[0];
+        e.twin = (const DykEwDesc*)mb->p[1];
+        return dyk_bn_finalize_act_fwd(&f, &e, stream);
+    }
+    case DYK_OP_BN_ACT_FWD: case DYK_OP_BN_BWD_REDUCE: case DYK_OP_BN_BWD_APPLY: case DYK_OP_AXPBY: {
+        DykEwDesc t = *(const DykEwDesc*)a->desc;
+        t.twin = (const DykEwDesc*)b->desc;
+        if (a->op == DYK_OP_BN_ACT_FWD) return dyk_bn_act_fwd(&t, stream);
+        if (a->op == DYK_OP_BN_BWD_REDUCE) return dyk_bn_act_bwd_reduce(&t, stream);
+        if (a->op == DYK_OP_BN_BWD_APPLY) return dyk_bn_act_bwd_apply(&t, stream);
+        return dyk_axpby(&t, stream);
+    }
+    default: return DYK_ERR_UNSUPPORTED;
+    }
+}
+
+namespace {
+// one schedule entry: a single command, or a two-problem launch of cmds[e.cmd] and cmds[e.cmd2]
+inline int run_entry(const DykCommand* cmds, const DykSchedEntry& e, void* stream) {
+    if (e.cmd2 >= 0) return dyk_run_command_pair(cmds + e.cmd, cmds + e.cmd2, stream);
+    return dyk_run_commands(cmds + e.cmd, 1, stream, nullptr);
+}
+}  // namespace
+
 // Concurrency beyond one in-order stream (the lists are chains of short kernels whose ramp-up and tail leave CUs idle):
 //  * the weight-gradient launches of a backward list are off the critical path (nothing in the pass reads dW): they go
 //    to a side stream, each behind an event covering everything enqueued before it on the issuing stream;
@@ -373,7 +423,7 @@ int sched_replay(SchedRuntime& rt, const DykCommand* cmds, const DykSchedEntry* 
         }
         if (e.cmd >= 0) {
             if (trace) { fprintf(stderr, "sched k=%d cmd=%d op=%d stream=%d nwait=%d w0=%d rec=%d\n", k, e.cmd, cmds[e.cmd].op, e.stream, e.nwait, e.nwait ? e.wait[0] : -1, e.record); fflush(stderr); }
-            const int rc = dyk_run_commands(cmds + e.cmd, 1, (void*)s, nullptr);
+            const int rc = run_entry(cmds, e, (void*)s);
             if (rc != DYK_OK) {
                 if (failed_index) *failed_index = e.cmd;
                 return rc;
@@ -436,7 +486,7 @@ struct IssuePool {
                 if (hipStreamWaitEvent(s, j.rt->events[w], 0) != hipSuccess) return DYK_ERR_HIP;
             }
             if (e.cmd >= 0) {
-                const int rc = dyk_run_commands(j.cmds + e.cmd, 1, (void*)s, nullptr);
+                const int rc = run_entry(j.cmds, e, (void*)s);
                 if (rc != DYK_OK) { failed_cmd.store(e.cmd); return rc; }
             }
             if (e.record) {
@@ -512,17 +562,50 @@ struct SchedGraph {
 };
 }  // namespace
 
+namespace {
+// the table must be replayable before anything is enqueued: a wait on an entry that records no event would spin forever
+// in the threaded path (and race silently in the single-threaded one)
+int sched_validate(const DykSchedEntry* sched, int32_t n, int32_t n_streams) {
+    for (int32_t k = 0; k < n; ++k) {
+        const DykSchedEntry& e = sched[k];
+        if (e.stream < 0 || e.stream >= n_streams || e.nwait < 0 || e.nwait > 7) return DYK_ERR_ARG;
+        for (int q = 0; q < e.nwait; ++q) {
+            const int32_t w = e.wait[q];
+            if (w < 0 || w >= k || !sched[w].record || sched[w].stream == e.stream) return DYK_ERR_ARG;
+        }
+    }
+    return DYK_OK;
+}
+constexpr int DYK_MAX_DEVICES = 16;
+}  // namespace
+
 extern "C" int dyk_run_schedule(const DykCommand* cmds, const DykSchedEntry* sched, int32_t n, int32_t n_streams,
                                 int32_t low_priority_last, void* stream, int32_t* failed_index) {
     if (!cmds || !sched || n < 0 || n_streams < 1 || n_streams > 8) return DYK_ERR_ARG;
-    static SchedRuntime rt;
+    if (sched_validate(sched, n, n_streams) != DYK_OK) return DYK_ERR_ARG;
+    // streams, events and issuing threads belong to ONE device: a process that runs plans on several GPUs (or moves a
+    // model from cuda:0 to cuda:1) gets a runtime per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DYK_MAX_DEVICES) return DYK_ERR_HIP;
+    static SchedRuntime rts[DYK_MAX_DEVICES];
+    SchedRuntime& rt = rts[dev];
     // DYK_ISSUE_THREADS=0: everything is issued by the calling thread (one launch at a time)
     static const bool threaded = !(getenv("DYK_ISSUE_THREADS") && getenv("DYK_ISSUE_THREADS")[0] == '0');
+    int rc;
     if (threaded && n_streams > 1) {
-        static IssuePool* pool = new IssuePool();        // (leaked on purpose: worker threads outlive static destruction)
-        return pool->run(rt, cmds, sched, n, n_streams, low_priority_last ? 1 : 0, (hipStream_t)stream, failed_index);
+        static IssuePool* pools[DYK_MAX_DEVICES] = {};   // (leaked on purpose: worker threads outlive static destruction)
+        if (!pools[dev]) pools[dev] = new IssuePool();
+        rc = pools[dev]->run(rt, cmds, sched, n, n_streams, low_priority_last ? 1 : 0, (hipStream_t)stream, failed_index);
+    } else {
+        rc = sched_replay(rt, cmds, sched, n, n_streams, low_priority_last, (hipStream_t)stream, failed_index);
     }
-    return sched_replay(rt, cmds, sched, n, n_streams, low_priority_last, (hipStream_t)stream, failed_index);
+    if (rc != DYK_OK) {
+        // error path: whatever the library streams hold must not outlive the call (the caller will reuse the arenas)
+        const int lp = low_priority_last ? 1 : 0;
+        for (int s = 1; s < n_streams; ++s)
+            if (rt.aux[lp][s]) (void)hipStreamSynchronize(rt.aux[lp][s]);
+    }
+    return rc;
 }
 
 // A command range as a hipGraph built from its DEPENDENCY lists (dyk/sched.py): every command is captured on its own
@@ -608,6 +691,28 @@ extern "C" int dyk_run_commands_timed(const DykCommand* cmds, int32_t n, void* s
     hipEventRecord(ev[0], s);
     for (int k = 0; k < n && rc == DYK_OK; ++k) {
         rc = dyk_run_commands(cmds + k, 1, stream, nullptr);
+        hipEventRecord(ev[k + 1], s);
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) rc = DYK_ERR_HIP;
+    if (rc == DYK_OK)
+        for (int k = 0; k < n; ++k)
+            if (hipEventElapsedTime(&ms_out[k], ev[k], ev[k + 1]) != hipSuccess) { rc = DYK_ERR_HIP; break; }
+    for (int i = 0; i <= n; ++i) hipEventDestroy(ev[i]);
+    delete[] ev;
+    return rc;
+}
+
+extern "C" int dyk_run_schedule_timed(const DykCommand* cmds, const DykSchedEntry* sched, int32_t n, void* stream,
+                                      float* ms_out) {
+    if (!cmds || !sched || n <= 0 || !ms_out) return DYK_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t* ev = new hipEvent_t[n + 1];
+    for (int i = 0; i <= n; ++i)
+        if (hipEventCreate(&ev[i]) != hipSuccess) { delete[] ev; return DYK_ERR_HIP; }
+    int rc = DYK_OK;
+    hipEventRecord(ev[0], s);
+    for (int k = 0; k < n && rc == DYK_OK; ++k) {
+        if (sched[k].cmd >= 0) rc = run_entry(cmds, sched[k], stream);
         hipEventRecord(ev[k + 1], s);
     }
     if (hipStreamSynchronize(s) != hipSuccess) rc = DYK_ERR_HIP;

@@ -90,7 +90,10 @@ def gather_detections(dets, image_ids):
             rows.append(torch.cat([torch.full((d.shape[0], 1), float(i), dtype=torch.float32, device=d.device), d.float()], 1))
     world = get_world_size()
     if world == 1:
-        return torch.cat(rows, 0) if rows else torch.zeros((0, 7))
+        if rows:
+            return torch.cat(rows, 0)
+        dev = next((d.device for d in dets if d is not None), torch.device("cpu"))
+        return torch.zeros((0, 7), device=dev)   # (empty, but on the device the detections live on)
     dist, dev = _dist(), _comm_device()
     mine = torch.cat(rows, 0).to(dev) if rows else torch.zeros((0, 7), device=dev)
     n = torch.tensor([mine.shape[0]], dtype=torch.int64, device=dev)
@@ -139,11 +142,17 @@ class GradAllReduce:
             segs = []
             c_prev, hi = 0, total
             marks = plan.bwd_marks                    # (commands emitted before layer i's backward, i), descending i
+            # twin sections (dyk/twins.py) run as two-problem launches: a cut between the backward of section t and that
+            # of its twin l < t would leave both halves unpaired, so no bucket closes at a layer in (l, t]
+            twin_spans = sorted((l, t) for l, t in getattr(plan, "twin_layer", {}).items() if l < t) \
+                if os.environ.get("DYK_PAIR", "1") != "0" else []
             for k in range(1, len(marks)):
                 c_end, layer_done = marks[k][0], marks[k - 1][1]     # commands [.., c_end) finish layer `layer_done`
                 lo = min((o for l, o in first_off.items() if l >= layer_done), default=hi)
                 cut_ok = getattr(plan, "bwd_cut_ok", None)          # atomic-free wgrads: cut only where the planes are folded
                 if cut_ok is not None and c_end not in cut_ok and k != len(marks) - 1:
+                    continue
+                if k != len(marks) - 1 and any(l < layer_done <= t for l, t in twin_spans):
                     continue
                 if (lo <= cuts[0] and lo < hi and c_end > c_prev) or k == len(marks) - 1:
                     lo = 0 if k == len(marks) - 1 else lo

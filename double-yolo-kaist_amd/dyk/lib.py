@@ -49,6 +49,7 @@ class DykConvDesc(ctypes.Structure):
         ("ncls", _i8), ("cls_first", _i8 * 4), ("cls_ntaps", _i8 * 4), ("cls_ooy", _i8 * 4), ("cls_oox", _i8 * 4),
         ("_pad2", _i8 * 3),
         ("act", _i32), ("flags", _i32), ("stats_slots", _i32), ("tune", _i32),
+        ("twin", _vp),
     ]
 
 
@@ -60,6 +61,7 @@ class DykWgradDesc(ctypes.Structure):
         ("isy", _i32), ("isx", _i32), ("ntaps", _i32),
         ("tdy", _i8 * MAX_TAPS), ("tdx", _i8 * MAX_TAPS), ("twt", _i8 * MAX_TAPS), ("_pad", _i8),
         ("splits", _i32), ("lddw", _i32), ("tune", _i32),
+        ("twin", _vp),
     ]
 
 
@@ -70,6 +72,7 @@ class DykEwDesc(ctypes.Structure):
         ("dtype", _i32), ("npix", _i32), ("C", _i32), ("lda", _i32), ("ldb", _i32), ("ldo", _i32),
         ("act", _i32), ("flags", _i32), ("B", _i32), ("H", _i32), ("W", _i32), ("k", _i32),
         ("alpha", _f32), ("beta", _f32), ("slots", _i32),
+        ("twin", _vp),
     ]
 
 
@@ -78,6 +81,7 @@ class DykBnFinalizeDesc(ctypes.Structure):
         ("stats", _vp), ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp),
         ("scale", _vp), ("shift", _vp), ("save_mean", _vp), ("save_rstd", _vp),
         ("C", _i32), ("count", _i32), ("momentum", _f32), ("eps", _f32), ("slots", _i32),
+        ("twin", _vp),
     ]
 
 
@@ -123,7 +127,8 @@ class DykStemDesc(ctypes.Structure):
 
 
 class DykSchedEntry(ctypes.Structure):
-    _fields_ = [("cmd", _i32), ("stream", ctypes.c_int16), ("nwait", _i8), ("record", _i8), ("wait", _i32 * 7)]
+    _fields_ = [("cmd", _i32), ("stream", ctypes.c_int16), ("nwait", _i8), ("record", _i8), ("wait", _i32 * 7),
+                ("cmd2", _i32)]
 
 
 class DykDecodeDesc(ctypes.Structure):
@@ -202,6 +207,8 @@ SIGNATURES = {
     "dyk_dwconv_wgrad": (_i32, [_P(DykDwDesc), _vp]),
     "dyk_dwconv_wgrad_rows": (_i32, [_P(DykDwDesc)]),
     "dyk_run_commands": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
+    "dyk_run_command_pair": (_i32, [_P(DykCommand), _P(DykCommand), _vp]),
+    "dyk_run_schedule_timed": (_i32, [_P(DykCommand), _P(DykSchedEntry), _i32, _vp, _P(_f32)]),
     "dyk_run_commands_overlap": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
     "dyk_run_schedule": (_i32, [_P(DykCommand), _P(DykSchedEntry), _i32, _i32, _i32, _vp, _P(_i32)]),
     "dyk_dag_graph_create": (_i32, [_P(DykCommand), _i32, _P(_i32), _P(_i32), _P(_vp), _P(_i32)]),

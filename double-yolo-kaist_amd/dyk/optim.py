@@ -126,17 +126,21 @@ class _FusedBase(torch.optim.Optimizer):
         flats = dict(zip(self._state_names, (m, v)))
         by_param = {id(e.param): e for e in st.entries}
         steps = set()
+        loaded = False
         with torch.no_grad():
             for p, s in list(self.state.items()):
                 e = by_param[id(p)]
                 for name, flat in flats.items():
                     if name in s and s[name] is not None:
                         st._view(flat, e).copy_(s[name].to(flat.device, torch.float32))
+                        loaded = True
                 if "step" in s:
                     steps.add(int(float(s["step"])))
         if len(steps) > 1:
             raise ValueError("per-parameter step counts differ (%s): the fused step keeps one counter" % sorted(steps))
-        self._t = steps.pop() if steps else 0
+        # torch.optim.SGD keeps only 'momentum_buffer' (no 'step'): a checkpoint that carries buffers is past its first
+        # step -- with _t = 0 the next step would take the first-step branch (m = g) and drop the loaded momentum
+        self._t = steps.pop() if steps else (1 if loaded else 0)
         self.state.clear()               # the flat buffers are the state; views are rebuilt on demand
 
 

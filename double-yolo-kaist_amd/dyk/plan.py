@@ -54,11 +54,15 @@ class Arena:
     def __init__(self, name):
         self.name, self.size, self.tensor = name, 0, None
         self.blocks = []                       # (offset, bytes) of every allocation, ascending (dyk/sched.py)
+        self.pads = {}                         # block offset -> trailing pad bytes
 
-    def alloc(self, nbytes, align=256):
+    def alloc(self, nbytes, align=256, pad=0):
+        """`pad`: zero bytes behind the payload that belong to the block but are never written (K-step over-read room)"""
         off = _ru(self.size, align)
-        self.size = off + nbytes
-        self.blocks.append((off, nbytes))
+        self.size = off + nbytes + pad
+        self.blocks.append((off, nbytes + pad))
+        if pad:
+            self.pads[off] = pad
         return off
 
     def materialize(self, device, zero=True):
@@ -213,10 +217,19 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     # so they contribute exactly 0; every arena ends in 256 spare zero bytes for the last pixel of the last tensor.
     tight = os.environ.get("DYK_TIGHT_ROWS", "1") != "0"
 
+    def kpad_bytes(ld, esize):
+        # A tensor (or a channel slice of a concat buffer) whose channel count is not a multiple of the MFMA conv's
+        # 32-channel K step is over-read by up to one K step (64 bytes) behind its LAST pixel: those bytes belong to the
+        # block itself (zero from materialisation, never written), so the tail never reaches a neighbouring block -- no
+        # ordering against that block's writers is needed and no Inf / NaN of a foreign tensor (an fp32 block read as
+        # bf16) can meet the zero weight rows.  Every activation / gradient block gets the pad: which slices of it
+        # will be read with a padded K is not known when it is allocated.
+        return 64
+
     def new_act(Bn, Hn, Wn, C, ld=None, esize=None):
         ld = ld or (_ru(C, 8) if tight else _ru(C, 32))
         esize = esize or es
-        return TRef("act", act_arena.alloc(Bn * Hn * Wn * ld * esize), Bn, Hn, Wn, C, ld, esize)
+        return TRef("act", act_arena.alloc(Bn * Hn * Wn * ld * esize, pad=kpad_bytes(ld, esize)), Bn, Hn, Wn, C, ld, esize)
 
     # ---- concat placement: a layer whose output is an input of a multi-source [route] writes straight into its
     # channel slice of the concatenation buffer (no copy at the route).  Decided up front from the channel counts.
@@ -736,7 +749,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             if t.tid not in grads:
                 ldn = ld or t.ld
                 Cn = C or t.C
-                g = TRef("grad", grad_arena.alloc(t.npix * ldn * es), t.B, t.H, t.W, Cn, ldn, es, tid=t.tid)
+                g = TRef("grad", grad_arena.alloc(t.npix * ldn * es, pad=kpad_bytes(ldn, es)), t.B, t.H, t.W, Cn, ldn, es, tid=t.tid)
                 grads[t.tid] = g
             return grads[t.tid]
 
@@ -950,7 +963,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 dyr = dz
                 if os.environ.get("DYK_DEBUG_PLAN") or rec.get("dz_is_addend"):
                     # keep dz intact: per-layer gradient dumps / it is still to be added to the skip tensor's gradient
-                    dyr = TRef("grad", grad_arena.alloc(dz.npix * dz.ld * es), dz.B, dz.H, dz.W, dz.C, dz.ld, es)
+                    dyr = TRef("grad", grad_arena.alloc(dz.npix * dz.ld * es, pad=kpad_bytes(dz.ld, es)), dz.B, dz.H, dz.W, dz.C, dz.ld, es)
                 ap = ew_desc(a=dz, b=rec["y_raw"], out=dyr, act=act_bwd)        # in place: dz (or da) -> dy_raw
                 # the apply pass folds the replicas of the reduction itself and adds them to dgamma / dbeta
                 ap.slots = STAT_SLOTS
@@ -1181,6 +1194,20 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             plan.bwd_lanes[q] = plan.bwd_lanes.get(q, 0) | 8
 
     plan.store = store
+    # cfg section of every command (dyk/twins.py pairs the commands of twin sections into two-problem launches)
+    from . import twins
+    plan.twin_layer = twins.twin_layers(defs, mods, second)
+    plan.fwd_layer = [-1] * len(plan.fwd)
+    for li, c0 in enumerate(fwd_start):
+        c1 = fwd_start[li + 1] if li + 1 < len(fwd_start) else (len(plan.fwd) - (0 if training else len(model.yolo_layers)))
+        for q in range(c0, c1):
+            plan.fwd_layer[q] = li
+    plan.bwd_layer = [-1] * len(plan.bwd)
+    if training:
+        marks = plan.bwd_marks
+        for k in range(len(marks) - 1):
+            for q in range(marks[k][0], marks[k + 1][0]):
+                plan.bwd_layer[q] = marks[k][1]
     plan.finalize()
     plan.info = info
     plan.grads = grads if training else {}
@@ -1447,6 +1474,8 @@ def autotune(plan, cache=None):
                         combos.append((c, 0 if o == auto else o))
                         times.append(t)
                 d.part, d.part_stride, d.splits, d.dw = None, 0, 0, saved_dw
+                if not combos:                     # no candidate applies to this problem: the kernel's defaults
+                    combos, times = [(0, 0)], [float("inf")]
                 best = combos[times.index(min(times))]
             else:
                 times = []
@@ -1455,7 +1484,8 @@ def autotune(plan, cache=None):
                     times.append(_time_launch(fn, d, stream))
                 best = cands[times.index(min(times))]
             cache[key] = best
-            _TUNE_MS[key] = min(times)
+            if min(times) != float("inf"):
+                _TUNE_MS[key] = min(times)
         for d in descs:
             if isinstance(best, tuple):
                 d.tune, d.splits = best             # (tile configuration, K splits: 0 = the kernel's own count)

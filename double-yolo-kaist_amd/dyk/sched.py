@@ -334,13 +334,14 @@ class Schedule:
         arr = (L.DykSchedEntry * max(self.n, 1))()
         for k, e in enumerate(entries):
             arr[k].cmd, arr[k].stream, arr[k].record = e["cmd"], e["stream"], 1 if e["record"] else 0
+            arr[k].cmd2 = e.get("cmd2", -1)
             arr[k].nwait = len(e["waits"])
             for q, w in enumerate(e["waits"]):
                 arr[k].wait[q] = w
         self.array = arr
 
 
-def schedule(cmds, deps, costs, n_streams, first=0, filler=None):
+def schedule(cmds, deps, costs, n_streams, first=0, filler=None, klass=None):
     """List scheduling (highest bottom level first) onto `n_streams` in-order streams.  Among the commands whose
     producers are all placed, the one with the longest remaining dependency chain goes next, onto the stream where it
     can start earliest; ties prefer the stream of its latest-finishing producer (no event needed), then the lowest
@@ -348,7 +349,17 @@ def schedule(cmds, deps, costs, n_streams, first=0, filler=None):
     (which nothing in a pass reads) fill the others.  `filler`: optional set of command indices restricted to the last
     stream (a low-priority stream in the executor).  Returns a Schedule whose entries are sorted by simulated start
     time -- the host issues in that order so that no stream starves behind another one's commands.  `first` is added
-    to the command indices (sub-range schedules)."""
+    to the command indices (sub-range schedules).
+
+    `klass` (resource-typed streams, DYK_SCHED_POLICY=typed): klass[i] = 0 for commands bound by the matrix pipe and its
+    operand path (implicit-GEMM convolutions, weight gradients), 1 for streaming kernels (BatchNorm / activation passes,
+    element-wise, pooling).  Measured (round 3, two-problem launches): a convolution launch with twice the workgroups takes
+    exactly twice as long at every layer of the target cfg -- ONE 4-wave workgroup per CU already saturates the CU's
+    operand path -- so two MFMA kernels on two streams only share the chip, while a streaming kernel (no LDS, HBM-bound)
+    runs beside an MFMA kernel almost for free.  With `klass` all class-0 commands go to stream 0, in an order that never
+    lets them compete with each other, and the class-1 commands to streams 1.. where they overlap with whatever stream 0
+    runs; a ready command of lower priority is placed first only when it finishes before the highest-priority one of its
+    class could start (backfill without delay)."""
     import heapq
     n = len(cmds)
     users = [[] for _ in range(n)]
@@ -359,22 +370,23 @@ def schedule(cmds, deps, costs, n_streams, first=0, filler=None):
     for i in range(n - 1, -1, -1):
         blevel[i] = costs[i] + max((blevel[u] for u in users[i]), default=0.0)
     missing = [len(deps[i]) for i in range(n)]
-    heap = [(-blevel[i], i) for i in range(n) if missing[i] == 0]
-    heapq.heapify(heap)
     general = n_streams - 1 if (filler and n_streams > 1) else n_streams
     avail = [0.0] * n_streams
     start, finish, stream_of = [0.0] * n, [0.0] * n, [0] * n
     pos_in_stream = [0] * n
     count = [0] * n_streams
     placed = 0
-    while heap:
-        _, i = heapq.heappop(heap)
+
+    def place(i):
+        """command i onto the stream of its class where it starts earliest"""
         ready, prod = 0.0, -1
         for j in deps[i]:
             if finish[j] > ready:
                 ready, prod = finish[j], j
         if filler and i in filler and n_streams > 1:
             cand = [n_streams - 1]
+        elif klass is not None and n_streams > 1:
+            cand = [0] if klass[i] == 0 else range(1, general)
         else:
             cand = range(general)
         pref = stream_of[prod] if prod >= 0 else 0
@@ -383,15 +395,52 @@ def schedule(cmds, deps, costs, n_streams, first=0, filler=None):
             t = max(ready, avail[s_])
             if best is None or t < best_t - 1e-9 or (abs(t - best_t) <= 1e-9 and s_ == pref and best != pref):
                 best, best_t = s_, t
-        start[i], finish[i], stream_of[i] = best_t, best_t + costs[i], best
-        avail[best] = finish[i]
-        pos_in_stream[i] = count[best]
-        count[best] += 1
-        placed += 1
-        for u in users[i]:
-            missing[u] -= 1
-            if missing[u] == 0:
-                heapq.heappush(heap, (-blevel[u], u))
+        return best, best_t
+
+    if klass is None:
+        heap = [(-blevel[i], i) for i in range(n) if missing[i] == 0]
+        heapq.heapify(heap)
+        while heap:
+            _, i = heapq.heappop(heap)
+            best, best_t = place(i)
+            start[i], finish[i], stream_of[i] = best_t, best_t + costs[i], best
+            avail[best] = finish[i]
+            pos_in_stream[i] = count[best]
+            count[best] += 1
+            placed += 1
+            for u in users[i]:
+                missing[u] -= 1
+                if missing[u] == 0:
+                    heapq.heappush(heap, (-blevel[u], u))
+    else:
+        ready_set = {i for i in range(n) if missing[i] == 0}
+        while ready_set:
+            # the highest-priority ready command, and where / when it could start
+            top = max(ready_set, key=lambda i: (blevel[i], -i))
+            s_top, t_top = place(top)
+            pick, s_pick, t_pick = top, s_top, t_top
+            # backfill: another ready command that fits in front of it on the same stream without delaying it
+            if t_top > avail[s_top] + 1e-9:
+                bestb = None
+                for j in ready_set:
+                    if j == top:
+                        continue
+                    sj, tj = place(j)
+                    if sj == s_top and tj + costs[j] <= t_top + 1e-9 and (bestb is None or blevel[j] > blevel[bestb[0]]):
+                        bestb = (j, sj, tj)
+                if bestb is not None:
+                    pick, s_pick, t_pick = bestb
+            i = pick
+            ready_set.discard(i)
+            start[i], finish[i], stream_of[i] = t_pick, t_pick + costs[i], s_pick
+            avail[s_pick] = finish[i]
+            pos_in_stream[i] = count[s_pick]
+            count[s_pick] += 1
+            placed += 1
+            for u in users[i]:
+                missing[u] -= 1
+                if missing[u] == 0:
+                    ready_set.add(u)
     assert placed == n, "dependency cycle"
     # issue order: by simulated start time, but never ahead of an earlier command of the same stream
     order = sorted(range(n), key=lambda i: (start[i], pos_in_stream[i], i))
@@ -419,7 +468,9 @@ def schedule(cmds, deps, costs, n_streams, first=0, filler=None):
         e["record"] = e["_c"] in needs_record
         if len(e["waits"]) > MAX_WAITS:
             raise RuntimeError("schedule entry with %d waits" % len(e["waits"]))
-    return Schedule(entries, n_streams, max(finish) if n else 0.0, sum(costs))
+    sc = Schedule(entries, n_streams, max(finish) if n else 0.0, sum(costs))
+    sc.entry_deps = [sorted(issue_pos[j] for j in deps[c]) for c in order]     # per entry: the entries it follows (issue positions)
+    return sc
 
 
 def build(plan, store, which, start, end, n_streams=None):
@@ -433,7 +484,34 @@ def build(plan, store, which, start, end, n_streams=None):
     filler = None
     if os.environ.get("DYK_SCHED_FILLER", "0") != "0":
         filler = {i for i, (op, _) in enumerate(cmds) if op in (L.OP_WGRAD, L.OP_DW_WGRAD, L.OP_GRAD_REDUCE)}
-    sc = schedule(cmds, deps, costs, max(1, min(n_streams, 8)), first=start, filler=filler)
+    klass = None
+    if os.environ.get("DYK_SCHED_POLICY", "typed") == "typed" and n_streams > 1:
+        klass = [0 if op in (L.OP_CONV, L.OP_WGRAD) else 1 for op, _ in cmds]
+    # two-problem launches for the twin sections of a dual-stream net (dyk/twins.py): commands of twin sections with
+    # equal descriptors that the dependency graph leaves unordered are contracted into one node each; the schedule is
+    # built on the contracted graph and every entry carries its second command (DykSchedEntry.cmd2)
+    pairs = []
+    twin_of = getattr(plan, "twin_layer", None)
+    layer_of = getattr(plan, which + "_layer", None)
+    if twin_of and layer_of is not None and os.environ.get("DYK_PAIR", "1") != "0":
+        from . import twins
+        pairs = twins.find_pairs(cmds, deps, layer_of[start:end], twin_of, plan, os.environ.get("DYK_PAIR_OPS", "ew"),
+                                 1e6 * float(os.environ.get("DYK_PAIR_MAX_MB", "48")))
+    if pairs:
+        members, ndeps, ncosts = twins.merge(len(cmds), deps, costs, pairs,
+                                             float(os.environ.get("DYK_PAIR_COST", "0.8")))
+        if filler:
+            filler = {k for k, m in enumerate(members) if m[0] in filler}
+        if klass is not None:
+            klass = [klass[m[0]] for m in members]
+        sc = schedule(members, ndeps, ncosts, max(1, min(n_streams, 8)), first=0, filler=filler, klass=klass)
+        for e, ent in zip(sc.entries, sc.array):
+            m = members[e["cmd"]]
+            e["cmd"] = ent.cmd = m[0] + start
+            e["cmd2"] = ent.cmd2 = (m[1] + start) if len(m) > 1 else -1
+    else:
+        sc = schedule(cmds, deps, costs, max(1, min(n_streams, 8)), first=start, filler=filler, klass=klass)
+    sc.n_pairs = len(pairs)
     sc.set_deps(_reduce(deps))
     return sc
 

@@ -130,6 +130,12 @@ typedef struct DykConvDesc {
                                        (2|3|4|6), 12..15 pixel tile (0 = 128, 1 = 80, 2 = 160; bf16), 24..27 channel
                                        tile (0 = by Cout, 1 = 32, 2 = 64, 3 = 128); bits 16..23 analysis switches; 1 << 28 = two K-groups per
                                        workgroup (512 threads, halves of Cin, bf16 / 128-byte K step / 80|160-pixel tiles) */
+    const struct DykConvDesc* twin; /* HOST pointer or NULL.  Two-problem launch: a second problem of IDENTICAL geometry, flags and
+                                       tile configuration (every non-pointer field equal) whose pointer fields x, w, y, scale,
+                                       shift, res, stats, aux0, aux1, add are used -- one launch covers both, the workgroups of
+                                       the second problem follow those of the first.  For the shape-identical RGB / LWIR twin
+                                       backbones of a dual-stream net (models.py:288,299-303): half the launches, twice the
+                                       workgroups per launch on the deep stages.  The twin's own `twin` field is ignored. */
 } DykConvDesc;
 
 int dyk_conv_igemm(const DykConvDesc* desc, void* stream);
@@ -166,6 +172,8 @@ typedef struct DykWgradDesc {
                                        (1 = tiles of at most 64 x 64: more tiles, fewer K splits for small GEMMs) | 1 << 28: multi-tap
                                        kernel (3x3 / pad 1, bf16, Wo % 32 == 0: dy and the x halo tile staged once for all nine
                                        taps; ignored where it does not apply) */
+    const struct DykWgradDesc* twin;/* HOST pointer or NULL: second problem of identical geometry / splits / tune whose x, dy, dw, part
+                                       are used (two-problem launch, see DykConvDesc.twin) */
 } DykWgradDesc;
 
 int dyk_conv_wgrad(const DykWgradDesc* desc, void* stream);
@@ -211,6 +219,9 @@ typedef struct DykEwDesc {
     int32_t B, H, W, k;             /* spatial ops (pool / upsample) */
     float alpha, beta;
     int32_t slots;                  /* replicas of `red` (reductions; 0 is read as 1) */
+    const struct DykEwDesc* twin;   /* HOST pointer or NULL: second problem with equal non-pointer fields (two-problem launch, see
+                                       DykConvDesc.twin).  Honoured by dyk_bn_act_fwd, dyk_bn_finalize_act_fwd, dyk_bn_act_bwd_reduce,
+                                       dyk_bn_act_bwd_apply and dyk_axpby; the other entry points return DYK_ERR_UNSUPPORTED for it */
 } DykEwDesc;
 
 /* BatchNorm2d, training mode (nn.BatchNorm2d at models.py:47, torch defaults eps=1e-5,
@@ -232,6 +243,7 @@ typedef struct DykBnFinalizeDesc {
     int32_t count;
     float momentum, eps;
     int32_t slots;              /* replicas of stats written by the conv epilogue (0 is read as 1) */
+    const struct DykBnFinalizeDesc* twin;   /* HOST pointer or NULL: second problem, equal C / count / momentum / eps / slots */
 } DykBnFinalizeDesc;
 
 int dyk_bn_finalize(const DykBnFinalizeDesc* desc, void* stream);
@@ -472,6 +484,11 @@ typedef struct DykCommand {
     const void* desc;
 } DykCommand;
 
+/* One two-problem launch of commands a and b (same op, descriptors equal in every non-pointer field; see DykConvDesc.twin).
+ * Ops: DYK_OP_CONV, DYK_OP_WGRAD, DYK_OP_BN_FINALIZE, DYK_OP_BN_ACT_FWD, DYK_OP_BN_FWD_FUSED, DYK_OP_BN_BWD_REDUCE,
+ * DYK_OP_BN_BWD_APPLY, DYK_OP_AXPBY; DYK_ERR_UNSUPPORTED otherwise, DYK_ERR_ARG when the two descriptors differ in shape. */
+int dyk_run_command_pair(const DykCommand* a, const DykCommand* b, void* stream);
+
 /* Enqueue cmds[0..n) in order.  Stops at the first failure and returns its code; *failed_index
  * (may be NULL) receives the index of the failing command. */
 int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream, int32_t* failed_index);
@@ -642,6 +659,8 @@ typedef struct DykSchedEntry {
     int8_t nwait;
     int8_t record;
     int32_t wait[7];
+    int32_t cmd2;         /* >= 0: cmds[cmd] and cmds[cmd2] are a shape-identical, mutually independent pair (the twin backbones):
+                             enqueued as ONE two-problem launch (dyk_run_command_pair); < 0: none */
 } DykSchedEntry;
 int dyk_run_schedule(const DykCommand* cmds, const DykSchedEntry* sched, int32_t n_entries, int32_t n_streams,
                      int32_t low_priority_last, void* stream, int32_t* failed_index);
@@ -671,6 +690,10 @@ int dyk_scale_coords(float* boxes, int32_t n, int32_t ld, float pad_x, float pad
  * and, after synchronising the stream, writes each command's duration in milliseconds to
  * ms_out[0..n).  Used by bench.py's roofline pass, never in a timed throughput region. */
 int dyk_run_commands_timed(const DykCommand* cmds, int32_t n, void* stream, float* ms_out_host);
+/* The same for the entries of a schedule, in issue order on ONE stream (two-problem entries as the single launch they
+ * are in the step): ms_out[k] = duration of entry k. */
+int dyk_run_schedule_timed(const DykCommand* cmds, const DykSchedEntry* sched, int32_t n_entries, void* stream,
+                           float* ms_out_host);
 
 #ifdef __cplusplus
 }

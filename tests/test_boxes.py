@@ -85,3 +85,32 @@ def test_scale_coords_on_detection_rows_in_place():
     assert np.array_equal(det.cpu().numpy()[:, 4:], x["wild"].numpy()[:, 4:])          # score / class untouched
     empty = torch.zeros((0, 6), device="cuda")
     assert U.scale_coords((128, 160), empty[:, :4], (512, 640)).shape == (0, 4)
+
+
+@pytest.mark.gpu
+def test_box_helpers_accept_other_dtypes_and_one_row_views():
+    """the reference's tensor expressions take any dtype and any view; the HIP entry points compute in fp32
+    on a row-contiguous copy and hand back the caller's dtype / write through the caller's view."""
+    from build_utils import utils as U
+    x = R2.box_inputs()["wild"][:, :4].clone()
+    want = U.xywh2xyxy(x)                                    # host form (bit-exact to the reference by boxes.npz)
+    for dt, tol in ((torch.float64, 0.0), (torch.float16, 2e-3)):
+        got = U.xywh2xyxy(x.to(dt).cuda())
+        assert got.dtype == dt and got.is_cuda
+        ref = want.to(dt).double() if dt == torch.float64 else U.xywh2xyxy(x.to(dt).float()).double()
+        assert float((got.double().cpu() - ref).abs().max()) <= tol * float(ref.abs().max()) + (0 if tol else 0.0)
+    # one row whose columns are NOT unit-stride (a transposed [4,1] tensor): read through the strides, not as contiguous
+    col = torch.tensor([[10.0], [20.0], [4.0], [6.0]]).cuda()         # [4,1]; .t() -> [1,4] with stride (1,1)? no: (1, 1)
+    wide = torch.arange(8.0).reshape(4, 2).cuda()                      # take column 1 of a [4,2] tensor as a [1,4] row
+    row = wide[:, 1].unsqueeze(0)                                      # shape [1,4], stride (1, 2): values 1,3,5,7
+    assert row.stride(1) == 2
+    got = U.xywh2xyxy(row)
+    assert torch.equal(got.cpu(), U.xywh2xyxy(torch.tensor([[1.0, 3.0, 5.0, 7.0]])))
+    boxes = wide[:, 1].unsqueeze(0)
+    U.clip_coords(boxes, (4, 4))
+    assert wide[:, 1].tolist() == [1.0, 3.0, 4.0, 4.0] and wide[:, 0].tolist() == [0.0, 2.0, 4.0, 6.0]
+    # no detections on a one-rank job: the empty result stays on the device
+    from dyk.ddp import gather_detections
+    assert gather_detections([None], [0]).shape == (0, 7)
+    e = gather_detections([torch.zeros((0, 6), device="cuda")], [0])
+    assert e.shape == (0, 7) and e.is_cuda

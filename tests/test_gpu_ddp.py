@@ -131,8 +131,11 @@ def test_dependency_scheduled_streams_equal_serial_execution_bitwise(name, dtype
     the same command lists enqueued in order on one stream: outputs, loss, every gradient, running statistics"""
     from build_utils.utils import compute_loss
     res = []
-    for mode in ("serial", "dag", "dag_graph", "dag6"):
+    for mode in ("serial", "dag", "dag_graph", "dag6", "dag_nopair"):
         monkeypatch.setenv("DYK_OVERLAP", "0" if mode == "serial" else "1")
+        monkeypatch.setenv("DYK_PAIR", "0" if mode == "dag_nopair" else "1")      # two-problem launches of the twin sections
+        monkeypatch.setenv("DYK_PAIR_OPS", "all" if mode in ("dag", "dag_graph") else "ew")    # all: convolutions too
+        monkeypatch.setenv("DYK_SCHED_POLICY", "hlfet" if mode == "dag6" else "typed")
         monkeypatch.setenv("DYK_STREAMS", "6" if mode == "dag6" else "4")
         monkeypatch.setenv("DYK_GRAPH", "1" if mode == "dag_graph" else "0")      # hipGraph of the dependency graph (optional path)
         m = _model(name, dtype)
@@ -148,6 +151,9 @@ def test_dependency_scheduled_streams_equal_serial_execution_bitwise(name, dtype
             plan = next(iter(m.engine.plans.values()))
             sc = plan.schedule("bwd", 0, len(plan.bwd))
             assert len({e["stream"] for e in sc.entries}) >= 3
+            # the twin backbones ride in two-problem launches (serial = one command per launch: the comparison partner)
+            assert sc.n == len(plan.bwd) - sc.n_pairs
+            assert {"dag_nopair": sc.n_pairs == 0, "dag6": sc.n_pairs >= 20}.get(mode, sc.n_pairs >= 100 or name != C3)
             assert bool(plan._graphs) == (mode == "dag_graph"), "the forward graph is captured on the second pass with the same pointers"
         res.append((outs, m.engine.store.G.clone(), m.engine.store.R.clone()))
     for other in res[1:]:

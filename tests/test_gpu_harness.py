@@ -160,6 +160,45 @@ def test_optimizer_state_dict_round_trip_and_format():
     topt.load_state_dict(osd)
 
 
+def test_sgd_resumes_from_a_torch_optim_sgd_checkpoint():
+    """torch.optim.SGD's state holds only 'momentum_buffer' (no 'step'); a FusedSGD loading such a checkpoint
+    must continue with the loaded momentum, not restart with m = g.  Two steps with torch.optim.SGD(nesterov) on the
+    product's gradients, checkpoint, third step: FusedSGD from the checkpoint == torch.optim.SGD continuing."""
+    from dyk.optim import FusedSGD
+    b = [_batch(20 + i) for i in range(3)]
+    m = _model(C1)
+    kw = dict(lr=1e-3, momentum=0.937, weight_decay=5e-4, nesterov=True)
+    topt = torch.optim.SGD(list(m.parameters()), **kw)
+    for i in range(2):
+        topt.zero_grad()
+        _backward(m, b[i])
+        topt.step()
+        m.engine.store.mark_dirty()
+    ck_model = {k: v.clone() for k, v in m.state_dict().items()}
+    osd = topt.state_dict()
+    assert "step" not in osd["state"][0] and "momentum_buffer" in osd["state"][0]
+    topt.zero_grad()
+    _backward(m, b[2])
+    topt.step()
+    want = m.engine.store.P.clone()
+    m2 = _model(C1)
+    m2.load_state_dict(ck_model)
+    x, y, _ = b[2]
+    m2(x, y)                                            # adopt the parameter store on the device
+    opt2 = FusedSGD(m2, **kw)
+    opt2.load_state_dict(osd)
+    assert opt2._t >= 1, "a checkpoint with momentum buffers is past the first step"
+    opt2.zero_grad()
+    _backward(m2, b[2])
+    opt2.step()
+    got = m2.engine.store.P
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    # FusedSGD -> FusedSGD round trip keeps its own step counter
+    opt3 = FusedSGD(m2, **kw)
+    opt3.load_state_dict(opt2.state_dict())
+    assert opt3._t == opt2._t
+
+
 def test_target_on_the_image_edge_raises_index_error():
     """a target with x == 1.0 indexes column nx of the grid: the reference raises IndexError inside compute_loss
     (utils.py:248); here the device flag is raised at the next optimizer step (or on demand)."""

@@ -8,7 +8,7 @@ import itertools
 import pytest
 import torch
 
-from helpers import C1, C3, C5
+from helpers import C1, C3, C5, INC, MNV2
 
 
 def _plan(name, training, B=2, H=64, W=96):
@@ -30,10 +30,14 @@ def _check(plan, st, which, start, end, n_streams):
     mem = sched.Memory(plan, st)
     sc = sched.build(plan, st, which, start, end, n_streams=n_streams)
     n = len(cmds)
-    assert sc.n == n and sorted(e["cmd"] for e in sc.entries) == list(range(start, end))
+    # every command exactly once, alone or as the second problem of a two-problem entry (twin sections)
+    covered = sorted([e["cmd"] for e in sc.entries] + [e["cmd2"] for e in sc.entries if e.get("cmd2", -1) >= 0])
+    assert covered == list(range(start, end))
+    assert sc.n == n - sc.n_pairs
     # happens-before closure over issue positions (bitsets): stream order + waits
     pos_of = {e["cmd"] - start: k for k, e in enumerate(sc.entries)}
-    before = [0] * n                      # before[k]: bitset of issue positions that complete before k starts
+    pos_of.update({e["cmd2"] - start: k for k, e in enumerate(sc.entries) if e.get("cmd2", -1) >= 0})
+    before = [0] * sc.n                   # before[k]: bitset of issue positions that complete before k starts
     last_on = {}
     for k, e in enumerate(sc.entries):
         b = 0
@@ -54,13 +58,24 @@ def _check(plan, st, which, start, end, n_streams):
         Rj, Wj, bj = acc[j]
         conflict = bi or bj or any(a.overlaps(b) for a in Wi for b in Rj + Wj) or any(a.overlaps(b) for a in Ri for b in Wj)
         if conflict:
+            assert pos_of[i] != pos_of[j], "conflicting commands %d, %d share one launch" % (i + start, j + start)
             assert (before[pos_of[j]] >> pos_of[i]) & 1, "commands %d -> %d (ops %d, %d) are not ordered" % (
                 i + start, j + start, cmds[i][0], cmds[j][0])
+    # a two-problem entry holds two commands of the same op and equal shape
+    from dyk import twins
+    for e in sc.entries:
+        if e.get("cmd2", -1) >= 0:
+            (o1, d1), (o2, d2) = cmds[e["cmd"] - start], cmds[e["cmd2"] - start]
+            assert o1 == o2 and twins.pair_signature(o1, d1, plan) == twins.pair_signature(o2, d2, plan)
     return sc, acc
 
 
-@pytest.mark.parametrize("name", [C3, C5, C1])
-def test_schedules_respect_every_memory_conflict(name):
+@pytest.mark.parametrize("name,pair,policy", [(C3, "all", "typed"), (C3, "ew", "typed"), (C3, "0", "hlfet"), (C5, "all", "hlfet"),
+                                              (C5, "ew", "typed"), (C1, "ew", "typed")])
+def test_schedules_respect_every_memory_conflict(name, pair, policy, monkeypatch):
+    monkeypatch.setenv("DYK_PAIR", "0" if pair == "0" else "1")
+    monkeypatch.setenv("DYK_PAIR_OPS", pair)
+    monkeypatch.setenv("DYK_SCHED_POLICY", policy)
     plan, st = _plan(name, True)
     for which, lst in (("fwd", plan.fwd), ("bwd", plan.bwd)):
         sc, acc = _check(plan, st, which, 0, len(lst), 4)
@@ -68,8 +83,20 @@ def test_schedules_respect_every_memory_conflict(name):
         from dyk import lib as L
         for (op, d), a in zip(lst, acc):
             assert not a[2] or op == L.OP_MEMSET, "op %d has no access model" % op
-        if name != C1:
-            assert sc.makespan_us < 0.8 * sc.serial_us, (which, sc.makespan_us, sc.serial_us)
+        if name != C1 and pair == "0":
+            assert sc.n_pairs == 0 and sc.makespan_us < 0.8 * sc.serial_us, (which, sc.makespan_us, sc.serial_us)
+        if policy == "typed":
+            # resource-typed streams: every matrix-pipe command on stream 0, the streaming passes elsewhere
+            for e in sc.entries:
+                op = lst[e["cmd"]][0]
+                assert (e["stream"] == 0) == (op in (L.OP_CONV, L.OP_WGRAD)) or op == L.OP_MEMSET, (op, e["stream"])
+        if name != C1 and pair == "ew":
+            assert sc.n_pairs >= 20 and not any(e["cmd2"] >= 0 and lst[e["cmd"]][0] in (L.OP_CONV, L.OP_WGRAD) for e in sc.entries)
+        if name != C1 and pair == "all":
+            # the twin sections' commands share launches: most convolutions of the dual-stream nets come in pairs
+            nconv = sum(1 for op, _ in lst if op == L.OP_CONV)
+            npair = sum(1 for e in sc.entries if e["cmd2"] >= 0 and lst[e["cmd"]][0] == L.OP_CONV)
+            assert 2 * npair >= (0.6 if name == C3 else 0.4) * nconv, (which, npair, nconv)
         assert {e["stream"] for e in sc.entries} <= set(range(4))
     # a sub-range (data-parallel segments) schedules on its own
     mid = len(plan.bwd) // 2
@@ -95,3 +122,28 @@ def test_eval_plan_schedules_and_channel_slices_are_independent():
     r2 = mem.block(a.ptr(b0) + 128, rs=256, width=128)
     r3 = mem.block(a.ptr(b0) + 64, rs=256, width=128)
     assert not r1.overlaps(r2) and r1.overlaps(r3) and r2.overlaps(r3) and r1.overlaps(mem.block(a.ptr(b0)))
+
+
+@pytest.mark.parametrize("name", [C3, C5, MNV2, INC])
+def test_conv_k_step_overread_stays_inside_the_tensors_own_block(name):
+    """the MFMA conv walks K in 32-channel steps; on a tight row (channel count not a multiple of 32) the last
+    step of the LAST pixel reads up to 48 bytes behind the tensor.  Those bytes must belong to the tensor's own arena
+    block (a zero pad nobody writes, dyk/plan.py kpad_bytes) -- never to a neighbouring block, whose writers the
+    scheduler treats as independent and whose contents (an fp32 block seen as bf16) could be Inf / NaN."""
+    from dyk import lib as L, sched
+    plan, st = _plan(name, True, B=2, H=64, W=96)
+    mem = sched.Memory(plan, st)
+    seen = 0
+    for lst in (plan.fwd, plan.bwd):
+        for op, d in lst:
+            if op != L.OP_CONV:
+                continue
+            es = 2 if d.dtype == L.DYK_BF16 else 4
+            r = mem.block(d.x)
+            assert r is not None and isinstance(r.key, tuple), "conv input outside the arenas"
+            base = plan.arenas[r.key[0]].ptr()
+            last = d.x + ((d.B * d.Hi * d.Wi - 1) * d.ldx + d.Cin) * es
+            assert last <= base + r.hi, "K-step tail of a conv input leaves its block by %d bytes" % (last - base - r.hi)
+            seen += (d.Cin * es) % 64 != 0 or (d.ldx * es) % 64 != 0
+    if name in (C5, MNV2):
+        assert seen > 10          # the MobileNet cfgs are the ones with tight rows
