@@ -326,7 +326,6 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
                 // for the forward conv of the same GEMM).  Addresses of dead chunks are clamped, their values ignored.
                 constexpr int NIT = (nchunk + 255) / 256;
                 constexpr int UB = (NIT % 2 == 0) ? 2 : 1;     // (5 or 4 loads per batch spill 400 bytes per lane into scratch)
-                const bool fast = (a.tune >> 21) & 1 ? false : true;      // bit 21: analysis switch, one load per trip (old form)
                 auto batched = [&](auto chain_tag) {
                     constexpr bool CH = decltype(chain_tag)::value;
                     for (int j0 = 0; j0 < NIT; j0 += UB) {
@@ -368,34 +367,7 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
                         }
                     }
                 };
-                if (fast) {
-                    if (chain) batched(std::true_type{}); else batched(std::false_type{});
-                } else
-                for (int q = tid; q < nchunk; q += 256) {
-                    const int row = q / cpr;
-                    const int po = t_out[row];
-                    if (po < 0) continue;
-                    float g[EPVT], yv[EPVT];
-                    vec_unpack<T>(*(const uint4*)(sC + row * rstride + cc * 16), g);
-                    vec_unpack<T>(*(const uint4*)((const T*)a.res + (long)t_res[row] + mc), yv);
-                    if (chain) {
-                        float ad[EPVT];
-                        vec_unpack<T>(*(const uint4*)((const T*)a.add + (long)po + mc), ad);
-#pragma unroll
-                        for (int j = 0; j < EPVT; ++j) g[j] += ad[j];
-                        const uint4 pk = vec_pack<T>(g);
-                        *(uint4*)((T*)a.y + (long)po + mc) = pk;
-                        vec_unpack<T>(pk, g);              // the apply pass will see the rounded dz: reduce the same values
-                    }
-#pragma unroll
-                    for (int j = 0; j < EPVT; ++j) {
-                        const float da = g[j] * act_bwd_c<ACTB>(yv[j] * sc[j] + sh[j], a.act);
-                        s1[j] += da;
-                        s2[j] += da * ((yv[j] - mu[j]) * rs[j]);
-                        g[j] = da;
-                    }
-                    if (!chain) *(uint4*)((T*)a.y + (long)po + mc) = vec_pack<T>(g);
-                }
+                if (chain) batched(std::true_type{}); else batched(std::false_type{});
             }
 #pragma unroll
             for (int j = 0; j < EPVT; ++j) {
@@ -423,15 +395,156 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
                 }
             }
         };
+        // ---- BatchNorm-backward epilogue, round-3 form: the raw conv output of the tile (and, in chain mode, the addend)
+        // arrives by LDS-DMA in ONE memory round trip -- the batched form above walks nchunk/256 chunks per thread with two
+        // loads in flight (5 dependent round trips for a 128 x 160 tile: 128->128 3x3 @64x80 forward 36 us, data gradient
+        // 63 us).  The tile lands lane-linear in the staging area (dense rows of BM elements, which the ring no longer
+        // needs); every lane then picks up the four channels of each of its accumulator fragments (ds_read_b64 / b128),
+        // forms da = dz * act'(u) in registers FROM THE FP32 ACCUMULATORS, reduces sum(da), sum(da * xhat) like the
+        // forward statistics (in-lane over the pixel fragments, DPP row sums over the 16 pixel lanes, waves in order,
+        // one fp64 atomic per channel and workgroup) and writes the result back over the bytes it read; the tile leaves
+        // through the same 16-byte coalesced stores as every other epilogue.
+        auto dma_bnbwd = [&](auto actb_tag) {
+            constexpr int ACTB = decltype(actb_tag)::value;
+            constexpr int eso = (int)sizeof(T);
+            constexpr int RB = BM * eso;                          // dense tile row (bytes)
+            constexpr int CPRW = RB / 16;                         // 16-byte chunks per row
+            constexpr int RPI = 64 / CPRW;                        // tile rows per DMA wave instruction
+            constexpr int NIY = BN * CPRW / 64;                   // DMA instructions per tile
+            constexpr int EPVT = 16 / eso;
+            static_assert(64 % CPRW == 0 && (BN * CPRW) % 64 == 0, "tile must be whole DMA instructions");
+            const int wv = __builtin_amdgcn_readfirstlane(wid);
+            const bool chain = (flags & DYK_EPI_ADDEND) != 0;
+            const T* zero = (const T*)dyk_zero_page;
+            auto dma_tile = [&](const T* base, const int* t_pix) {
+#pragma unroll
+                for (int j = 0; j < (NIY + 3) / 4; ++j) {
+                    const int inst = j * 4 + wv;
+                    if (inst < NIY) {
+                        const int row = inst * RPI + lane / CPRW, ch = (lane % CPRW) * EPVT;
+                        const bool ok = t_out[row] >= 0 && m0 + ch + EPVT <= a.Cout;
+                        const T* src = ok ? base + (long)t_pix[row] + m0 + ch : zero;
+                        glds16(src, lds_addr_of(sC + inst * 1024));
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            };
+            if (chain) {
+                // dz = acc + addend, rounded to the storage type: the apply pass will see the rounded value, so da below is
+                // formed from it
+                dma_tile((const T*)a.add, t_out);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int ml = wm * WTM + mi * 16 + mlane;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int nl = wn * WTN + ni * 16 + (lane & 15);
+                        const char* src = sC + nl * RB + ml * eso;
+                        if constexpr (sizeof(T) == 4) {
+                            const float4 v = *(const float4*)src;
+                            acc[mi][ni][0] += v.x; acc[mi][ni][1] += v.y; acc[mi][ni][2] += v.z; acc[mi][ni][3] += v.w;
+                        } else {
+                            const uint2 v = *(const uint2*)src;
+                            acc[mi][ni][0] += __uint_as_float(v.x << 16); acc[mi][ni][1] += __uint_as_float(v.x & 0xffff0000u);
+                            acc[mi][ni][2] += __uint_as_float(v.y << 16); acc[mi][ni][3] += __uint_as_float(v.y & 0xffff0000u);
+                            const uint32_t p0 = f32x2_to_bf16x2(acc[mi][ni][0], acc[mi][ni][1]), p1 = f32x2_to_bf16x2(acc[mi][ni][2], acc[mi][ni][3]);
+                            acc[mi][ni][0] = __uint_as_float(p0 << 16); acc[mi][ni][1] = __uint_as_float(p0 & 0xffff0000u);
+                            acc[mi][ni][2] = __uint_as_float(p1 << 16); acc[mi][ni][3] = __uint_as_float(p1 & 0xffff0000u);
+                        }
+                    }
+                }
+                __syncthreads();                                  // everybody has read the addend: the tile area is free again
+            }
+            dma_tile((const T*)a.res, t_res);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int ml = wm * WTM + mi * 16 + mlane;
+                const int m = m0 + ml;
+                float sc[4], sh[4], mu[4], rs[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool okc = m + r < a.Cout;
+                    sc[r] = okc ? a.scale[m + r] : 0.f; sh[r] = okc ? a.shift[m + r] : 0.f;
+                    mu[r] = okc ? a.aux0[m + r] : 0.f; rs[r] = okc ? a.aux1[m + r] : 0.f;
+                }
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int nl = wn * WTN + ni * 16 + (lane & 15);
+                    char* cell = sC + nl * RB + ml * eso;
+                    float yv[4];
+                    if constexpr (sizeof(T) == 4) {
+                        const float4 v = *(const float4*)cell;
+                        yv[0] = v.x; yv[1] = v.y; yv[2] = v.z; yv[3] = v.w;
+                    } else {
+                        const uint2 v = *(const uint2*)cell;
+                        yv[0] = __uint_as_float(v.x << 16); yv[1] = __uint_as_float(v.x & 0xffff0000u);
+                        yv[2] = __uint_as_float(v.y << 16); yv[3] = __uint_as_float(v.y & 0xffff0000u);
+                    }
+                    const bool livep = t_out[nl] >= 0;            // (ragged tile rows: zero page, accumulators of padding pixels)
+                    float outv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float g = acc[mi][ni][r];
+                        const float da = g * act_bwd_c<ACTB>(yv[r] * sc[r] + sh[r], a.act);
+                        if (livep) { s1[r] += da; s2[r] += da * ((yv[r] - mu[r]) * rs[r]); }
+                        outv[r] = chain ? g : da;
+                    }
+                    if constexpr (sizeof(T) == 4) {
+                        *(float4*)cell = make_float4(outv[0], outv[1], outv[2], outv[3]);
+                    } else {
+                        uint2 pk;
+                        pk.x = f32x2_to_bf16x2(outv[0], outv[1]);
+                        pk.y = f32x2_to_bf16x2(outv[2], outv[3]);
+                        *(uint2*)cell = pk;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t1 = row16_sum(s1[r]), t2 = row16_sum(s2[r]);
+                    if ((lane & 15) == 0) {
+                        s_stat[(wn * 2 + 0) * BM + ml + r] = t1;
+                        s_stat[(wn * 2 + 1) * BM + ml + r] = t2;
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * BM) {
+                const int ml = tid % BM, which = tid / BM;
+                if (m0 + ml < a.Cout) {
+                    float tot = 0.f;
+#pragma unroll
+                    for (int q = 0; q < WN; ++q) tot += s_stat[(q * 2 + which) * BM + ml];
+                    double* st = a.stats + (size_t)((unsigned)blk % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
+                    atomicAdd(st + which * a.Cout + m0 + ml, (double)tot);
+                }
+            }
+            constexpr int nchunk = BN * CPRW;
+            for (int q = tid; q < nchunk; q += 256) {
+                const int row = q / CPRW, cc = q % CPRW;
+                const int po = t_out[row];
+                const int mc = m0 + cc * EPVT;
+                if (po < 0 || mc + EPVT > a.Cout) continue;
+                *(uint4*)((T*)a.y + (long)po + mc) = *(const uint4*)(sC + row * RB + cc * 16);
+            }
+        };
         using std::integral_constant;
         using std::true_type;
         using std::false_type;
         if (flags & DYK_EPI_BNBWD) {
+            if ((a.tune >> 21) & 1) {          // analysis switch: the round-2 form (register-staged raw output, batched loads)
+                switch (a.act) {
+                case DYK_ACT_MISH: staged_bnbwd(integral_constant<int, DYK_ACT_MISH>{}); break;
+                default: staged_bnbwd(integral_constant<int, -1>{}); break;
+                }
+                return;
+            }
             switch (a.act) {
-            case DYK_ACT_LINEAR: staged_bnbwd(integral_constant<int, DYK_ACT_LINEAR>{}); break;
-            case DYK_ACT_LEAKY: staged_bnbwd(integral_constant<int, DYK_ACT_LEAKY>{}); break;
-            case DYK_ACT_MISH: staged_bnbwd(integral_constant<int, DYK_ACT_MISH>{}); break;
-            default: staged_bnbwd(integral_constant<int, -1>{}); break;
+            case DYK_ACT_LINEAR: dma_bnbwd(integral_constant<int, DYK_ACT_LINEAR>{}); break;
+            case DYK_ACT_LEAKY: dma_bnbwd(integral_constant<int, DYK_ACT_LEAKY>{}); break;
+            case DYK_ACT_MISH: dma_bnbwd(integral_constant<int, DYK_ACT_MISH>{}); break;
+            default: dma_bnbwd(integral_constant<int, -1>{}); break;
             }
             return;
         }
@@ -1036,6 +1149,12 @@ int dispatch_conv_halo(const DykConvDesc* d, hipStream_t stream) {
     const int bm_code = (d->tune >> 24) & 0xf;
     if (bm_code == 2) bm = 64;
     if (bm_code == 3) bm = 128;
+    if constexpr (TH == 8) {
+        // 32-channel tiles (8 x 20 patches only: a wave needs 16 channel rows): the data gradients into 32-channel tensors
+        // at 256 x 320 (3x3 32 -> 64 of the first CSP block) spend a 64-row tile half on zero rows
+        if (d->Cout <= 32 && bm_code != 2 && bm_code != 3)
+            return k128 ? launch_conv_halo<T, 32, TH, 128>(d, stream) : launch_conv_halo<T, 32, TH, 64>(d, stream);
+    }
     if (k128) return bm == 128 ? launch_conv_halo<T, 128, TH, 128>(d, stream) : launch_conv_halo<T, 64, TH, 128>(d, stream);
     return bm == 128 ? launch_conv_halo<T, 128, TH, 64>(d, stream) : launch_conv_halo<T, 64, TH, 64>(d, stream);
 }

@@ -145,7 +145,7 @@ class GradAllReduce:
             # twin sections (dyk/twins.py) run as two-problem launches: a cut between the backward of section t and that
             # of its twin l < t would leave both halves unpaired, so no bucket closes at a layer in (l, t]
             twin_spans = sorted((l, t) for l, t in getattr(plan, "twin_layer", {}).items() if l < t) \
-                if os.environ.get("DYK_PAIR", "1") != "0" else []
+                if os.environ.get("DYK_PAIR", "0") != "0" else []
             for k in range(1, len(marks)):
                 c_end, layer_done = marks[k][0], marks[k - 1][1]     # commands [.., c_end) finish layer `layer_done`
                 lo = min((o for l, o in first_off.items() if l >= layer_done), default=hi)

@@ -961,9 +961,13 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                         setattr(r, "red", ws.ptr(red))))
                     plan.bwd.append((L.OP_BN_BWD_REDUCE, r))
                 dyr = dz
-                if os.environ.get("DYK_DEBUG_PLAN") or rec.get("dz_is_addend"):
-                    # keep dz intact: per-layer gradient dumps / it is still to be added to the skip tensor's gradient
+                if os.environ.get("DYK_DEBUG_PLAN") or rec.get("dz_is_addend") or os.environ.get("DYK_KEEP_DZ"):
+                    # keep dz intact: per-layer gradient dumps / it is still to be added to the skip tensor's gradient /
+                    # DYK_KEEP_DZ: the SAME commands and fusions as the default plan, only the apply pass writes beside
+                    # its input instead of over it, so that both sides of every BatchNorm backward stay readable
+                    # (tests/test_gpu_bwd_bf16.py holds each section of the backward to the oracle on identical inputs)
                     dyr = TRef("grad", grad_arena.alloc(dz.npix * dz.ld * es, pad=kpad_bytes(dz.ld, es)), dz.B, dz.H, dz.W, dz.C, dz.ld, es)
+                rec["dz_ref"], rec["dy_raw_ref"] = dz, dyr
                 ap = ew_desc(a=dz, b=rec["y_raw"], out=dyr, act=act_bwd)        # in place: dz (or da) -> dy_raw
                 # the apply pass folds the replicas of the reduction itself and adds them to dgamma / dbeta
                 ap.slots = STAT_SLOTS

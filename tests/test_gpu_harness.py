@@ -175,7 +175,8 @@ def test_sgd_resumes_from_a_torch_optim_sgd_checkpoint():
         topt.step()
         m.engine.store.mark_dirty()
     ck_model = {k: v.clone() for k, v in m.state_dict().items()}
-    osd = topt.state_dict()
+    import copy
+    osd = copy.deepcopy(topt.state_dict())              # (state_dict() hands out the live buffers: the next step would change them)
     assert "step" not in osd["state"][0] and "momentum_buffer" in osd["state"][0]
     topt.zero_grad()
     _backward(m, b[2])
