@@ -120,19 +120,55 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(DykFinPair fp, DykEwP
     const int PY = 256 / CVB;
     const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
     const int cv = blockIdx.x * CVB + tx;
-    const bool live = cv * EPV < d.C;
+    {
+        const int c_base = blockIdx.x * CVB * EPV;
+        const int nch = min(CVB * EPV, d.C - c_base);
+        const int slots = f.slots > 0 ? f.slots : 1;
+        const size_t rs = (size_t)2 * f.C;
+        for (int cl = threadIdx.x; cl < nch; cl += 256) {
+            const int c = c_base + cl;
+            double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+            int r = 0;
+            for (; r + 4 <= slots; r += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a1[u] += f.stats[(size_t)(r + u) * rs + c]; a2[u] += f.stats[(size_t)(r + u) * rs + f.C + c]; }
+            }
+            for (; r < slots; ++r) { a1[0] += f.stats[(size_t)r * rs + c]; a2[0] += f.stats[(size_t)r * rs + f.C + c]; }
+            const double n = (double)f.count;
+            const double mean = ((a1[0] + a1[1]) + (a1[2] + a1[3])) / n;
+            double var = ((a2[0] + a2[1]) + (a2[2] + a2[3])) / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+            const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+            const float sc = g * rstd, sh = b - (float)mean * sc;
+            s_aff[0][cl] = sc;
+            s_aff[1][cl] = sh;
+            if (blockIdx.y == 0) {
+                f.scale[c] = sc;
+                f.shift[c] = sh;
+                if (f.save_mean) f.save_mean[c] = (float)mean;
+                if (f.save_rstd) f.save_rstd[c] = rstd;
+                if (f.running_mean) {
+                    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+                    f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+                    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (cv * EPV >= d.C) return;
     const int c = cv * EPV;
+    float sc[EPV], sh[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) { sc[j] = s_aff[0][tx * EPV + j]; sh[j] = s_aff[1][tx * EPV + j]; }
     const T* __restrict__ a = (const T*)d.a;
     const T* __restrict__ r = (const T*)d.b;
     T* __restrict__ o = (T*)d.out;
     constexpr int U = 4;
     const long pstep = (long)gridDim.y * PY;
-    // The first batch of pixel loads is issued BEFORE the statistics replicas are folded: on the 5-20 MB tensors of the
-    // deep stages this launch is a chain of memory round trips (replica loads -> barrier -> pixel loads -> stores, 10-14 us
-    // for 2-4 us of traffic); the tensor does not depend on the fold, so the two round trips overlap.
-    uint4 vx[U], vr[U];
-    const long pfirst = (long)blockIdx.y * PY + ty;
-    auto load_batch = [&](long p0) {
+    for (long p0 = (long)blockIdx.y * PY + ty; p0 < d.npix; p0 += pstep * U) {
+        uint4 vx[U], vr[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long p = p0 + u * pstep;
@@ -141,50 +177,6 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(DykFinPair fp, DykEwP
                 if (r) vr[u] = *(const uint4*)(r + p * d.ldb + c);
             }
         }
-    };
-    if (live) load_batch(pfirst);
-    {
-        const int c_base = blockIdx.x * CVB * EPV;
-        const int nch = min(CVB * EPV, d.C - c_base);
-        const int slots = f.slots > 0 ? f.slots : 1;
-        const size_t rs = (size_t)2 * f.C;
-        for (int cl = threadIdx.x; cl < nch; cl += 256) {
-            const int cc = c_base + cl;
-            double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
-            int q = 0;
-            for (; q + 4 <= slots; q += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { a1[u] += f.stats[(size_t)(q + u) * rs + cc]; a2[u] += f.stats[(size_t)(q + u) * rs + f.C + cc]; }
-            }
-            for (; q < slots; ++q) { a1[0] += f.stats[(size_t)q * rs + cc]; a2[0] += f.stats[(size_t)q * rs + f.C + cc]; }
-            const double n = (double)f.count;
-            const double mean = ((a1[0] + a1[1]) + (a1[2] + a1[3])) / n;
-            double var = ((a2[0] + a2[1]) + (a2[2] + a2[3])) / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
-            const float g = f.gamma ? f.gamma[cc] : 1.f, b = f.beta ? f.beta[cc] : 0.f;
-            const float sc = g * rstd, sh = b - (float)mean * sc;
-            s_aff[0][cl] = sc;
-            s_aff[1][cl] = sh;
-            if (blockIdx.y == 0) {
-                f.scale[cc] = sc;
-                f.shift[cc] = sh;
-                if (f.save_mean) f.save_mean[cc] = (float)mean;
-                if (f.save_rstd) f.save_rstd[cc] = rstd;
-                if (f.running_mean) {
-                    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-                    f.running_mean[cc] = (1.f - f.momentum) * f.running_mean[cc] + f.momentum * (float)mean;
-                    f.running_var[cc] = (1.f - f.momentum) * f.running_var[cc] + f.momentum * (float)unb;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (!live) return;
-    float sc[EPV], sh[EPV];
-#pragma unroll
-    for (int j = 0; j < EPV; ++j) { sc[j] = s_aff[0][tx * EPV + j]; sh[j] = s_aff[1][tx * EPV + j]; }
-    for (long p0 = pfirst; p0 < d.npix;) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long p = p0 + u * pstep;
@@ -201,8 +193,6 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(DykFinPair fp, DykEwP
             }
             *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(y);
         }
-        p0 += pstep * U;
-        if (p0 < d.npix) load_batch(p0);
     }
 }
 
@@ -298,29 +288,6 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwPair pr, int
     const int PY = 256 / CVB;
     const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
     const int cv = blockIdx.x * CVB + tx;
-    const bool live = cv * EPV < d.C;
-    const int c = cv * EPV;
-    const T* __restrict__ dz = (const T*)d.a;
-    const T* __restrict__ y = (const T*)d.b;
-    T* __restrict__ o = (T*)d.out;
-    const bool accum = d.flags & DYK_EW_ACCUM;
-    constexpr int U = 4;
-    const long pstep = (long)gridDim.y * PY;
-    const long pfirst = (long)blockIdx.y * PY + ty;
-    // first batch of tensor loads ahead of the replica fold (see bn_fused_fwd_kernel): the two round trips overlap
-    uint4 vg[U], vy[U], vo[U];
-    auto load_batch = [&](long p0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long p = p0 + u * pstep;
-            if (p < d.npix) {
-                vg[u] = *(const uint4*)(dz + p * d.lda + c);
-                vy[u] = *(const uint4*)(y + p * d.ldb + c);
-                if (accum) vo[u] = *(const uint4*)(o + p * d.ldo + c);
-            }
-        }
-    };
-    if (live) load_batch(pfirst);
     {
         const int c_base = blockIdx.x * CVB * EPV;
         const int nch = min(CVB * EPV, d.C - c_base);
@@ -346,7 +313,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwPair pr, int
         }
         __syncthreads();
     }
-    if (!live) return;
+    if (cv * EPV >= d.C) return;
+    const int c = cv * EPV;
     const float invn = 1.f / (float)d.npix;
     float sc[EPV], sh[EPV], mu[EPV], rs[EPV], m1[EPV], m2[EPV];
 #pragma unroll
@@ -354,7 +322,23 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwPair pr, int
         sc[j] = d.p0[c + j]; sh[j] = d.p1[c + j]; mu[j] = d.p2[c + j]; rs[j] = d.p3[c + j];
         m1[j] = s_tot[0][tx * EPV + j] * invn; m2[j] = s_tot[1][tx * EPV + j] * invn;
     }
-    for (long p0 = pfirst; p0 < d.npix;) {
+    const T* __restrict__ dz = (const T*)d.a;
+    const T* __restrict__ y = (const T*)d.b;
+    T* __restrict__ o = (T*)d.out;
+    const bool accum = d.flags & DYK_EW_ACCUM;
+    constexpr int U = 4;
+    const long pstep = (long)gridDim.y * PY;
+    for (long p0 = (long)blockIdx.y * PY + ty; p0 < d.npix; p0 += pstep * U) {
+        uint4 vg[U], vy[U], vo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long p = p0 + u * pstep;
+            if (p < d.npix) {
+                vg[u] = *(const uint4*)(dz + p * d.lda + c);
+                vy[u] = *(const uint4*)(y + p * d.ldb + c);
+                if (accum) vo[u] = *(const uint4*)(o + p * d.ldo + c);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long p = p0 + u * pstep;
@@ -376,8 +360,6 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwPair pr, int
             }
             *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(r);
         }
-        p0 += pstep * U;
-        if (p0 < d.npix) load_batch(p0);
     }
 }
 

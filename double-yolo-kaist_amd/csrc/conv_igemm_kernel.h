@@ -102,7 +102,11 @@ template <int BN> constexpr int table_bytes() { return BN * (3 * 4 + 2 * 2) + 10
 
 // Shared epilogue of the convolution kernels: BN statistics, affine / activation / residual / accumulate, staged
 // coalesced stores.  Called by every thread after the K loop's last barrier (the operand ring is free: sC overlays it).
-template <typename T, int BM, int BN>
+// EPIK = 0: forward / plain data-gradient epilogues (statistics, affine, activation, residual, accumulate);
+// EPIK = 1: the fused BatchNorm-backward epilogues (DYK_EPI_BNBWD).  Separate kernel instantiations: with both families in
+// one kernel the 128 x 160 tile spilled 320-350 VGPRs (272-332 bytes of scratch per lane, also paid by the forward launches:
+// +0.4 ms per step over all forward convolutions when the LDS-DMA form of the BatchNorm-backward epilogue was added).
+template <typename T, int BM, int BN, int EPIK = 0>
 __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&acc)[(BM / WaveGrid<BM, BN>::WM) / 16][(BN / WaveGrid<BM, BN>::WN) / 16],
                                               char* sC, float* s_stat, const int* t_out, const int* t_res, int m0, int blk) {
     constexpr int WM = WaveGrid<BM, BN>::WM, WN = WaveGrid<BM, BN>::WN;
@@ -122,7 +126,7 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
     }
     const int flags = a.flags;
     const int mlane = (lane >> 4) * 4;
-    if (flags & DYK_EPI_STATS) {
+    if (EPIK == 0 && (flags & DYK_EPI_STATS)) {
         // per-channel sum / sum of squares of the raw accumulators: in-lane over ni, DPP row rotate-adds over the
         // 16 pixel lanes, one LDS slot per wave (summed in wave order: the forward pass is reproducible -- with LDS
         // float atomics the order of the adds, and through the chaotic random-weight nets the outputs, changed from
@@ -532,9 +536,15 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
         using std::integral_constant;
         using std::true_type;
         using std::false_type;
-        if (flags & DYK_EPI_BNBWD) {
-            if ((a.tune >> 21) & 1) {          // analysis switch: the round-2 form (register-staged raw output, batched loads)
+        if constexpr (EPIK == 1) {
+            // Measured (round 3, same box, every launch alone): the LDS-DMA form takes 10 % off the plain fused epilogue
+            // (3x3 128->128 @64x80: 70 -> 64 us, 64->32 @256x320 -9 %), but in chain mode (addend + raw output = two
+            // dependent DMA round trips with a barrier each) it LOSES 10-25 % against the batched register form (1x1
+            // 128->128 @64x80: 32 -> 38 us): each mode keeps its faster form.  tune bit 21 forces the register form.
+            if ((flags & DYK_EPI_ADDEND) || ((a.tune >> 21) & 1)) {
                 switch (a.act) {
+                case DYK_ACT_LINEAR: staged_bnbwd(integral_constant<int, DYK_ACT_LINEAR>{}); break;
+                case DYK_ACT_LEAKY: staged_bnbwd(integral_constant<int, DYK_ACT_LEAKY>{}); break;
                 case DYK_ACT_MISH: staged_bnbwd(integral_constant<int, DYK_ACT_MISH>{}); break;
                 default: staged_bnbwd(integral_constant<int, -1>{}); break;
                 }
@@ -547,23 +557,25 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
             default: dma_bnbwd(integral_constant<int, -1>{}); break;
             }
             return;
-        }
-        if (out_f32) {
-            // heads (bias, linear) and the fp32 dtype: runtime activation, few launches
-            if (!affine && a.act == 0) staged(true_type{}, integral_constant<int, 0>{}, false_type{});
-            else if (a.act == 0) staged(true_type{}, integral_constant<int, 0>{}, true_type{});
-            else staged(true_type{}, integral_constant<int, -1>{}, true_type{});
+        } else {
+            if (out_f32) {
+                // heads (bias, linear) and the fp32 dtype: runtime activation, few launches
+                if (!affine && a.act == 0) staged(true_type{}, integral_constant<int, 0>{}, false_type{});
+                else if (a.act == 0) staged(true_type{}, integral_constant<int, 0>{}, true_type{});
+                else staged(true_type{}, integral_constant<int, -1>{}, true_type{});
+                return;
+            }
+            if (!affine && a.act == 0) { staged(false_type{}, integral_constant<int, 0>{}, false_type{}); return; }
+            switch (a.act) {
+            case DYK_ACT_LINEAR: staged(false_type{}, integral_constant<int, DYK_ACT_LINEAR>{}, true_type{}); break;
+            case DYK_ACT_LEAKY: staged(false_type{}, integral_constant<int, DYK_ACT_LEAKY>{}, true_type{}); break;
+            case DYK_ACT_MISH: staged(false_type{}, integral_constant<int, DYK_ACT_MISH>{}, true_type{}); break;
+            default: staged(false_type{}, integral_constant<int, -1>{}, true_type{}); break;
+            }
             return;
         }
-        if (!affine && a.act == 0) { staged(false_type{}, integral_constant<int, 0>{}, false_type{}); return; }
-        switch (a.act) {
-        case DYK_ACT_LINEAR: staged(false_type{}, integral_constant<int, DYK_ACT_LINEAR>{}, true_type{}); break;
-        case DYK_ACT_LEAKY: staged(false_type{}, integral_constant<int, DYK_ACT_LEAKY>{}, true_type{}); break;
-        case DYK_ACT_MISH: staged(false_type{}, integral_constant<int, DYK_ACT_MISH>{}, true_type{}); break;
-        default: staged(false_type{}, integral_constant<int, -1>{}, true_type{}); break;
-        }
-        return;
     }
+    if constexpr (EPIK == 1) return;           // (the fused BatchNorm-backward epilogue exists in the staged form only: validated by the front end)
     // ---- fallback: per-lane stores straight from the MFMA layout (unaligned / odd-stride outputs)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -617,8 +629,11 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
 //       holds two 4-wave groups that walk the two halves of the input channels with private LDS rings (same barriers);
 //       group 1 hands its accumulators to group 0 through LDS before the epilogue -- twice the waves per CU without a
 //       split-K pass through memory.  2-stage ring only.
-template <typename T, int BM, int BN, int BKB, int PIPE, int KG = 1>
-__global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_kernel(const ConvArgs args) {
+// (the 128 x 160 tile with the BatchNorm-backward epilogue needs more than the 168 VGPRs of three waves per SIMD: 72-209
+// spilled registers; its LDS footprint allows two workgroups per CU for most configurations anyway)
+template <typename T, int BM, int BN, int BKB, int PIPE, int KG = 1, int EPIK = 0>
+__global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(EPIK == 1 && BM * BN >= 128 * 160 ? 2 : 3)))
+void conv_igemm_kernel(const ConvArgs args) {
     static_assert(KG == 1 || PIPE == 2, "K-groups use the 2-stage ring");
     int blk, nblk;
     const DykConvDesc& a = args.d[conv_pick_problem(args, blk, nblk)];
@@ -874,7 +889,7 @@ __global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(3))) v
     }
 
     // ------------------------------------------------------------------ epilogue
-    conv_epilogue<T, BM, BN>(a, acc, sC, s_stat, t_out, t_res, m0, blk);
+    conv_epilogue<T, BM, BN, EPIK>(a, acc, sC, s_stat, t_out, t_res, m0, blk);
 }
 
 // ======================================================================================
@@ -892,8 +907,9 @@ template <int BM, int TH> constexpr int halo_table_bytes() {
     return HaloGeom<TH>::BN * 8 + 1024 + 2 * 32 * 4 + 4 * 2 * 128 * 4;
 }
 
-template <typename T, int BM, int TH, int BKB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_halo_kernel(const ConvArgs args) {
+template <typename T, int BM, int TH, int BKB, int EPIK = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPIK == 1 && BM * HaloGeom<TH>::BN >= 128 * 160 ? 2 : 3)))
+void conv_halo_kernel(const ConvArgs args) {
     int blk, nblk;
     const DykConvDesc& a = args.d[conv_pick_problem(args, blk, nblk)];
     using G = HaloGeom<TH>;
@@ -1068,7 +1084,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         nxt = (nxt == NA - 1) ? 0 : nxt + 1;
         if (++t == 9) { t = 0; ++c; }
     }
-    conv_epilogue<T, BM, BN>(a, acc, sC, s_stat, t_out, t_res, m0, blk);
+    conv_epilogue<T, BM, BN, EPIK>(a, acc, sC, s_stat, t_out, t_res, m0, blk);
 }
 
 // fills the kernel arguments of a single- or two-problem launch; returns the grid size.  `vec`: the staged (16-byte
@@ -1107,7 +1123,7 @@ inline bool conv_halo_eligible(const DykConvDesc* d, int TH) {
     return true;
 }
 
-template <typename T, int BM, int TH, int BKB>
+template <typename T, int BM, int TH, int BKB, int EPIK = 0>
 int launch_conv_halo(const DykConvDesc* d, hipStream_t stream) {
     using G = HaloGeom<TH>;
     constexpr int BN = G::BN;
@@ -1120,7 +1136,7 @@ int launch_conv_halo(const DykConvDesc* d, hipStream_t stream) {
     const size_t body = ring + hsrc > stage_c ? ring + hsrc : stage_c;
     const size_t lds = halo_table_bytes<BM, TH>() + body;
     static bool attr_set = false;
-    auto kfn = conv_halo_kernel<T, BM, TH, BKB>;
+    auto kfn = conv_halo_kernel<T, BM, TH, BKB, EPIK>;
     if (!attr_set) {
         constexpr size_t sc_max = (size_t)BN * (BM * 4 + 16);
         constexpr size_t lds_max = halo_table_bytes<BM, TH>() + (ring + hsrc > sc_max ? ring + hsrc : sc_max);
@@ -1139,7 +1155,7 @@ int launch_conv_halo(const DykConvDesc* d, hipStream_t stream) {
 }
 
 // pixel-tile codes 3 / 4 of the tune word: halo kernel with 4x20 / 8x20 pixel patches
-template <typename T, int TH>
+template <typename T, int TH, int EPIK = 0>
 int dispatch_conv_halo(const DykConvDesc* d, hipStream_t stream) {
     if (!conv_halo_eligible(d, TH)) return DYK_ERR_UNSUPPORTED;
     const int row_bytes = d->Cin * (int)sizeof(T);
@@ -1153,13 +1169,13 @@ int dispatch_conv_halo(const DykConvDesc* d, hipStream_t stream) {
         // 32-channel tiles (8 x 20 patches only: a wave needs 16 channel rows): the data gradients into 32-channel tensors
         // at 256 x 320 (3x3 32 -> 64 of the first CSP block) spend a 64-row tile half on zero rows
         if (d->Cout <= 32 && bm_code != 2 && bm_code != 3)
-            return k128 ? launch_conv_halo<T, 32, TH, 128>(d, stream) : launch_conv_halo<T, 32, TH, 64>(d, stream);
+            return k128 ? launch_conv_halo<T, 32, TH, 128, EPIK>(d, stream) : launch_conv_halo<T, 32, TH, 64, EPIK>(d, stream);
     }
-    if (k128) return bm == 128 ? launch_conv_halo<T, 128, TH, 128>(d, stream) : launch_conv_halo<T, 64, TH, 128>(d, stream);
-    return bm == 128 ? launch_conv_halo<T, 128, TH, 64>(d, stream) : launch_conv_halo<T, 64, TH, 64>(d, stream);
+    if (k128) return bm == 128 ? launch_conv_halo<T, 128, TH, 128, EPIK>(d, stream) : launch_conv_halo<T, 64, TH, 128, EPIK>(d, stream);
+    return bm == 128 ? launch_conv_halo<T, 128, TH, 64, EPIK>(d, stream) : launch_conv_halo<T, 64, TH, 64, EPIK>(d, stream);
 }
 
-template <typename T, int BM, int BN, int BKB, int PIPE, int KG = 1>
+template <typename T, int BM, int BN, int BKB, int PIPE, int KG = 1, int EPIK = 0>
 int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     constexpr int TABLE_BYTES = table_bytes<BN>();
     constexpr size_t ring = KG > 1 ? (size_t)KG * PIPE * (BM + BN) * BKB + 0 : PIPE * (size_t)(BM + BN) * BKB;   // K-groups: private rings; the 16 KiB-per-wave park area (BM*BN*4) fits inside
@@ -1169,7 +1185,7 @@ int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     const size_t stage_c = (size_t)BN * (BM * (of32 ? 4 : 2) + 16);
     const size_t lds = TABLE_BYTES + (ring > stage_c ? ring : stage_c);
     static bool attr_set = false;
-    auto kfn = conv_igemm_kernel<T, BM, BN, BKB, PIPE, KG>;
+    auto kfn = conv_igemm_kernel<T, BM, BN, BKB, PIPE, KG, EPIK>;
     if (!attr_set) {
         constexpr size_t lds_max = TABLE_BYTES + (ring > (size_t)BN * (BM * 4 + 16) ? ring : (size_t)BN * (BM * 4 + 16));
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -1191,21 +1207,21 @@ int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     return DYK_OK;
 }
 
-template <typename T, int BM, int BN, int BKB>
+template <typename T, int BM, int BN, int BKB, int EPIK = 0>
 int launch_conv(const DykConvDesc* d, hipStream_t stream) {
     // 2-stage ring by default: 2-4 resident workgroups per CU beat a deeper ring unless the autotuner says otherwise
     switch ((d->tune >> 8) & 0xf) {
-    case 3: return launch_conv_impl<T, BM, BN, BKB, 3>(d, stream);
-    case 4: return launch_conv_impl<T, BM, BN, BKB, 4>(d, stream);
-    case 6: if constexpr ((size_t)6 * (BM + BN) * BKB + table_bytes<BN>() <= 160 * 1024) return launch_conv_impl<T, BM, BN, BKB, 6>(d, stream);
-            else return launch_conv_impl<T, BM, BN, BKB, 4>(d, stream);
-    default: return launch_conv_impl<T, BM, BN, BKB, 2>(d, stream);
+    case 3: return launch_conv_impl<T, BM, BN, BKB, 3, 1, EPIK>(d, stream);
+    case 4: return launch_conv_impl<T, BM, BN, BKB, 4, 1, EPIK>(d, stream);
+    case 6: if constexpr ((size_t)6 * (BM + BN) * BKB + table_bytes<BN>() <= 160 * 1024) return launch_conv_impl<T, BM, BN, BKB, 6, 1, EPIK>(d, stream);
+            else return launch_conv_impl<T, BM, BN, BKB, 4, 1, EPIK>(d, stream);
+    default: return launch_conv_impl<T, BM, BN, BKB, 2, 1, EPIK>(d, stream);
     }
 }
 
 // tune word: bits 0..7 K-step bytes (64 | 128), 8..11 ring stages (2 | 3 | 4 | 6), 12..15 pixel tile (0 = 128, 1 = 80, 2 = 160),
 // 24..27 channel tile (0 = by Cout, 1 = 32, 2 = 64, 3 = 128); bits 16..23 are analysis switches
-template <typename T, int BN>
+template <typename T, int BN, int EPIK = 0>
 int dispatch_conv_bn(const DykConvDesc* d, hipStream_t stream) {
     const int row_bytes = d->Cin * (int)sizeof(T);
     if ((row_bytes % 64) != 0) return DYK_ERR_ARG;
@@ -1218,13 +1234,13 @@ int dispatch_conv_bn(const DykConvDesc* d, hipStream_t stream) {
     if (bm_code >= 1 && bm_code <= 3) bm = 16 << bm_code;
     if constexpr (BN == 80) { if (bm == 32) bm = 64; }          // a wave needs 16 channel rows
     if (k128) {
-        if (bm == 128) return launch_conv<T, 128, BN, 128>(d, stream);
-        if (bm == 64) return launch_conv<T, 64, BN, 128>(d, stream);
-        if constexpr (BN != 80) return launch_conv<T, 32, BN, 128>(d, stream);
+        if (bm == 128) return launch_conv<T, 128, BN, 128, EPIK>(d, stream);
+        if (bm == 64) return launch_conv<T, 64, BN, 128, EPIK>(d, stream);
+        if constexpr (BN != 80) return launch_conv<T, 32, BN, 128, EPIK>(d, stream);
     }
-    if (bm == 128) return launch_conv<T, 128, BN, 64>(d, stream);
-    if (bm == 64) return launch_conv<T, 64, BN, 64>(d, stream);
-    if constexpr (BN != 80) return launch_conv<T, 32, BN, 64>(d, stream);
+    if (bm == 128) return launch_conv<T, 128, BN, 64, EPIK>(d, stream);
+    if (bm == 64) return launch_conv<T, 64, BN, 64, EPIK>(d, stream);
+    if constexpr (BN != 80) return launch_conv<T, 32, BN, 64, EPIK>(d, stream);
     return DYK_ERR_UNSUPPORTED;
 }
 

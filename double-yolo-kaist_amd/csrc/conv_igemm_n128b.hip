@@ -1,0 +1,7 @@
+// 128-pixel tile, bf16, fused BatchNorm-backward epilogues (DYK_EPI_BNBWD)
+#include "conv_igemm_kernel.h"
+
+int dyk_conv_launch_n128b(const DykConvDesc* d, hipStream_t s) {
+    if (d->dtype == DYK_BF16) return dispatch_conv_bn<bf16_t, 128, 1>(d, s);
+    return DYK_ERR_UNSUPPORTED;
+}
