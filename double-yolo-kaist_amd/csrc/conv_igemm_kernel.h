@@ -329,7 +329,9 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
                 // this epilogue a chain of nchunk/256 dependent HBM latencies (dgrad 128->128 @64x80: 60 us against 39 us
                 // for the forward conv of the same GEMM).  Addresses of dead chunks are clamped, their values ignored.
                 constexpr int NIT = (nchunk + 255) / 256;
-                constexpr int UB = (NIT % 2 == 0) ? 2 : 1;     // (5 or 4 loads per batch spill 400 bytes per lane into scratch)
+                // (round 3: batches of 5 / 4 / 3 loads, possible without spills now that this epilogue has its own kernels, measured
+                // WORSE than two: 1x1 256->256 @32x40 chain mode 340 -> 371 us per 16 launches, +0.2 ms over all data gradients)
+                constexpr int UB = (NIT % 2 == 0) ? 2 : 1;
                 auto batched = [&](auto chain_tag) {
                     constexpr bool CH = decltype(chain_tag)::value;
                     for (int j0 = 0; j0 < NIT; j0 += UB) {

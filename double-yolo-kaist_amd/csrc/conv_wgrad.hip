@@ -476,7 +476,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_mt_kernel(const WgArgs args, c
     const int tn = bid % tiles_n;
     const int sp = bid / tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int SPR = a.Wo / KW;                                 // segments per output row
+    const int SPR = (a.Wo + KW - 1) / KW;                      // segments per output row (the last one may be ragged: its
+                                                               // missing dy rows come from the zero page and contribute 0)
     const int nseg = a.B * a.Ho * SPR;
     const int g_begin = sp * chunk;
     const int g_end = min(nseg, g_begin + chunk);
@@ -555,7 +556,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_mt_kernel(const WgArgs args, c
             const long nbase = ((long)b * a.Ho + yo) * a.Wo + xo0;
 #pragma unroll
             for (int j = 0; j < NIA_W; ++j) {
-                const T* src = a_ch[j] < a.Cout ? dyg + (nbase + a_row[j]) * a.lddy + a_ch[j] : zero;
+                const bool ok = (a_ch[j] < a.Cout) & (xo0 + a_row[j] < a.Wo);
+                const T* src = ok ? dyg + (nbase + a_row[j]) * a.lddy + a_ch[j] : zero;
                 wg_glds16(src, wg_lds_addr(da + (j * 4 + wv) * 1024));
             }
 #pragma unroll
@@ -607,7 +609,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_mt_kernel(const WgArgs args, c
 // vectors, plain [tap][Cout][Cin] gradient rows
 bool mt_eligible(const DykWgradDesc* d) {
     if (d->dtype != DYK_BF16 || d->ntaps != 9 || d->isy != d->isx || (d->isy != 1 && d->isy != 2)) return false;
-    if (d->Wo % 32 || d->Cin % 8 || d->Cout % 8 || (d->lddw > 0 && d->lddw != d->Cin)) return false;
+    // (Wo need not be a multiple of the 32-pixel segment: ragged last segments are zero filled -- 80-, 40- and 20-pixel rows
+    // of the deep stages waste 17 / 37 / 37 % of the MFMA work of a row but stage dy and x once for all nine taps)
+    static const bool ragged = !(getenv("DYK_MT_RAGGED") && getenv("DYK_MT_RAGGED")[0] == '0');     // (A/B switch)
+    if (d->Wo < 16 || (!ragged && d->Wo % 32) || d->Cin % 8 || d->Cout % 8 || (d->lddw > 0 && d->lddw != d->Cin)) return false;
     for (int t = 0; t < 9; ++t)
         if (d->tdy[t] != t / 3 - 1 || d->tdx[t] != t % 3 - 1) return false;
     return true;
@@ -626,7 +631,7 @@ int launch_wgrad_mt(const DykWgradDesc* d, hipStream_t stream, int* query) {
         attr_set = true;
     }
     const int tiles = dyk_div_up(d->Cout, 64) * dyk_div_up(d->Cin, BN);
-    const int nseg = d->B * d->Ho * (d->Wo / KW);
+    const int nseg = d->B * d->Ho * ((d->Wo + KW - 1) / KW);
     int splits = d->splits;
     if (splits <= 0) {
         splits = dyk_div_up(512, tiles);
