@@ -796,6 +796,12 @@ void conv_igemm_kernel(const ConvArgs args) {
             b_y0[j] = live ? t_y[row] : -20000; b_x0[j] = live ? t_x[row] : -20000;
         }
         const T* zero = (const T*)dyk_zero_page;
+        // Image extents in SGPRs for the whole loop.  Read through `a` inside the loop they were RE-LOADED from the kernel
+        // arguments (s_load_dword + s_waitcnt lgkmcnt(0)) in front of every activation-row DMA -- the LDS-DMA asm statements
+        // clobber "memory", so the compiler does not keep descriptor fields across them -- and the short-circuit && of the
+        // in-image test became two exec-mask branches per DMA (ISA of the 128 x 160 tile: 6 scalar loads, 5 branches and 17
+        // waits around the 9 DMA instructions of a K step).
+        const unsigned Hi_u = (unsigned)__builtin_amdgcn_readfirstlane(a.Hi), Wi_u = (unsigned)__builtin_amdgcn_readfirstlane(a.Wi);
         auto stage = [&](int buf, int c0, int t) {
             const int toff = tap_x[t] + c0;
             const int tdy_t = tap_dy[t], tdx_t = tap_dx[t];
@@ -818,7 +824,7 @@ void conv_igemm_kernel(const ConvArgs args) {
                 const int inst = j * 4 + wv;
                 // in-image test of this row under tap t: five VALU ops in the shadow of the step's MFMAs (a per-row tap
                 // bitmask built in the prologue cost ~400 exposed instructions per workgroup on a 3x3 conv)
-                const bool ok = ((unsigned)(b_y0[j] + tdy_t) < (unsigned)a.Hi) && ((unsigned)(b_x0[j] + tdx_t) < (unsigned)a.Wi);
+                const bool ok = ((unsigned)(b_y0[j] + tdy_t) < Hi_u) & ((unsigned)(b_x0[j] + tdx_t) < Wi_u);
                 const T* src = ok ? xg + (long)b_off[j] + toff : zero;
                 glds16(src, lds_addr_of((NI_B % 4 == 0 || inst < NI_B) ? db + inst * 1024 : sink));
             }

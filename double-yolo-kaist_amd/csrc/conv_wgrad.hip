@@ -222,8 +222,15 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgArgs args,
             b_img[j] = b; b_yo[j] = r / a.Wo; b_xo[j] = r - b_yo[j] * a.Wo;
         }
         int sp0 = p_begin;                       // first pixel of the next step to stage
-        const int adv_q = ROWS / a.Wo, adv_r = ROWS - adv_q * a.Wo;
-        const bool adv_fast = adv_q + 1 <= 2 * a.Ho;
+        // descriptor scalars in SGPRs for the whole loop: read through `a` they are re-loaded from the kernel arguments behind
+        // every LDS-DMA statement (its "memory" clobber), with a wait each, and the address selects turn into exec-mask branches
+        const int Cout_s = __builtin_amdgcn_readfirstlane(a.Cout), Cin_s = __builtin_amdgcn_readfirstlane(a.Cin);
+        const int lddy_s = __builtin_amdgcn_readfirstlane(a.lddy), ldx_s = __builtin_amdgcn_readfirstlane(a.ldx);
+        const int isy_s = __builtin_amdgcn_readfirstlane(a.isy), isx_s = __builtin_amdgcn_readfirstlane(a.isx);
+        const int Hi_s = __builtin_amdgcn_readfirstlane(a.Hi), Wi_s = __builtin_amdgcn_readfirstlane(a.Wi);
+        const int Ho_s = __builtin_amdgcn_readfirstlane(a.Ho), Wo_s = __builtin_amdgcn_readfirstlane(a.Wo);
+        const int adv_q = ROWS / Wo_s, adv_r = ROWS - adv_q * Wo_s;
+        const bool adv_fast = adv_q + 1 <= 2 * Ho_s;
         auto stage_next = [&](int buf) {
             char* da = sA + buf * A_BYTES;
             char* db = sB + buf * B_BYTES;
@@ -231,17 +238,19 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgArgs args,
             for (int j = 0; j < NIA_W; ++j) {
                 const int n = sp0 + a_row[j];
                 const int c = m0 + a_ch[j];
-                const bool ok = (n < p_end) & (c < a.Cout);         // (& not &&: straight-line address selects, no exec-mask branches)
-                const T* src = ok ? dyg + (long)n * a.lddy + c : zero;
+                const bool ok = (n < p_end) & (c < Cout_s);          // (& not &&: straight-line address selects, no exec-mask branches)
+                const T* cand = dyg + (long)n * lddy_s + c;
+                const T* src = ok ? cand : zero;
                 wg_glds16(src, wg_lds_addr(da + (j * 4 + wv) * 1024));
             }
 #pragma unroll
             for (int j = 0; j < NIB_W; ++j) {
                 const int n = sp0 + b_row[j];
                 const int c = n0 + b_ch[j];
-                const int yi = b_yo[j] * a.isy + tdy, xi = b_xo[j] * a.isx + tdx;
-                const bool ok = (n < p_end) & (c < a.Cin) & ((unsigned)yi < (unsigned)a.Hi) & ((unsigned)xi < (unsigned)a.Wi);
-                const T* src = ok ? xg + ((long)(b_img[j] * a.Hi + yi) * a.Wi + xi) * a.ldx + c : zero;
+                const int yi = b_yo[j] * isy_s + tdy, xi = b_xo[j] * isx_s + tdx;
+                const bool ok = (n < p_end) & (c < Cin_s) & ((unsigned)yi < (unsigned)Hi_s) & ((unsigned)xi < (unsigned)Wi_s);
+                const T* cand = xg + ((long)(b_img[j] * Hi_s + yi) * Wi_s + xi) * ldx_s + c;
+                const T* src = ok ? cand : zero;
                 wg_glds16(src, wg_lds_addr(db + (j * 4 + wv) * 1024));
             }
             // advance the per-lane (image, row, column) by ROWS pixels.  Straight-line code on every real map (two
@@ -251,20 +260,20 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgArgs args,
 #pragma unroll
                 for (int j = 0; j < NIB_W; ++j) {
                     int xo = b_xo[j] + adv_r, yo = b_yo[j] + adv_q, bb = b_img[j];
-                    const bool cx = xo >= a.Wo;
-                    xo -= cx ? a.Wo : 0; yo += cx ? 1 : 0;
-                    const bool c1 = yo >= a.Ho;
-                    yo -= c1 ? a.Ho : 0; bb += c1 ? 1 : 0;
-                    const bool c2 = yo >= a.Ho;
-                    yo -= c2 ? a.Ho : 0; bb += c2 ? 1 : 0;
+                    const bool cx = xo >= Wo_s;
+                    xo -= cx ? Wo_s : 0; yo += cx ? 1 : 0;
+                    const bool c1 = yo >= Ho_s;
+                    yo -= c1 ? Ho_s : 0; bb += c1 ? 1 : 0;
+                    const bool c2 = yo >= Ho_s;
+                    yo -= c2 ? Ho_s : 0; bb += c2 ? 1 : 0;
                     b_xo[j] = xo; b_yo[j] = yo; b_img[j] = bb;
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < NIB_W; ++j) {
                     int xo = b_xo[j] + ROWS, yo = b_yo[j], bb = b_img[j];
-                    while (xo >= a.Wo) { xo -= a.Wo; ++yo; }
-                    while (yo >= a.Ho) { yo -= a.Ho; ++bb; }
+                    while (xo >= Wo_s) { xo -= Wo_s; ++yo; }
+                    while (yo >= Ho_s) { yo -= Ho_s; ++bb; }
                     b_xo[j] = xo; b_yo[j] = yo; b_img[j] = bb;
                 }
             }
@@ -547,24 +556,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_mt_kernel(const WgArgs args, c
             b_ch[j] = n0 + wg_logical_ch<T, BN>(h, lane % VPR_B);
         }
         int seg = g_begin;
+        const int Cout_s = __builtin_amdgcn_readfirstlane(a.Cout), Cin_s = __builtin_amdgcn_readfirstlane(a.Cin);
+        const int lddy_s = __builtin_amdgcn_readfirstlane(a.lddy), ldx_s = __builtin_amdgcn_readfirstlane(a.ldx);
+        const int Hi_s = __builtin_amdgcn_readfirstlane(a.Hi), Wi_s = __builtin_amdgcn_readfirstlane(a.Wi);
+        const int Ho_s = __builtin_amdgcn_readfirstlane(a.Ho), Wo_s = __builtin_amdgcn_readfirstlane(a.Wo);
+        const int SPR_s = __builtin_amdgcn_readfirstlane(SPR);
         auto stage_next = [&](int buf) {
-            const int b = seg / (a.Ho * SPR);
-            const int r = seg - b * (a.Ho * SPR);
-            const int yo = r / SPR, xo0 = (r - yo * SPR) * KW;
+            const int b = seg / (Ho_s * SPR_s);
+            const int r = seg - b * (Ho_s * SPR_s);
+            const int yo = r / SPR_s, xo0 = (r - yo * SPR_s) * KW;
             char* da = sA + buf * A_BYTES;
             char* db = sB + buf * B_BYTES;
-            const long nbase = ((long)b * a.Ho + yo) * a.Wo + xo0;
+            const long nbase = ((long)b * Ho_s + yo) * Wo_s + xo0;
 #pragma unroll
             for (int j = 0; j < NIA_W; ++j) {
-                const bool ok = (a_ch[j] < a.Cout) & (xo0 + a_row[j] < a.Wo);
-                const T* src = ok ? dyg + (nbase + a_row[j]) * a.lddy + a_ch[j] : zero;
+                const bool ok = (a_ch[j] < Cout_s) & (xo0 + a_row[j] < Wo_s);
+                const T* cand = dyg + (nbase + a_row[j]) * lddy_s + a_ch[j];
+                const T* src = ok ? cand : zero;
                 wg_glds16(src, wg_lds_addr(da + (j * 4 + wv) * 1024));
             }
 #pragma unroll
             for (int j = 0; j < NIB_W; ++j) {
                 const int yi = yo * SI + b_rr[j] - 1, xi = xo0 * SI + b_jj[j] - 1;
-                const bool ok = (b_ch[j] < a.Cin) & ((unsigned)yi < (unsigned)a.Hi) & ((unsigned)xi < (unsigned)a.Wi);
-                const T* src = ok ? xg + ((long)(b * a.Hi + yi) * a.Wi + xi) * a.ldx + b_ch[j] : zero;
+                const bool ok = (b_ch[j] < Cin_s) & ((unsigned)yi < (unsigned)Hi_s) & ((unsigned)xi < (unsigned)Wi_s);
+                const T* cand = xg + ((long)(b * Hi_s + yi) * Wi_s + xi) * ldx_s + b_ch[j];
+                const T* src = ok ? cand : zero;
                 wg_glds16(src, wg_lds_addr(db + (j * 4 + wv) * 1024));
             }
             ++seg;

@@ -17,16 +17,17 @@ python bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --dump-cmds gp
 python tools/cmd_roofline.py gpurun_out/cmds_b1.json > gpurun_out/cmd_roofline_b1.txt 2>&1
 rm -f gpurun_out/cmds_c3.json gpurun_out/cmds_c5.json gpurun_out/cmds_b1.json
 rm -rf gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write && mkdir -p gpurun_out/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r2 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/prof/bench_under_prof.json 2> gpurun_out/prof/err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r3 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/prof/bench_under_prof.json 2> gpurun_out/prof/err.log
 # counters in their own runs, one pass per counter (TCC slots), kernel trace only
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_write.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_summary.json > gpurun_out/pmc_summary.txt 2>&1
+bash tools/run_pmc_sq.sh > gpurun_out/pmc_sq_run.log 2>&1
 cat gpurun_out/pmc_summary.txt
 # one step's kernels by family (durations as they ran in the step, autotune trials excluded) and per-stream occupancy
-python tools/step_kernel_summary.py gpurun_out/prof/*/r2_kernel_trace.csv gpurun_out/step_kernels.json > gpurun_out/step_kernels.txt 2>&1 || python tools/step_kernel_summary.py gpurun_out/prof/r2_kernel_trace.csv gpurun_out/step_kernels.json > gpurun_out/step_kernels.txt 2>&1
+python tools/step_kernel_summary.py gpurun_out/prof/*/r3_kernel_trace.csv gpurun_out/step_kernels.json > gpurun_out/step_kernels.txt 2>&1 || python tools/step_kernel_summary.py gpurun_out/prof/r3_kernel_trace.csv gpurun_out/step_kernels.json > gpurun_out/step_kernels.txt 2>&1
 head -20 gpurun_out/step_kernels.txt
-python tools/trace_timeline.py $(ls gpurun_out/prof/r2_kernel_trace.csv gpurun_out/prof/*/r2_kernel_trace.csv 2>/dev/null | head -1) > gpurun_out/step_timeline.txt 2>&1
+python tools/trace_timeline.py $(ls gpurun_out/prof/r3_kernel_trace.csv gpurun_out/prof/*/r3_kernel_trace.csv 2>/dev/null | head -1) > gpurun_out/step_timeline.txt 2>&1
 # keep the merge small: drop the per-dispatch traces
 find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*kernel_trace.csv" -delete
 find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*counter_collection.csv" -size +20M -delete
