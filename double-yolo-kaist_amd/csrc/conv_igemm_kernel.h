@@ -631,10 +631,20 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&ac
 //       holds two 4-wave groups that walk the two halves of the input channels with private LDS rings (same barriers);
 //       group 1 hands its accumulators to group 0 through LDS before the epilogue -- twice the waves per CU without a
 //       split-K pass through memory.  2-stage ring only.
-// (the 128 x 160 tile with the BatchNorm-backward epilogue needs more than the 168 VGPRs of three waves per SIMD: 72-209
-// spilled registers; its LDS footprint allows two workgroups per CU for most configurations anyway)
+// Waves per SIMD the kernel is compiled for (= its VGPR budget: 168 at three, 256 at two).  Three wherever the LDS footprint
+// lets three 4-wave workgroups share a CU; two where LDS allows two workgroups anyway -- there the 168-register cap only
+// cost: the ISA of the 128 x 160 / 128-byte-K-step tile re-used ONE register quad for the four weight fragments of the
+// second half step (ds_read -> s_waitcnt lgkmcnt(0) -> 5 MFMAs, four times per K step: four exposed LDS latencies).  The
+// 128 x 160 tile with the BatchNorm-backward epilogue needs the larger budget in any case (72-209 spilled registers at 168).
+template <typename T, int BM, int BN, int BKB, int PIPE, int KG, int EPIK>
+constexpr int conv_waves_per_eu() {
+    constexpr size_t ring = (size_t)KG * PIPE * (BM + BN) * BKB;
+    constexpr size_t sc = (size_t)BN * (BM * sizeof(T) + 16);
+    constexpr size_t lds = table_bytes<BN>() + (ring > sc ? ring : sc);
+    return (EPIK == 1 && BM * BN >= 128 * 160) || 3 * lds > 160 * 1024 ? 2 : 3;
+}
 template <typename T, int BM, int BN, int BKB, int PIPE, int KG = 1, int EPIK = 0>
-__global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(EPIK == 1 && BM * BN >= 128 * 160 ? 2 : 3)))
+__global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_waves_per_eu(conv_waves_per_eu<T, BM, BN, BKB, PIPE, KG, EPIK>(), conv_waves_per_eu<T, BM, BN, BKB, PIPE, KG, EPIK>())))
 void conv_igemm_kernel(const ConvArgs args) {
     static_assert(KG == 1 || PIPE == 2, "K-groups use the 2-stage ring");
     int blk, nblk;
@@ -745,6 +755,34 @@ void conv_igemm_kernel(const ConvArgs args) {
     // global_load_lds instruction are then spent while the LDS reads are in flight / the matrix pipe drains, instead
     // of in front of the step with nothing else going on in the wave.
     auto compute = [&](const char* pa, const char* pb, auto&& mid) {
+        if constexpr (KK == 2 && conv_waves_per_eu<T, BM, BN, BKB, PIPE, KG, EPIK>() == 2) {
+            // 128-byte K step with the 256-register budget: the fragments of BOTH half steps are requested before the first
+            // MFMA (round 3: the compiler had re-used one register quad for the weight fragments of the second half step --
+            // ds_read, full wait, five MFMAs, four times per K step)
+            uint4 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) fa0[mi] = *(const uint4*)(pa + lds_off<BKB>(wm * WTM + mi * 16 + frow, fslot));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) fb0[ni] = *(const uint4*)(pb + lds_off<BKB>(wn * WTN + ni * 16 + frow, fslot));
+            mid();
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) fa1[mi] = *(const uint4*)(pa + lds_off<BKB>(wm * WTM + mi * 16 + frow, 4 + fslot));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) fb1[ni] = *(const uint4*)(pb + lds_off<BKB>(wn * WTN + ni * 16 + frow, 4 + fslot));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], fa0[mi], fb0[ni]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], fa1[mi], fb1[ni]);
+            // nothing may sink below this point: the loop's `s_waitcnt vmcnt(..)` follows, and an MFMA block scheduled behind it
+            // would wait for the NEXT step's DMA before computing this one (seen in the ISA without the fence)
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             uint4 fa[MI], fb[NI];
@@ -760,6 +798,9 @@ void conv_igemm_kernel(const ConvArgs args) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], fa[mi], fb[ni]);
         }
+        // (see above: without the fence the compiler sinks the MFMA block below the loop's `s_waitcnt vmcnt(0)` -- ISA of the
+        // 64-byte-K-step tiles: 19 of the 20 MFMAs of a step waited for the NEXT step's DMA)
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     {
@@ -802,21 +843,22 @@ void conv_igemm_kernel(const ConvArgs args) {
         // in-image test became two exec-mask branches per DMA (ISA of the 128 x 160 tile: 6 scalar loads, 5 branches and 17
         // waits around the 9 DMA instructions of a K step).
         const unsigned Hi_u = (unsigned)__builtin_amdgcn_readfirstlane(a.Hi), Wi_u = (unsigned)__builtin_amdgcn_readfirstlane(a.Wi);
+        const unsigned sA_u = lds_addr_of(sA), sB_u = lds_addr_of(sB), sink_u = lds_addr_of(sink);
         auto stage = [&](int buf, int c0, int t) {
             const int toff = tap_x[t] + c0;
             const int tdy_t = tap_dy[t], tdx_t = tap_dx[t];
             const long wbase = (long)tap_w[t] + c0;
-            char* da = sA + buf * A_BYTES;
-            char* db = sB + buf * B_BYTES;
+            // (LDS destinations as plain integers: a generic -> LDS pointer cast per DMA costs a null check, 4 SALU instructions)
+            const unsigned da = sA_u + buf * A_BYTES, db = sB_u + buf * B_BYTES;
 #pragma unroll
             for (int j = 0; j < NIA_W; ++j) {
                 const int inst = j * 4 + wv;
                 if (NI_A % 4 == 0 || inst < NI_A) {
                     const T* src = a_ok[j] ? wg + wbase + a_off[j] : zero;
-                    glds16(src, lds_addr_of(da + inst * 1024));
+                    glds16(src, da + inst * 1024);
                 } else {
                     // keep the per-wave DMA count uniform so that one counted vmcnt fits all waves
-                    glds16(zero, lds_addr_of(sink));
+                    glds16(zero, sink_u);
                 }
             }
 #pragma unroll
@@ -826,7 +868,7 @@ void conv_igemm_kernel(const ConvArgs args) {
                 // bitmask built in the prologue cost ~400 exposed instructions per workgroup on a 3x3 conv)
                 const bool ok = ((unsigned)(b_y0[j] + tdy_t) < Hi_u) & ((unsigned)(b_x0[j] + tdx_t) < Wi_u);
                 const T* src = ok ? xg + (long)b_off[j] + toff : zero;
-                glds16(src, lds_addr_of((NI_B % 4 == 0 || inst < NI_B) ? db + inst * 1024 : sink));
+                glds16(src, (NI_B % 4 == 0 || inst < NI_B) ? db + inst * 1024 : sink_u);
             }
         };
         // staging iterator (runs two steps ahead of the compute iterator)
@@ -1061,6 +1103,7 @@ void conv_halo_kernel(const ConvArgs args) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], fa[mi], fb[ni]);
         }
+        __builtin_amdgcn_sched_barrier(0);     // (the MFMA block must not sink below the loop's s_waitcnt vmcnt: see conv_igemm_kernel)
     };
 
     // prologue: whole halo tile of chunk 0, weight tiles of steps 0 and 1

@@ -135,7 +135,10 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgArgs args,
     const int p_begin = sp * chunk + grp * gchunk;
     const int p_end = min(Ntot, p_begin + gchunk);
     if (KG == 1 && p_begin >= p_end && !a.part) return;      // (with `part` every launched split owns a plane and writes it)
-    const int tdy = a.tdy[tap], tdx = a.tdx[tap];
+    // (readfirstlane: the tap offsets come out of a dynamically indexed kernel-argument array, i.e. a VECTOR load; consumed
+    // for the first time inside the K loop, that load made the compiler wait vmcnt(0) -- for every LDS-DMA in flight -- in
+    // the middle of each step's staging block: the dy tile's DMAs were drained before the x tile's were issued)
+    const int tdy = __builtin_amdgcn_readfirstlane((int)a.tdy[tap]), tdx = __builtin_amdgcn_readfirstlane((int)a.tdx[tap]);
     const T* __restrict__ dyg = (const T*)a.dy;
     const T* __restrict__ xg = (const T*)a.x;
 
@@ -193,6 +196,9 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgArgs args,
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
             }
         }
+        // the MFMA block must not sink below the loop's `s_waitcnt vmcnt(..)`: it would wait for the NEXT step's DMA before
+        // computing this one (found in the ISA of the convolution kernels, round 3)
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // bits 16.. of `tune`: ablation switches for kernel analysis (tools/gpu_probe.py wgablate), never set by the plan
@@ -536,6 +542,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mt_kernel(const WgArgs args, c
                             __builtin_bit_cast(bf16x8_t, fa[mi]), __builtin_bit_cast(bf16x8_t, fb[ni]), acc[t][mi][ni], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     {
