@@ -69,6 +69,13 @@ template <int BKB> __device__ inline int lds_off(int row, int slot) {
     return row * 64 + ((slot ^ (((row >> 3) & 1) * 3)) << 4);
 }
 
+// a wave-uniform pointer pinned in SGPRs (two v_readfirstlane): the compiler cannot re-materialise it by re-loading the kernel argument
+template <typename P> __device__ inline P* sgpr_ptr(P* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (P*)(((unsigned long long)hi << 32) | lo);
+}
+
 // all-zero source for padding taps / ragged rows of the LDS-DMA path
 __device__ uint4 dyk_zero_page[8];
 
@@ -107,8 +114,20 @@ template <int BN> constexpr int table_bytes() { return BN * (3 * 4 + 2 * 2) + 10
 // one kernel the 128 x 160 tile spilled 320-350 VGPRs (272-332 bytes of scratch per lane, also paid by the forward launches:
 // +0.4 ms per step over all forward convolutions when the LDS-DMA form of the BatchNorm-backward epilogue was added).
 template <typename T, int BM, int BN, int EPIK = 0>
-__device__ __forceinline__ void conv_epilogue(const DykConvDesc& a, f32x4_t (&acc)[(BM / WaveGrid<BM, BN>::WM) / 16][(BN / WaveGrid<BM, BN>::WN) / 16],
+__device__ __forceinline__ void conv_epilogue(const DykConvDesc& desc, f32x4_t (&acc)[(BM / WaveGrid<BM, BN>::WM) / 16][(BN / WaveGrid<BM, BN>::WN) / 16],
                                               char* sC, float* s_stat, const int* t_out, const int* t_res, int m0, int blk) {
+    // The descriptor fields this epilogue uses, in SGPRs: read through the kernel-argument reference they are re-loaded
+    // (s_load + s_waitcnt lgkmcnt(0)) behind every barrier / LDS-DMA statement -- 34 scalar loads in the staged store loop of
+    // the 128 x 160 tile (ISA, round 3).
+    struct {
+        void* y; const void* res; const void* add; double* stats; const float* scale; const float* shift; const float* aux0; const float* aux1;
+        int Cout, act, flags, stats_slots, tune;
+    } a;
+    a.y = sgpr_ptr(desc.y); a.res = sgpr_ptr(desc.res); a.add = sgpr_ptr(desc.add); a.stats = sgpr_ptr(desc.stats);
+    a.scale = sgpr_ptr(desc.scale); a.shift = sgpr_ptr(desc.shift); a.aux0 = sgpr_ptr(desc.aux0); a.aux1 = sgpr_ptr(desc.aux1);
+    a.Cout = __builtin_amdgcn_readfirstlane(desc.Cout); a.act = __builtin_amdgcn_readfirstlane(desc.act);
+    a.flags = __builtin_amdgcn_readfirstlane(desc.flags); a.stats_slots = __builtin_amdgcn_readfirstlane(desc.stats_slots);
+    a.tune = __builtin_amdgcn_readfirstlane(desc.tune);
     constexpr int WM = WaveGrid<BM, BN>::WM, WN = WaveGrid<BM, BN>::WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = WTM / 16, NI = WTN / 16;
@@ -738,8 +757,8 @@ void conv_igemm_kernel(const ConvArgs args) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    const T* __restrict__ xg = (const T*)a.x;
-    const T* __restrict__ wg = (const T*)a.w;
+    const T* __restrict__ xg = sgpr_ptr((const T*)a.x);
+    const T* __restrict__ wg = sgpr_ptr((const T*)a.w);
     // bits 16.. of `tune` are ablation switches for kernel analysis (tools/gpu_probe.py ablate): never set by the plan
     const bool abl_nostore = (a.tune >> 16) & 1, abl_noloop = (a.tune >> 17) & 1;
     const bool abl_nobar = (a.tune >> 22) & 1;      // analysis: K loop without its workgroup barrier (WRONG results: timing only)

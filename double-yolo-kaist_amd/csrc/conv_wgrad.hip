@@ -47,6 +47,13 @@ inline unsigned wg_fill_args(WgArgs& args, const DykWgradDesc* d, int blocks) {
     return 2u * (unsigned)args.pair_blocks;
 }
 
+// a wave-uniform pointer pinned in SGPRs (the compiler cannot re-materialise it by re-loading the kernel argument in the loop)
+template <typename P> __device__ inline P* wg_sgpr_ptr(P* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (P*)(((unsigned long long)hi << 32) | lo);
+}
+
 typedef short v4i16_t __attribute__((__vector_size__(4 * sizeof(short))));
 #define LDS_AS __attribute__((address_space(3)))
 
@@ -139,8 +146,8 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgArgs args,
     // for the first time inside the K loop, that load made the compiler wait vmcnt(0) -- for every LDS-DMA in flight -- in
     // the middle of each step's staging block: the dy tile's DMAs were drained before the x tile's were issued)
     const int tdy = __builtin_amdgcn_readfirstlane((int)a.tdy[tap]), tdx = __builtin_amdgcn_readfirstlane((int)a.tdx[tap]);
-    const T* __restrict__ dyg = (const T*)a.dy;
-    const T* __restrict__ xg = (const T*)a.x;
+    const T* __restrict__ dyg = wg_sgpr_ptr((const T*)a.dy);
+    const T* __restrict__ xg = wg_sgpr_ptr((const T*)a.x);
 
     f32x4_t acc[MI][NI];
 #pragma unroll
@@ -497,8 +504,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_mt_kernel(const WgArgs args, c
     const int g_begin = sp * chunk;
     const int g_end = min(nseg, g_begin + chunk);
     const int S = g_end > g_begin ? g_end - g_begin : 0;
-    const T* __restrict__ dyg = (const T*)a.dy;
-    const T* __restrict__ xg = (const T*)a.x;
+    const T* __restrict__ dyg = wg_sgpr_ptr((const T*)a.dy);
+    const T* __restrict__ xg = wg_sgpr_ptr((const T*)a.x);
 
     f32x4_t acc[9][MI][NI];
 #pragma unroll
