@@ -29,6 +29,11 @@ namespace {
 struct ConvArgs {
     DykConvDesc d[2];
     int pair_tiles;
+    // Tap table in closed form, detected by the launcher: tdy[q] = a0 + sy * (q / kw), tdx[q] = b0 + sx * (q % kw),
+    // twt[q] = w0 + q -- every forward k x k table (ops.fwd_taps) and the data gradient of a stride-1 conv.  The kernel
+    // then BUILDS its LDS tap tables instead of loading the byte arrays of the descriptor: indexed by the lane those came
+    // through vector memory, a ~1 us round trip in front of every workgroup's first barrier (kw = 0: generic table, loaded).
+    int aff_kw, aff_a0, aff_sy, aff_b0, aff_sx, aff_w0;
 };
 
 // workgroup -> (problem, block id within the problem, blocks per problem)
@@ -743,10 +748,16 @@ void conv_igemm_kernel(const ConvArgs args) {
     }
     if (tid_all >= 256 - 32 && tid_all < 256 - 32 + ntaps) {   // tap tables in LDS: no vector-memory loads inside the K loop
         const int q = tid - (256 - 32);
-        const int dy = a.tdy[tap0 + q], dx = a.tdx[tap0 + q];
+        int dy, dx, wt;
+        if (args.aff_kw > 0 && a.ncls <= 1) {       // closed form (see ConvArgs): no memory round trip before the first barrier
+            const int r = q / args.aff_kw, c = q - r * args.aff_kw;
+            dy = args.aff_a0 + args.aff_sy * r; dx = args.aff_b0 + args.aff_sx * c; wt = args.aff_w0 + q;
+        } else {
+            dy = a.tdy[tap0 + q]; dx = a.tdx[tap0 + q]; wt = a.twt[tap0 + q];
+        }
         tap_dy[q] = dy; tap_dx[q] = dx;
         tap_x[q] = (dy * a.Wi + dx) * a.ldx;
-        tap_w[q] = a.twt[tap0 + q] * a.Cout * a.Cin;
+        tap_w[q] = wt * a.Cout * a.Cin;
     }
     __syncthreads();
     if ((a.tune >> 19) & 1) return;            // ablation: tables only
@@ -1032,8 +1043,15 @@ void conv_halo_kernel(const ConvArgs args) {
     }
     if (tid >= 256 - 32 && tid < 256 - 32 + a.ntaps) {
         const int q = tid - (256 - 32);
-        tap_h[q] = a.tdy[q] * HW + a.tdx[q];
-        tap_w[q] = a.twt[q] * a.Cout * a.Cin;
+        int dy, dx, wt;
+        if (args.aff_kw > 0) {
+            const int r = q / args.aff_kw, c = q - r * args.aff_kw;
+            dy = args.aff_a0 + args.aff_sy * r; dx = args.aff_b0 + args.aff_sx * c; wt = args.aff_w0 + q;
+        } else {
+            dy = a.tdy[q]; dx = a.tdx[q]; wt = a.twt[q];
+        }
+        tap_h[q] = dy * HW + dx;
+        tap_w[q] = wt * a.Cout * a.Cin;
     }
     for (int e = tid; e < NB * 64; e += 256) {
         const int q = e >> 6, l = e & 63;
@@ -1160,6 +1178,16 @@ void conv_halo_kernel(const ConvArgs args) {
 // fills the kernel arguments of a single- or two-problem launch; returns the grid size.  `vec`: the staged (16-byte
 // vector) epilogue is possible for every problem of the launch
 inline unsigned conv_fill_args(ConvArgs& args, const DykConvDesc* d, int tiles, bool vec) {
+    args.aff_kw = 0;
+    for (int kw = 1; kw <= 7 && !args.aff_kw && d->ntaps > 0 && d->ncls <= 1; kw += 2) {
+        if (d->ntaps % kw) continue;
+        const int a0 = d->tdy[0], b0 = d->tdx[0], w0 = d->twt[0];
+        const int sy = d->ntaps > kw ? d->tdy[kw] - a0 : 0, sx = kw > 1 ? d->tdx[1] - b0 : 0;
+        bool ok = true;
+        for (int q = 0; q < d->ntaps && ok; ++q)
+            ok = d->tdy[q] == a0 + sy * (q / kw) && d->tdx[q] == b0 + sx * (q % kw) && d->twt[q] == w0 + q;
+        if (ok) { args.aff_kw = kw; args.aff_a0 = a0; args.aff_sy = sy; args.aff_b0 = b0; args.aff_sx = sx; args.aff_w0 = w0; }
+    }
     args.d[0] = *d;
     args.d[0].twin = nullptr;
     args.pair_tiles = 0;

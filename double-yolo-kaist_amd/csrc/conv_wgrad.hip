@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgArgs args,
     if (bid >= tiles_m * tiles_n * a.ntaps * splits) return;     // padding blocks of a two-problem launch
     const int tm = bid % tiles_m; bid /= tiles_m;
     const int tn = bid % tiles_n; bid /= tiles_n;
-    const int tap = bid % a.ntaps;
+    const int tap = __builtin_amdgcn_readfirstlane(bid % a.ntaps);   // (provably uniform: the tap offsets below come by scalar load)
     const int sp = bid / a.ntaps;
     const int m0 = tm * BM, n0 = tn * BN;
     const int HWo = a.Ho * a.Wo;
