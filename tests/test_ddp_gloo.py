@@ -91,3 +91,92 @@ def test_bucketed_gradient_allreduce_two_ranks():
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res), "all-reduced gradient buffer is wrong"
     assert all(r[3] for r in res)
+
+
+def _worker_real_plan(rank, world, port, q):
+    """the REAL backward command list of the dual-stream target cfg (dry plan: resolved descriptors, no kernels): every
+    command's writes into the flat gradient buffer are read off its descriptor (dyk/sched.py access sets) and replayed
+    symbolically -- each write adds (rank + 1) to the bytes it covers -- with the all-reduce of a bucket issued exactly
+    where dyk.ddp enqueues it.  A cut that closes a bucket before its last writer has run leaves a value that is not
+    (number of writers) x sum(rank + 1): caught here without hardware (VERDICT r2 #9)."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "double-yolo-kaist_amd"), os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from build_utils.parse_config import materialize_cfg
+        from dyk import lib as L, sched
+        from dyk.ddp import GradAllReduce
+        from dyk.plan import compile_plan
+        from models import YOLO
+        torch.manual_seed(0)
+        m = YOLO(materialize_cfg("kaist_dyolov4_fshare_global_concat_se3"))
+        eng = m.engine
+        eng.store.adopt(torch.device("cpu"))
+        plan = compile_plan(m, eng.store, 2, 64, 96, torch.bfloat16, True, torch.device("cpu"), dry=True)
+        mem = sched.Memory(plan, eng.store)
+        G = eng.store.G
+        g0 = G.data_ptr()
+        writes = []                                   # per command: [(first float, last float + 1)] inside G
+        for op, d in plan.bwd:
+            _, W, barrier = sched.accesses(op, d, mem, plan)
+            assert not barrier or op == L.OP_MEMSET
+            writes.append([(r.lo // 4, (r.hi + 3) // 4) for r in W if r.key == "G"])
+        nwrites = torch.zeros(eng.store.total)
+        for ws in writes:
+            for lo, hi in ws:
+                nwrites[lo:hi] += 1
+        assert float((nwrites > 0).float().mean()) > 0.99, "every parameter of the net gets a gradient"
+        ok, nseg = True, []
+        for nb, pair in ((0, "0"), (6, "0"), (0, "1")):
+            os.environ["DYK_PAIR"] = pair
+            plan.__dict__.pop("_ddp_segs", None)
+            red = GradAllReduce(m, dist, n_buckets=nb)
+            segs = red.segments(plan)
+            nseg.append(len(segs))
+            assert segs[0][0] == 0 and segs[-1][1] == len(plan.bwd) and segs[0][3] == eng.store.total and segs[-1][2] == 0
+            assert all(a[1] == b[0] and a[2] == b[3] for a, b in zip(segs, segs[1:]))
+            # static form of the check: nobody writes into a bucket after it was handed to the exchange
+            for (c0, c1, lo, hi) in segs:
+                for c in range(c1, len(plan.bwd)):
+                    assert all(w1 <= lo or w0 >= hi for (w0, w1) in writes[c]), (
+                        "command %d (op %d) writes into bucket [%d, %d) closed at command %d" % (c, plan.bwd[c][0], lo, hi, c1))
+            # dynamic form, through the real collective
+            G.zero_()
+            for (c0, c1, lo, hi) in segs:
+                for c in range(c0, c1):
+                    for w0, w1 in writes[c]:
+                        G[w0:w1] += float(rank + 1)
+                red.bucket_ready(lo, hi)
+            red.all_reduce()
+            want = nwrites * float(sum(range(1, world + 1)))
+            ok = ok and bool(torch.equal(G, want))
+            if pair == "1":
+                # two-problem launches: no bucket closes between the backward of a section and that of its twin
+                marks = {cnt: layer for cnt, layer in plan.bwd_marks}
+                for (c0, c1, lo, hi) in segs[:-1]:
+                    done = min(l for cnt, l in plan.bwd_marks if cnt <= c1 and l >= 0) if any(cnt <= c1 for cnt, _ in plan.bwd_marks) else None
+                    for l, t in plan.twin_layer.items():
+                        if l < t and done is not None:
+                            assert not (l < done <= t) or c1 == len(plan.bwd), ("cut inside twin span", l, t, done)
+        q.put((rank, ok, nseg))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_cuts_against_the_real_backward_list_two_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker_real_plan, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res), "a gradient bucket was exchanged before its last writer ran"
+    assert all(2 <= n <= 8 for r in res for n in r[2]), res
