@@ -14,7 +14,7 @@ namespace {
 
 // 32 lanes per channel: lane r sums replicas r, r+32, ... , a 5-step xor-shuffle folds them, lane 0 finalises
 __global__ __launch_bounds__(256) void bn_finalize_kernel(DykFinPair pr) {
-    const DykBnFinalizeDesc& d = pr.d[blockIdx.z];
+    const DykBnFinalizeDesc d = pr.d[blockIdx.z];
     const int sub = threadIdx.x & 31;
     const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (c >= d.C) return;
@@ -62,7 +62,7 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
 // row (whole rows for C <= 256 bf16), i.e. fully coalesced when ld == C.
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwPair pr, int CVB) {
-    const DykEwDesc& d = pr.d[blockIdx.z];
+    const DykEwDesc d = pr.d[blockIdx.z];          // a COPY, not a reference (see DykEwPair in dyk_common.h)
     constexpr int EPV = ElemTraits<T>::EPV;
     const int PY = 256 / CVB;
     const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwPair pr, int CVB) 
 // may still be reading them): the caller zeroes the statistics arena once per forward pass.
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(DykFinPair fp, DykEwPair pr, int CVB) {
-    const DykBnFinalizeDesc& f = fp.d[blockIdx.z];
-    const DykEwDesc& d = pr.d[blockIdx.z];
+    const DykBnFinalizeDesc f = fp.d[blockIdx.z];
+    const DykEwDesc d = pr.d[blockIdx.z];          // a COPY, not a reference (see DykEwPair in dyk_common.h)
     constexpr int EPV = ElemTraits<T>::EPV;
     __shared__ float s_aff[2][256];
     const int PY = 256 / CVB;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(DykFinPair fp, DykEwP
 // block = (CVB channel vectors) x (PY pixel lanes); grid.x over channel-vector groups, grid.y over pixels
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(DykEwPair pr, int CVB) {
-    const DykEwDesc& d = pr.d[blockIdx.z];
+    const DykEwDesc d = pr.d[blockIdx.z];          // a COPY, not a reference (see DykEwPair in dyk_common.h)
     constexpr int EPV = ElemTraits<T>::EPV;
     __shared__ float red[256 * 2 * 8];
     const int PY = 256 / CVB;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void bn_bwd_params_kernel(double* red, float* 
 // dgamma / dbeta (aux / aux2): no separate parameter-gradient launch on the critical chain of the backward pass.
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwPair pr, int CVB) {
-    const DykEwDesc& d = pr.d[blockIdx.z];
+    const DykEwDesc d = pr.d[blockIdx.z];          // a COPY, not a reference (see DykEwPair in dyk_common.h)
     constexpr int EPV = ElemTraits<T>::EPV;
     __shared__ float s_tot[2][256];
     const int PY = 256 / CVB;

@@ -177,6 +177,9 @@ static inline int dyk_div_up(long a, long b) { return (int)((a + b - 1) / b); }
 // Two-problem launches of the elementwise / BatchNorm kernels (DykEwDesc.twin, DykBnFinalizeDesc.twin): the kernel takes
 // both descriptors and blockIdx.z selects the problem.  fill_* return the number of problems (1 | 2), 0 when the twin
 // differs in a non-pointer field.
+// Kernels COPY their descriptor out of the pair (`const DykEwDesc d = pr.d[blockIdx.z];`): through a reference into the
+// kernel arguments every field was re-loaded (s_load + s_waitcnt lgkmcnt(0)) in front of each load and store of the pixel
+// loop -- the BatchNorm passes had become 5 % slower when the two-problem form was introduced (ISA, round 3).
 struct DykEwPair { DykEwDesc d[2]; };
 struct DykFinPair { DykBnFinalizeDesc d[2]; };
 static inline int dyk_fill_ew_pair(DykEwPair& p, const DykEwDesc* d) {

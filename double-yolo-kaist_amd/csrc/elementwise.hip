@@ -15,7 +15,7 @@ inline int epv_of(int dtype) { return dtype == DYK_BF16 ? 8 : 4; }
 // out = sa*a (+ sb*b), sa = alpha * (p0 ? p0[0] : 1), sb = beta * (p1 ? p1[0] : 1)
 template <typename T>
 __global__ __launch_bounds__(256) void axpby_kernel(DykEwPair pr) {
-    const DykEwDesc& d = pr.d[blockIdx.z];
+    const DykEwDesc d = pr.d[blockIdx.z];          // a COPY, not a reference (see DykEwPair in dyk_common.h)
     constexpr int EPV = ElemTraits<T>::EPV;
     const int CV = d.C / EPV;
     const long total = (long)d.npix * CV;
