@@ -271,6 +271,129 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(DykEwDesc d, const uin
     }
 }
 
+// Stride-1 pools on maps that fit LDS (the SPP block: 5 / 9 / 13 windows on the 16 x 20 map, models.py:91-94): one workgroup
+// per (image, 16-byte channel vector) holds its plane of the map in LDS.
+//   forward   separable: row pass (first maximum of each window row and its dx), column pass over the row results.  The
+//             first row that holds the window maximum, and the first dx inside it, IS the first maximum in scan order (and
+//             with NaNs the last NaN, as torch's `val > max || isnan(val)` keeps it): values and argmax codes are those of
+//             the k*k scan above, for 2k instead of k*k loads per output (13 x 13: 43 -> 8 us per launch).
+//   backward  the k*k gather of the kernel above, same (dy, dx) order -- same bits -- from an LDS copy of the gradient and
+//             argmax planes.
+template <typename T>
+__global__ __launch_bounds__(1024) void maxpool_tile_fwd_kernel(DykEwDesc d, uint8_t* __restrict__ idx) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int HW = d.H * d.W, k = d.k, pad = (k - 1) / 2;
+    uint4* tile = (uint4*)smem;                  // [HW] raw values
+    uint4* rmax = tile + HW;                     // [HW] row-window maxima (as T)
+    uint2* radx = (uint2*)(rmax + HW);           // [HW] dx of the row maximum, one byte per element
+    const int CV = d.C / EPV;
+    const int b = blockIdx.x / CV, c = (blockIdx.x % CV) * EPV;
+    const T* __restrict__ a = (const T*)d.a + (long)b * HW * d.lda + c;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) tile[p] = *(const uint4*)(a + (long)p * d.lda);
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        const int y = p / d.W, x = p - y * d.W;
+        float m[EPV]; uint32_t mi[EPV];
+        bool first = true;
+        for (int dx = 0; dx < k; ++dx) {
+            const int xx = x + dx - pad;
+            if (xx < 0 || xx >= d.W) continue;
+            float t[EPV];
+            vec_unpack<T>(tile[y * d.W + xx], t);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j)
+                if (first || t[j] > m[j] || t[j] != t[j]) { m[j] = t[j]; mi[j] = (uint32_t)dx; }
+            first = false;
+        }
+        rmax[p] = vec_pack<T>(m);                // (exact: the maxima are elements of the tile)
+        uint2 pk = make_uint2(0u, 0u);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            if (j < 4) pk.x |= mi[j] << (8 * j); else pk.y |= mi[j] << (8 * (j - 4));
+        }
+        radx[p] = pk;
+    }
+    __syncthreads();
+    T* __restrict__ o = (T*)d.out + (long)b * HW * d.ldo + c;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        const int y = p / d.W, x = p - y * d.W;
+        float m[EPV]; uint32_t mi[EPV];
+        bool first = true;
+        for (int dy = 0; dy < k; ++dy) {
+            const int yy = y + dy - pad;
+            if (yy < 0 || yy >= d.H) continue;
+            float t[EPV];
+            vec_unpack<T>(rmax[yy * d.W + x], t);
+            const uint2 ax = radx[yy * d.W + x];
+#pragma unroll
+            for (int j = 0; j < EPV; ++j)
+                if (first || t[j] > m[j] || t[j] != t[j]) {
+                    m[j] = t[j];
+                    mi[j] = (uint32_t)(dy * k) + (((j < 4 ? ax.x : ax.y) >> (8 * (j & 3))) & 0xffu);
+                }
+            first = false;
+        }
+        *(uint4*)(o + (long)p * d.ldo) = vec_pack<T>(m);
+        if (idx) {
+            uint8_t* ip = idx + ((long)b * HW + p) * d.C + c;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) ip[j] = (uint8_t)mi[j];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void maxpool_tile_bwd_kernel(DykEwDesc d, const uint8_t* __restrict__ idx) {
+    constexpr int EPV = ElemTraits<T>::EPV;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int HW = d.H * d.W, k = d.k, pad = (k - 1) / 2;
+    uint4* gt = (uint4*)smem;                    // [HW] output gradients
+    uint2* it = (uint2*)(gt + HW);               // [HW] argmax codes, one byte per element
+    const int CV = d.C / EPV;
+    const int b = blockIdx.x / CV, c = (blockIdx.x % CV) * EPV;
+    const T* __restrict__ a = (const T*)d.a + (long)b * HW * d.lda + c;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        gt[p] = *(const uint4*)(a + (long)p * d.lda);
+        const uint8_t* ip = idx + ((long)b * HW + p) * d.C + c;
+        uint2 pk;
+        pk.x = *(const uint32_t*)ip;
+        pk.y = EPV > 4 ? *(const uint32_t*)(ip + 4) : 0u;
+        it[p] = pk;
+    }
+    __syncthreads();
+    T* __restrict__ o = (T*)d.out + (long)b * HW * d.ldo + c;
+    const bool accum = d.flags & DYK_EW_ACCUM;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        const int y = p / d.W, x = p - y * d.W;
+        float s[EPV];
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) s[j] = 0.f;
+        for (int dy = 0; dy < k; ++dy) {
+            const int yo = y - dy + pad;
+            if (yo < 0 || yo >= d.H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int xo = x - dx + pad;
+                if (xo < 0 || xo >= d.W) continue;
+                const uint32_t code = (uint32_t)(dy * k + dx);
+                const uint2 ix = it[yo * d.W + xo];
+                float g[EPV];
+                vec_unpack<T>(gt[yo * d.W + xo], g);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j)
+                    if ((((j < 4 ? ix.x : ix.y) >> (8 * (j & 3))) & 0xffu) == code) s[j] += g[j];
+            }
+        }
+        if (accum) {
+            float t[EPV];
+            vec_unpack<T>(*(const uint4*)(o + (long)p * d.ldo), t);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) s[j] += t[j];
+        }
+        *(uint4*)(o + (long)p * d.ldo) = vec_pack<T>(s);
+    }
+}
+
 // ------------------------------------------------------------------ squeeze-excitation
 // pooled[b][c] = alpha * sum_hw a[b,p,c] * (b ? b[b,p,c] : 1)        grid (CV groups, B, HS)
 // HS = gridDim.z > 1: the pixels of an image are split over HS workgroups which store unscaled partial sums
@@ -380,98 +503,100 @@ __device__ inline float dot16(const float* __restrict__ wrow, const float* v, in
     return row16_sum((a0 + a1) + (a2 + a3));
 }
 
-// one block per image: h = relu(W1 pooled + b1); s = hardsigmoid(W2 h + b2)   (layers.py:185-189)
-__global__ __launch_bounds__(1024) void se_fc_fwd_kernel(DykSeFcDesc d) {
-    extern __shared__ float sm[];           // pooled[C] | h[Cs]
-    float* pooled = sm;
-    float* h = sm + d.C;
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < d.C; i += blockDim.x) pooled[i] = d.pooled[(long)b * d.C + i];
-    __syncthreads();
-    const int l16 = threadIdx.x & 15, g16 = threadIdx.x >> 4, ng = blockDim.x >> 4;
-    for (int j = g16; j < d.Cs; j += ng) {
-        const float acc = dot16(d.w1 + (long)j * d.C, pooled, d.C, l16);
-        if (l16 == 0) h[j] = fmaxf(acc + d.b1[j], 0.f);
-    }
-    __syncthreads();
-    for (int c = g16; c < d.C; c += ng) {
-        const float acc = dot16(d.w2 + (long)c * d.Cs, h, d.Cs, l16);
-        if (l16 == 0) d.scale[(long)b * d.C + c] = fminf(fmaxf(acc + d.b2[c] + 3.f, 0.f), 6.f) * (1.f / 6.f);
-    }
-}
-
-// backward of the two FCs for one image per block; parameter gradients via fp32 atomics.
-// in: dscale[b][c] = sum_hw dz*x ; out: dpooled[b][c] (gradient w.r.t. the pooled mean)
-__global__ __launch_bounds__(1024) void se_fc_bwd_kernel(DykSeFcDesc d) {
-    extern __shared__ float sm[];           // pooled[C] | h[Cs] | t1[Cs] | dt2[C] | dt1[Cs]
-    float* pooled = sm;
-    float* h = pooled + d.C;
-    float* t1 = h + d.Cs;
-    float* dt2 = t1 + d.Cs;
-    float* dt1 = dt2 + d.C;
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < d.C; i += blockDim.x) pooled[i] = d.pooled[(long)b * d.C + i];
-    __syncthreads();
-    const int l16 = threadIdx.x & 15, g16 = threadIdx.x >> 4, ng = blockDim.x >> 4;
-    for (int j = g16; j < d.Cs; j += ng) {
-        const float acc = dot16(d.w1 + (long)j * d.C, pooled, d.C, l16);
-        if (l16 == 0) { t1[j] = acc + d.b1[j]; h[j] = fmaxf(t1[j], 0.f); }
-    }
-    __syncthreads();
-    for (int c = g16; c < d.C; c += ng) {
-        const float acc = dot16(d.w2 + (long)c * d.Cs, h, d.Cs, l16);
+// The two FC layers of a squeeze-excitation block, h = relu(W1 pooled + b1), s = hardsigmoid(W2 h + b2) (layers.py:185-189),
+// and their backward, as small launches that spread the WEIGHT MATRICES over the chip.  (Rounds 1-2 ran one 1024-thread
+// block per image through the whole chain: every block streamed both matrices -- 2 x 1 MB fp32 at C = 1024 -- through one
+// CU, 24 us forward and 57 us backward per block for 4 MFLOP; 19 such blocks per MobileNetV3 step.)
+//   forward    se_rows_kernel<0>: h  [B][Cs] -> ws        se_rows_kernel<1>: s -> scale, t2 = W2 h + b2 -> ws
+//   backward   se_cols_kernel<0>: dt2 = dscale * hardsigmoid'(t2);  dt1 = (h > 0) * (W2^T dt2) -> ws
+//              se_cols_kernel<1>: dpooled = W1^T dt1             se_fc_wgrad_kernel: parameter gradients
+// Every sum has a fixed order (16-lane DPP rows / 16 partial sums folded as a tree): bit-reproducible.
+// ws: h [B][Cs] | dt1 [B][Cs] | t2 [B][C]  -- h and t2 are written by the forward call and read by the backward call.
+template <int ACT>
+__global__ __launch_bounds__(256) void se_rows_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                      const float* __restrict__ in, float* __restrict__ out, float* __restrict__ pre,
+                                                      int R, int K, int B, int bper) {
+    // out[b][r] = act(dot(W[r], in[b]) + bias[r]): a 16-lane group per row, the images of this block's slice in turn
+    const int l16 = threadIdx.x & 15, g16 = threadIdx.x >> 4;
+    const int r = blockIdx.x * 16 + g16;
+    if (r >= R) return;
+    const int b0 = blockIdx.y * bper, b1 = min(B, b0 + bper);
+    const float bs = bias[r];
+    for (int b = b0; b < b1; ++b) {
+        const float acc = dot16(W + (long)r * K, in + (long)b * K, K, l16);
         if (l16 == 0) {
-            const float t2 = acc + d.b2[c];
-            const float g = (t2 > -3.f && t2 < 3.f) ? d.dscale[(long)b * d.C + c] * (1.f / 6.f) : 0.f;
-            dt2[c] = g;                                   // (db2 = sum over the batch: se_fc_wgrad_kernel, in image order)
+            const float t = acc + bs;
+            if (ACT == 0) out[(long)b * R + r] = fmaxf(t, 0.f);
+            else {
+                out[(long)b * R + r] = fminf(fmaxf(t + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                if (pre) pre[(long)b * R + r] = t;
+            }
         }
-    }
-    __syncthreads();
-    // dh[j] = sum_c W2[c][j] dt2[c]: column sums, coalesced over j; the 4 row groups of the block split c and park their
-    // partial sums in dtp[rg][j], folded in a FIXED order (LDS float atomics made the order -- and the last bit of the
-    // gradients -- depend on which wave arrived first)
-    float* dtp = dt1 + d.Cs;                 // [4][Cs]
-    {
-        const int jt = threadIdx.x & 255, rg = threadIdx.x >> 8, nrg = blockDim.x >> 8;
-        for (int j = jt; j < d.Cs; j += 256) {
-            float acc = 0.f;
-#pragma unroll 8
-            for (int c = rg; c < d.C; c += nrg) acc += d.w2[(long)c * d.Cs + j] * dt2[c];
-            dtp[rg * d.Cs + j] = acc;
-        }
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < d.Cs; j += blockDim.x) {
-        const float sum = (dtp[j] + dtp[d.Cs + j]) + (dtp[2 * d.Cs + j] + dtp[3 * d.Cs + j]);
-        dt1[j] = t1[j] > 0.f ? sum : 0.f;
-    }
-    __syncthreads();
-    // park what the weight-gradient kernel needs: h | dt1 | dt2
-    float* wsh = d.ws + (long)b * d.Cs;
-    float* wsd1 = d.ws + (long)d.B * d.Cs + (long)b * d.Cs;
-    float* wsd2 = d.ws + 2L * d.B * d.Cs + (long)b * d.C;
-    for (int j = threadIdx.x; j < d.Cs; j += blockDim.x) { wsh[j] = h[j]; wsd1[j] = dt1[j]; }
-    for (int c = threadIdx.x; c < d.C; c += blockDim.x) wsd2[c] = dt2[c];
-    for (int c = threadIdx.x; c < d.C; c += blockDim.x) {      // coalesced over c, short loop over Cs
-        float acc = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < d.Cs; ++j) acc += d.w1[(long)j * d.C + c] * dt1[j];
-        d.dpooled[(long)b * d.C + c] = acc;
     }
 }
 
-// dW2[c][j] += sum_b dt2[b][c] h[b][j] ;  dW1[j][c] += sum_b dt1[b][j] pooled[b][c]   (one thread per element)
+// out[b][k] = sum_r W[r][k] v[b][r]: 16 columns x 16 row groups per block and image, partial sums folded in a fixed order
+//   MODE 0: W = W2 [C][Cs], v = dt2 (built here from t2 and dscale), out = dt1 = (h > 0) ? sum : 0
+//   MODE 1: W = W1 [Cs][C], v = dt1,                                 out = dpooled
+template <int MODE>
+__global__ __launch_bounds__(256) void se_cols_kernel(DykSeFcDesc d) {
+    extern __shared__ float sm[];           // v[R] | part[16][16]
+    const int R = MODE == 0 ? d.C : d.Cs, K = MODE == 0 ? d.Cs : d.C;
+    const float* __restrict__ W = MODE == 0 ? d.w2 : d.w1;
+    const int b = blockIdx.y;
+    float* v = sm;
+    float* part = sm + R;
+    float* h = d.ws + (long)b * d.Cs;
+    float* dt1 = d.ws + (long)d.B * d.Cs + (long)b * d.Cs;
+    const float* t2 = d.ws + 2L * d.B * d.Cs + (long)b * d.C;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        if (MODE == 0) {
+            const float t = t2[r];
+            v[r] = (t > -3.f && t < 3.f) ? d.dscale[(long)b * d.C + r] * (1.f / 6.f) : 0.f;
+        } else {
+            v[r] = dt1[r];
+        }
+    }
+    __syncthreads();
+    const int kt = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + kt;
+    float acc = 0.f;
+    if (k < K) {
+#pragma unroll 16
+        for (int r = rg; r < R; r += 16) acc += W[(long)r * K + k] * v[r];
+    }
+    part[rg * 16 + kt] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16 && k < K) {
+        float q[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) q[i] = part[i * 16 + kt];
+#pragma unroll
+        for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+            for (int i = 0; i < w; ++i) q[i] += q[i + w];
+        if (MODE == 0) dt1[k] = h[k] > 0.f ? q[0] : 0.f;
+        else d.dpooled[(long)b * d.C + k] = q[0];
+    }
+}
+
+// dW2[c][j] += sum_b dt2[b][c] h[b][j] ;  dW1[j][c] += sum_b dt1[b][j] pooled[b][c]   (one thread per element; dt2 is
+// rebuilt from t2 and dscale: the backward launches never overwrite what the forward call parked)
 __global__ __launch_bounds__(256) void se_fc_wgrad_kernel(DykSeFcDesc d) {
     const long n = (long)d.C * d.Cs;
     const float* h = d.ws;
     const float* dt1 = d.ws + (long)d.B * d.Cs;
-    const float* dt2 = d.ws + 2L * d.B * d.Cs;
+    const float* t2 = d.ws + 2L * d.B * d.Cs;
+    auto dt2 = [&](int b, long c) {
+        const float t = t2[(long)b * d.C + c];
+        return (t > -3.f && t < 3.f) ? d.dscale[(long)b * d.C + c] * (1.f / 6.f) : 0.f;
+    };
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < 2 * n + d.C + d.Cs; i += (long)gridDim.x * blockDim.x) {
         float acc = 0.f;
         if (i >= 2 * n) {                       // bias gradients: plain sums over the batch in image order (reproducible)
             const long k = i - 2 * n;
             if (k < d.C) {
-                for (int b = 0; b < d.B; ++b) acc += dt2[(long)b * d.C + k];
+                for (int b = 0; b < d.B; ++b) acc += dt2(b, k);
                 d.db2[k] += acc;
             } else {
                 for (int b = 0; b < d.B; ++b) acc += dt1[(long)b * d.Cs + (k - d.C)];
@@ -479,7 +604,7 @@ __global__ __launch_bounds__(256) void se_fc_wgrad_kernel(DykSeFcDesc d) {
             }
         } else if (i < n) {
             const int c = (int)(i / d.Cs), j = (int)(i - (long)c * d.Cs);
-            for (int b = 0; b < d.B; ++b) acc += dt2[(long)b * d.C + c] * h[(long)b * d.Cs + j];
+            for (int b = 0; b < d.B; ++b) acc += dt2(b, c) * h[(long)b * d.Cs + j];
             d.dw2[i] += acc;
         } else {
             const long k = i - n;
@@ -743,10 +868,26 @@ extern "C" int dyk_upsample2x_bwd(const DykEwDesc* d, void* stream) {
         DYK_LAUNCH_CHECK();                                                                                      \
     } while (0)
 
+// the LDS-plane kernels: stride 1, odd window (output map = input map), map of at most 1024 pixels, 4-byte aligned argmax rows
+static bool maxpool_tile_ok(const DykEwDesc* d) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("DYK_MAXPOOL_TILE"); off = (e && e[0] == '0') ? 1 : 0; }
+    return !off && d->slots <= 1 && (d->k & 1) && d->H * d->W <= 1024 && d->C % 4 == 0;
+}
+static int maxpool_tile_threads(int HW) { const int t = (HW + 63) / 64 * 64; return t > 1024 ? 1024 : t; }
+
 extern "C" int dyk_maxpool_fwd(const DykEwDesc* d, uint8_t* argmax, void* stream) {
     const int rc = check_ew(d, false);
     if (rc) return rc;
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0 || d->k > 15 || d->slots < 0 || d->slots > 8) return DYK_ERR_ARG;
+    if (maxpool_tile_ok(d)) {
+        const int HW = d->H * d->W, threads = maxpool_tile_threads(HW);
+        const unsigned grid = (unsigned)(d->B * (d->C / epv_of(d->dtype)));
+        if (d->dtype == DYK_BF16) hipLaunchKernelGGL(maxpool_tile_fwd_kernel<bf16_t>, dim3(grid), dim3(threads), (size_t)HW * 40, (hipStream_t)stream, *d, argmax);
+        else hipLaunchKernelGGL(maxpool_tile_fwd_kernel<float>, dim3(grid), dim3(threads), (size_t)HW * 40, (hipStream_t)stream, *d, argmax);
+        DYK_LAUNCH_CHECK();
+        return DYK_OK;
+    }
     const int grid = ew_grid((long)d->B * d->H * d->W * (d->C / epv_of(d->dtype)));
     MAXPOOL_DISPATCH(maxpool_fwd_kernel, argmax);
     return DYK_OK;
@@ -756,6 +897,14 @@ extern "C" int dyk_maxpool_bwd(const DykEwDesc* d, const uint8_t* argmax, void* 
     const int rc = check_ew(d, false);
     if (rc) return rc;
     if (!argmax || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0 || d->k > 15 || d->slots < 0 || d->slots > 8) return DYK_ERR_ARG;
+    if (maxpool_tile_ok(d)) {
+        const int HW = d->H * d->W, threads = maxpool_tile_threads(HW);
+        const unsigned grid = (unsigned)(d->B * (d->C / epv_of(d->dtype)));
+        if (d->dtype == DYK_BF16) hipLaunchKernelGGL(maxpool_tile_bwd_kernel<bf16_t>, dim3(grid), dim3(threads), (size_t)HW * 24, (hipStream_t)stream, *d, argmax);
+        else hipLaunchKernelGGL(maxpool_tile_bwd_kernel<float>, dim3(grid), dim3(threads), (size_t)HW * 24, (hipStream_t)stream, *d, argmax);
+        DYK_LAUNCH_CHECK();
+        return DYK_OK;
+    }
     const int grid = ew_grid((long)d->B * d->H * d->W * (d->C / epv_of(d->dtype)));
     MAXPOOL_DISPATCH(maxpool_bwd_kernel, argmax);
     return DYK_OK;
@@ -786,21 +935,41 @@ extern "C" int dyk_se_pool(const DykEwDesc* d, float* pooled, void* stream) {
     return DYK_OK;
 }
 
+static void se_rows_grid(int R, int B, dim3* grid, int* bper) {
+    const int gx = (R + 15) / 16;
+    int gy = 512 / gx;                      // about two workgroups per CU over (row blocks) x (image slices)
+    if (gy < 1) gy = 1;
+    if (gy > B) gy = B;
+    *bper = (B + gy - 1) / gy;
+    *grid = dim3((unsigned)gx, (unsigned)((B + *bper - 1) / *bper));
+}
+
 extern "C" int dyk_se_fc_fwd(const DykSeFcDesc* d, void* stream) {
-    if (!d || !d->pooled || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->scale || d->B <= 0 || d->C <= 0 || d->Cs <= 0)
+    if (!d || !d->pooled || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->scale || !d->ws || d->B <= 0 || d->C <= 0 || d->Cs <= 0 ||
+        d->C % 4 || d->Cs % 4)
         return DYK_ERR_ARG;
-    const size_t lds = (size_t)(d->C + d->Cs) * sizeof(float);
-    hipLaunchKernelGGL(se_fc_fwd_kernel, dim3(d->B), dim3(1024), lds, (hipStream_t)stream, *d);
+    float* h = d->ws;
+    float* t2 = d->ws + 2L * d->B * d->Cs;
+    dim3 grid;
+    int bper;
+    se_rows_grid(d->Cs, d->B, &grid, &bper);
+    hipLaunchKernelGGL(se_rows_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, d->w1, d->b1, d->pooled, h, (float*)nullptr, d->Cs,
+                       d->C, d->B, bper);
+    se_rows_grid(d->C, d->B, &grid, &bper);
+    hipLaunchKernelGGL(se_rows_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, d->w2, d->b2, (const float*)h, d->scale, t2, d->C,
+                       d->Cs, d->B, bper);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
 
 extern "C" int dyk_se_fc_bwd(const DykSeFcDesc* d, void* stream) {
     if (!d || !d->pooled || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->dscale || !d->dpooled || !d->dw1 || !d->db1 ||
-        !d->dw2 || !d->db2 || !d->ws || d->B <= 0 || d->C <= 0 || d->Cs <= 0)
+        !d->dw2 || !d->db2 || !d->ws || d->B <= 0 || d->C <= 0 || d->Cs <= 0 || d->C > 8192 || d->Cs > 8192)
         return DYK_ERR_ARG;
-    const size_t lds = (size_t)(2 * d->C + 7 * d->Cs) * sizeof(float);
-    hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(d->B), dim3(1024), lds, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(se_cols_kernel<0>, dim3((unsigned)((d->Cs + 15) / 16), (unsigned)d->B), dim3(256), (size_t)(d->C + 256) * 4,
+                       (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(se_cols_kernel<1>, dim3((unsigned)((d->C + 15) / 16), (unsigned)d->B), dim3(256), (size_t)(d->Cs + 256) * 4,
+                       (hipStream_t)stream, *d);
     const long n2 = 2L * d->C * d->Cs + d->C + d->Cs;
     hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3((unsigned)((n2 + 255) / 256 < 4096 ? (n2 + 255) / 256 : 4096)), dim3(256), 0,
                        (hipStream_t)stream, *d);

@@ -76,6 +76,8 @@ def squeeze_excitation(x, w1, b1, w2, b2):
     fd.pooled, fd.scale = pooled.data_ptr(), scale.data_ptr()
     fd.w1, fd.b1, fd.w2, fd.b2 = (t.data_ptr() for t in prm)
     fd.B, fd.C, fd.Cs = B, C, Cs
+    fcws = torch.empty(B * (C + 2 * Cs), device=x.device)       # h | dt1 | t2 (include/dyk_hip.h)
+    fd.ws = fcws.data_ptr()
     ops.call("dyk_se_fc_fwd", fd)
     z = torch.empty_like(xd)
     ops.call("dyk_se_scale", ops.ew_desc(a=xd, out=z, p0=scale, B=B, H=H, W=W))

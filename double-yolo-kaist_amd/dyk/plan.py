@@ -657,12 +657,14 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             fd.w1, fd.b1 = store.p_ptr(pre + "fc1.weight"), store.p_ptr(pre + "fc1.bias")
             fd.w2, fd.b2 = store.p_ptr(pre + "fc2.weight"), store.p_ptr(pre + "fc2.bias")
             fd.B, fd.C, fd.Cs = B, C, Cs
-            later(lambda fd=fd, pooled=pooled, scale=scale: (setattr(fd, "pooled", ws.ptr(pooled)), setattr(fd, "scale", ws.ptr(scale))))
+            fcws = new_ws(B * (C + 2 * Cs) * 4)               # h | dt1 | t2: parked by the forward call for the backward one
+            later(lambda fd=fd, pooled=pooled, scale=scale, fcws=fcws: (
+                setattr(fd, "pooled", ws.ptr(pooled)), setattr(fd, "scale", ws.ptr(scale)), setattr(fd, "ws", ws.ptr(fcws))))
             plan.fwd.append((L.OP_SE_FC_FWD, fd))
             sd = ew_desc(a=x_in, out=z, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W)
             later(lambda sd=sd, scale=scale: setattr(sd, "p0", ws.ptr(scale)))
             plan.fwd.append((L.OP_SE_SCALE, sd))
-            rec.update(x=x_in, z=z, pooled=pooled, scale=scale, C=C, Cs=Cs)
+            rec.update(x=x_in, z=z, pooled=pooled, scale=scale, C=C, Cs=Cs, fcws=fcws)
             cur = z
         elif t == "maxpool":
             x_in = cur
@@ -1086,7 +1088,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 x_in, C, Cs = rec["x"], rec["C"], rec["Cs"]
                 dscale = new_ws(B * C * 4)
                 dpooled = new_ws(B * C * 4)
-                fcws = new_ws(B * (C + 2 * Cs) * 4)
+                fcws = rec["fcws"]
                 pd = ew_desc(a=dz, b=x_in, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W, alpha=1.0)
                 pparts = new_ws(L.SE_POOL_SPLITS * B * C * 4)
                 later(lambda pd=pd, dscale=dscale, pparts=pparts: (setattr(pd, "aux", ws.ptr(dscale)), setattr(pd, "aux2", ws.ptr(pparts))))
@@ -1487,6 +1489,8 @@ def autotune(plan, cache=None):
                     d.tune = c
                     times.append(_time_launch(fn, d, stream))
                 best = cands[times.index(min(times))]
+                if os.environ.get("DYK_TUNE_VERBOSE"):   # analysis: every candidate's time, fastest first
+                    print("tune", key, " ".join("%#x:%.1f" % (c, 1e3 * t) for t, c in sorted(zip(times, cands))[:12]), flush=True)
             cache[key] = best
             if min(times) != float("inf"):
                 _TUNE_MS[key] = min(times)

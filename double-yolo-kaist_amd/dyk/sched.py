@@ -221,9 +221,9 @@ def accesses(op, d, mem, plan):
         if d.out:
             wr(T(d.out, d.ldo, d.C, es))
     elif op == L.OP_SE_FC_FWD:
-        rd(V(d.pooled)); wr(V(d.scale))
+        rd(V(d.pooled)); wr(V(d.scale)); wr(V(d.ws))
     elif op == L.OP_SE_FC_BWD:
-        rd(V(d.pooled)); rd(V(d.scale)); rd(V(d.dscale))
+        rd(V(d.pooled)); rd(V(d.dscale))
         wr(V(d.dpooled)); wr(V(d.ws))
         for p, n in ((d.dw1, d.Cs * d.C), (d.db1, d.Cs), (d.dw2, d.C * d.Cs), (d.db2, d.C)):
             wr(mem.interval(_v(p), n * 4))

@@ -300,11 +300,14 @@ int dyk_maxpool_bwd(const DykEwDesc* desc, const uint8_t* argmax, void* stream);
  *                 per-channel scale).  desc->aux2 (optional): scratch of DYK_SE_POOL_SPLITS * B * C floats;
  *                 with it the pixels of an image are reduced by up to DYK_SE_POOL_SPLITS workgroups whose
  *                 partial sums are folded in a fixed order (same result from run to run)
- *   dyk_se_fc_fwd : scale = hardsigmoid(W2 relu(W1 pooled + b1) + b2), one block per image
+ *   dyk_se_fc_fwd : scale = hardsigmoid(W2 relu(W1 pooled + b1) + b2); two launches that spread the rows of W1 / W2 over
+ *                   the chip.  Needs `ws` (B*(C + 2*Cs) floats): h = relu(..) and t2 = W2 h + b2 are parked there
  *   dyk_se_scale  : out[b,hw,c] = a[b,hw,c]*p0[b*C+c] (+ alpha*p1[b*C+c])
- *   dyk_se_fc_bwd : from dscale = d(loss)/d(scale) produce dpooled and accumulate dW1,db1,dW2,db2.  Two launches:
- *                   per image the FC chain (h, dt2, dt1 parked in `ws`), then one thread per weight element
- *                   sums its outer products over the batch -- no atomics on the weight gradients. */
+ *   dyk_se_fc_bwd : from dscale = d(loss)/d(scale) produce dpooled and accumulate dW1,db1,dW2,db2.  MUST follow
+ *                   dyk_se_fc_fwd on the same `ws` (it reads the h and t2 the forward call parked; nothing is
+ *                   recomputed).  Three launches: dt1 = relu'(h) * W2^T (dscale * hardsigmoid'(t2)) -> ws,
+ *                   dpooled = W1^T dt1, then one thread per weight element sums its outer products over the
+ *                   batch -- no atomics on the weight gradients, every sum in a fixed order. */
 typedef struct DykSeFcDesc {
     const float* pooled;   /* [B][C] */
     const float* w1;       /* [Cs][C]  fc1.weight */
@@ -315,7 +318,7 @@ typedef struct DykSeFcDesc {
     const float* dscale;   /* [B][C] (bwd) */
     float* dpooled;        /* [B][C] out (bwd) */
     float* dw1; float* db1; float* dw2; float* db2;   /* accumulated (bwd) */
-    float* ws;             /* bwd scratch, B*(C + 2*Cs) floats: h [B][Cs] | dt1 [B][Cs] | dt2 [B][C] */
+    float* ws;             /* B*(C + 2*Cs) floats: h [B][Cs] (fwd) | dt1 [B][Cs] (bwd) | t2 [B][C] (fwd) */
     int32_t B, C, Cs;
 } DykSeFcDesc;
 #define DYK_SE_POOL_SPLITS 16

@@ -204,10 +204,40 @@ def test_upsample_maxpool(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_squeeze_excitation_fwd_bwd(dtype):
+def test_spp_pools_on_the_16x20_map(dtype):
+    """the LDS-plane pool kernels (stride 1, odd window) at the SPP block's own map size: values equal torch's, the
+    argmax codes are torch's first maximum in scan order (ties on purpose), gradient by the tie rule"""
+    from dyk import ops
+    B, C, H, W = 2, 64, 16, 20
+    g = torch.Generator().manual_seed(15)
+    xq = (torch.randn(B, C, H, W, generator=g) * 1.5).round() / 2
+    xqd = ops.to_nhwc(xq.cuda(), dtype)
+    tol = _tol(dtype)
+    yy, xx = torch.arange(H).view(1, 1, H, 1), torch.arange(W).view(1, 1, 1, W)
+    for k in (5, 9, 13):
+        pad = (k - 1) // 2
+        xr = xq.clone().requires_grad_(True)
+        mp_ref, ind = F.max_pool2d(xr, k, 1, pad, return_indices=True)
+        dmp = torch.randn(mp_ref.shape, generator=g)
+        if dtype == torch.bfloat16:
+            dmp = dmp.bfloat16().float()
+        mp_ref.backward(dmp)
+        mp = torch.empty_like(xqd)
+        amax = torch.zeros(B * H * W * C, dtype=torch.uint8, device="cuda")
+        ops.call("dyk_maxpool_fwd", ops.ew_desc(a=xqd, out=mp, B=B, H=H, W=W, k=k), amax)
+        assert torch.equal(ops.to_nchw(mp).cpu(), mp_ref.detach()), "maxpool k=%d" % k
+        code = (ind // W - (yy - pad)) * k + (ind % W - (xx - pad))
+        assert torch.equal(amax.view(B, H, W, C).permute(0, 3, 1, 2).cpu().long(), code), "argmax codes k=%d" % k
+        dxp = torch.empty_like(xqd)
+        ops.call("dyk_maxpool_bwd", ops.ew_desc(a=ops.to_nhwc(dmp.cuda(), dtype), out=dxp, B=B, H=H, W=W, k=k), amax)
+        _close(ops.to_nchw(dxp).cpu(), xr.grad, 8 * tol, "maxpool bwd k=%d" % k)
+
+
+@pytest.mark.parametrize("B,C,Cs,H,W", [(3, 64, 16, 6, 8), (5, 520, 132, 2, 3)])       # (ragged row / column blocks)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_squeeze_excitation_fwd_bwd(dtype, B, C, Cs, H, W):
     from dyk import ops
     from dyk.lib import DykSeFcDesc
-    B, C, Cs, H, W = 3, 64, 16, 6, 8
     g = torch.Generator().manual_seed(6)
     x = torch.randn(B, C, H, W, generator=g)
     dz = torch.randn(B, C, H, W, generator=g)
@@ -230,6 +260,8 @@ def test_squeeze_excitation_fwd_bwd(dtype):
     fd = DykSeFcDesc()
     fd.pooled, fd.w1, fd.b1, fd.w2, fd.b2, fd.scale = pooled.data_ptr(), prm[0].data_ptr(), prm[1].data_ptr(), prm[2].data_ptr(), prm[3].data_ptr(), scale.data_ptr()
     fd.B, fd.C, fd.Cs = B, C, Cs
+    fcws = torch.zeros(B * (C + 2 * Cs), device="cuda")      # h | dt1 | t2: the forward call parks h and t2 for the backward one
+    fd.ws = fcws.data_ptr()
     ops.call("dyk_se_fc_fwd", fd)
     _close(scale.cpu(), s.detach().view(B, C), 1e-5, "se scale")
     z = torch.empty_like(xd)
@@ -242,8 +274,6 @@ def test_squeeze_excitation_fwd_bwd(dtype):
     grads = [torch.zeros_like(t) for t in prm]
     fd.dscale, fd.dpooled = dscale.data_ptr(), dpooled.data_ptr()
     fd.dw1, fd.db1, fd.dw2, fd.db2 = (t.data_ptr() for t in grads)
-    fcws = torch.zeros(B * (C + 2 * Cs), device="cuda")
-    fd.ws = fcws.data_ptr()
     ops.call("dyk_se_fc_bwd", fd)
     for got, ref, nm in zip(grads, (w1, b1, w2, b2), ("dw1", "db1", "dw2", "db2")):
         _close(got.cpu().view(-1), ref.grad.view(-1), 20 * tol, nm)

@@ -125,6 +125,41 @@ if "ablate" in what:
             print(rows[-1], flush=True)
     res["ablate"] = rows
 
+if "clsablate" in what:
+    # stride-2 data gradient with the four output-parity classes in one launch: where does the time go?
+    import ctypes as C
+    from dyk import lib as L
+    fn = L.load().dyk_conv_igemm
+    for (cf_in, cf_out, Hi, Wi) in [(32, 64, 512, 640), (64, 128, 256, 320), (128, 256, 128, 160)]:
+        B, dt = 16, torch.bfloat16
+        Ho, Wo = Hi // 2, Wi // 2
+        dy = torch.randn(B, Ho, Wo, cf_out, device="cuda").to(dt)
+        w = torch.randn(cf_out, cf_in, 3, 3, device="cuda") * 0.05
+        wpt = ops.pack_weight(w, dt, transposed=True)
+        out = torch.empty(B, Hi, Wi, cf_in, device="cuda", dtype=dt)
+        classes = ops.dgrad_classes(3, 1, 2, Hi, Wi)
+        d = ops.make_conv_desc(dy, wpt, out, Hi=Ho, Wi=Wo, Cin=cf_out, Cout=cf_in, Hg=classes[0][2], Wg=classes[0][3], Ho=Hi, Wo=Wi,
+                               taps=[t for c in classes for t in c[4]], osy=2, osx=2)
+        d.ncls, q0 = len(classes), 0
+        for c, (py, px, _, _, taps) in enumerate(classes):
+            d.cls_first[c], d.cls_ntaps[c], d.cls_ooy[c], d.cls_oox[c] = q0, len(taps), py, px
+            q0 += len(taps)
+        line = []
+        for base in (0x2340, 0x2240, 0x2280, 0x240):
+            for name, bits in [("full", 0), ("nostore", 1 << 16), ("noloop", 1 << 17), ("empty", 1 << 18), ("tables", 1 << 19), ("noepi", 1 << 20), ("noloop+noepi", (1 << 20) | (1 << 17))]:
+                d.tune = base | bits
+                for _ in range(2):
+                    fn(C.byref(d), None)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    fn(C.byref(d), None)
+                e1.record(); torch.cuda.synchronize()
+                line.append("%s=%.1f" % (name, e0.elapsed_time(e1) / 10 * 1e3))
+            print((cf_in, cf_out, Hi), hex(base), " ".join(line), flush=True)
+            line = []
+
 if "nobar" in what:
     # upper bound of a barrier-free K loop: the autotuned best configuration with / without its per-step s_barrier
     import ctypes as C
