@@ -337,12 +337,21 @@ __global__ __launch_bounds__(1024) void maxpool_tile_fwd_kernel(DykEwDesc d, uin
         *(uint4*)(o + (long)p * d.ldo) = vec_pack<T>(m);
         if (idx) {
             uint8_t* ip = idx + ((long)b * HW + p) * d.C + c;
+            uint32_t lo = 0u, hi = 0u;
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) ip[j] = (uint8_t)mi[j];
+            for (int j = 0; j < EPV; ++j) {
+                if (j < 4) lo |= mi[j] << (8 * j); else hi |= mi[j] << (8 * (j - 4));
+            }
+            *(uint32_t*)ip = lo;                 // (C % 4 == 0: aligned)
+            if (EPV > 4) *(uint32_t*)(ip + 4) = hi;
         }
     }
 }
 
+// (Tried in round 3 and dropped: the backward as a SCATTER -- one lane per (image, channel) walking its outputs in scan order
+// with ds_add_f32 into a [pixel][64] fp32 plane, deterministic because one lane owns an address.  One add per output instead
+// of k*k compare-selects per input, but a 64-channel slab needs 143 KB of LDS, i.e. one workgroup per CU and 128 workgroups
+// per launch: 51 us per launch whatever the window, against 12 / 40 / 80 us for the 5 / 9 / 13 gathers below.)
 template <typename T>
 __global__ __launch_bounds__(1024) void maxpool_tile_bwd_kernel(DykEwDesc d, const uint8_t* __restrict__ idx) {
     constexpr int EPV = ElemTraits<T>::EPV;

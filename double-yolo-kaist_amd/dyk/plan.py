@@ -22,7 +22,10 @@ from .ops import conv_out_size, dgrad_classes, fwd_taps
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 HEAD_LD = 32            # head conv outputs / their gradients live in 32-channel rows
-FWD_SLOTS_CAP = int(os.environ.get("DYK_FWD_SLOTS_CAP", "256"))   # most replicas of a forward statistics buffer
+FWD_SLOTS_CAP = int(os.environ.get("DYK_FWD_SLOTS_CAP", "32"))    # most replicas of a forward statistics buffer.  32 = every layer's
+# finalize rides on its normalise launch (42 launches of 9 us fewer on the forward chain of the target cfg: -0.2 ms in an A/B
+# against 256 replicas, round 3; the 10 240 tiles of a 256 x 320 layer then put 320 fp64 atomics on an address -- the backward
+# pass has always run such layers with 16 replicas)
 STAT_SLOTS = int(os.environ.get("DYK_STAT_SLOTS", "16"))   # replicas of every per-channel fp64 reduction buffer of the backward (bounds atomic
                                                             # contention; every apply workgroup folds them: 32 -> 16 measured -0.15 ms, 64 +0.4 ms)
 
