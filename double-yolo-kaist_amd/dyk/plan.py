@@ -1460,7 +1460,10 @@ def autotune(plan, cache=None):
                         scratch[0] = torch.empty(n, dtype=torch.float32, device=dev)
                     return scratch[0].data_ptr()
 
-                fold_w = float(os.environ.get("DYK_WGRAD_FOLD_W", "1"))
+                # Weight of the fold term.  2, not 1: the trial times the weight-gradient launch ALONE, in the step it shares the
+                # chip with three other streams and every plane byte is paid for at the shared rate -- in-call A/B of the whole step
+                # (round 3, C3): weight 0.5 / 1 / 1.5 / 2 / 2.5 / 3 / 4 -> 32.8 / 32.6 / 32.2 / 31.8 / 32.1 / 32.0 / 32.6 ms
+                fold_w = float(os.environ.get("DYK_WGRAD_FOLD_W", "2"))
                 combos, times = [], []
                 for c in cands:
                     d.tune, d.part, d.part_stride, d.splits = c, None, 0, 0
