@@ -66,7 +66,16 @@ template <typename T, int C> __device__ inline int wg_off(int row, int ch) {
     constexpr int RB = C * (int)sizeof(T);
     if (sizeof(T) == 2) {
         constexpr int NCH = RB / 32;                     // 32-byte chunks per row
-        const int f = ((row & 3) | (((row >> 3) & 1) << 2)) & (NCH - 1);
+        // A 32-lane group of the transposing fragment read touches ONE 32-byte chunk column of the eight rows
+        // b + {0,1,2,3, 8,9,10,11} (b = K offset of the step, plus the tap shift in the multi-tap kernel: any value).  Rows
+        // that are congruent modulo 256 / RB share their banks, so the XOR key must tell exactly those rows apart -- from row
+        // bits that differ for ANY b: 256-byte rows (all eight collide) bits 0,1,3; 128-byte rows (the four of equal parity
+        // collide) bits 1,3; 64-byte rows (b + i and b + 8 + i collide) bit 3.  (Rounds 1-3 keyed every width with
+        // `row & 3 | bit 3 << 2` masked to the chunk count: right for 256-byte rows only -- 64-wide tiles, i.e. every dy tile
+        // of the multi-tap kernel, read with 2-way conflicts: 57 % of its LDS cycles in the round-3 counters.)
+        const int f = NCH >= 8 ? ((row & 3) | (((row >> 3) & 1) << 2)) & (NCH - 1)
+                    : NCH == 4 ? (((row >> 1) & 1) | (((row >> 3) & 1) << 1))
+                    : NCH == 2 ? ((row >> 3) & 1) : 0;
         const int chunk = (ch >> 4) ^ f;
         return row * RB + chunk * 32 + (ch & 15) * 2;
     } else {
