@@ -1411,6 +1411,34 @@ def _time_launch(fn, desc, stream, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
+def _refine(cands, times, trial, within=1.10, keep=4, rounds=2, reps=6):
+    """Second look at the front runners of a tuning pass.  The first pass times every candidate with three back-to-back
+    launches; candidates within a few per cent of each other then win or lose on timer noise, and the step time of one
+    build moved by 0.4 ms from run to run on one box (round 3).  The `keep` fastest within `within` of the best are timed
+    again, interleaved, `rounds` x `reps` launches each; their times are replaced by the mean of the second look."""
+    knob = os.environ.get("DYK_TUNE_REFINE", "1")          # "0": off; "keep,rounds,reps": sweep knob
+    if knob == "0" or len(cands) < 2:
+        return times
+    if "," in knob:
+        keep, rounds, reps = (int(v) for v in knob.split(","))
+    best = min(times)
+    short = sorted((t, i) for i, t in enumerate(times) if t <= within * best)[:keep]
+    if len(short) < 2:
+        return times
+    acc = {i: 0.0 for _, i in short}
+    for _ in range(rounds):
+        for _, i in short:
+            acc[i] += trial(cands[i], reps)
+    out = list(times)
+    worst = max(acc.values()) / rounds
+    for j, t in enumerate(out):                    # everything outside the short list stays behind it
+        if j not in acc:
+            out[j] = max(t, worst * 1.0001)
+    for i, a in acc.items():
+        out[i] = a / rounds
+    return out
+
+
 def autotune(plan, cache=None):
     """Measure, don't guess: for every distinct convolution / weight-gradient problem of the plan, time
     the tile configurations the kernels offer (K-step bytes x LDS ring depth) on the real buffers and
@@ -1464,6 +1492,21 @@ def autotune(plan, cache=None):
                 # chip with three other streams and every plane byte is paid for at the shared rate -- in-call A/B of the whole step
                 # (round 3, C3): weight 0.5 / 1 / 1.5 / 2 / 2.5 / 3 / 4 -> 32.8 / 32.6 / 32.2 / 31.8 / 32.1 / 32.0 / 32.6 ms
                 fold_w = float(os.environ.get("DYK_WGRAD_FOLD_W", "2"))
+                def trial(c, o, reps=3):
+                    """time tile configuration c with o K splits (0 = the kernel's own count); None if c does not apply"""
+                    d.tune, d.part, d.part_stride, d.splits = c, None, 0, o
+                    n = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
+                    if n < 1:
+                        return None
+                    if n >= 2 and plane % 4 == 0:
+                        d.part, d.part_stride, d.splits = room(n * plane), plane, n
+                        t = _time_launch(fn, d, stream, reps) + fold_w * (n + 1) * plane * 4 / 2.7e9
+                    else:
+                        d.dw = room(plane)                         # (trial sums must not land in the gradient buffer)
+                        t = _time_launch(fn, d, stream, reps)
+                        d.dw = saved_dw
+                    return t
+
                 combos, times = [], []
                 for c in cands:
                     d.tune, d.part, d.part_stride, d.splits = c, None, 0, 0
@@ -1474,26 +1517,21 @@ def autotune(plan, cache=None):
                     if os.environ.get("DYK_WGRAD_TUNE_SPLITS", "1") != "0" and plane % 4 == 0:
                         opts |= {max(1, auto // 2), max(1, auto // 4), max(1, auto // 8)}
                     for o in sorted(opts, reverse=True):
-                        d.part, d.part_stride, d.splits = None, 0, (0 if o == auto else o)
-                        n = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
-                        if n >= 2 and plane % 4 == 0:
-                            d.part, d.part_stride, d.splits = room(n * plane), plane, n
-                            t = _time_launch(fn, d, stream) + fold_w * (n + 1) * plane * 4 / 2.7e9
-                        else:
-                            d.dw = room(plane)                     # (trial sums must not land in the gradient buffer)
-                            t = _time_launch(fn, d, stream)
-                            d.dw = saved_dw
-                        combos.append((c, 0 if o == auto else o))
-                        times.append(t)
-                d.part, d.part_stride, d.splits, d.dw = None, 0, 0, saved_dw
+                        t = trial(c, 0 if o == auto else o)
+                        if t is not None:
+                            combos.append((c, 0 if o == auto else o))
+                            times.append(t)
                 if not combos:                     # no candidate applies to this problem: the kernel's defaults
                     combos, times = [(0, 0)], [float("inf")]
+                else:
+                    times = _refine(combos, times, lambda cc, reps: trial(cc[0], cc[1], reps))
+                d.part, d.part_stride, d.splits, d.dw = None, 0, 0, saved_dw
                 best = combos[times.index(min(times))]
             else:
-                times = []
-                for c in cands:
+                def trial_c(c, reps=3):
                     d.tune = c
-                    times.append(_time_launch(fn, d, stream))
+                    return _time_launch(fn, d, stream, reps)
+                times = _refine(cands, [trial_c(c) for c in cands], trial_c)
                 best = cands[times.index(min(times))]
                 if os.environ.get("DYK_TUNE_VERBOSE"):   # analysis: every candidate's time, fastest first
                     print("tune", key, " ".join("%#x:%.1f" % (c, 1e3 * t) for t, c in sorted(zip(times, cands))[:12]), flush=True)
