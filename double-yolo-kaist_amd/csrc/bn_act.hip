@@ -127,8 +127,19 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(DykFinPair fp, DykEwP
         const size_t rs = (size_t)2 * f.C;
         for (int cl = threadIdx.x; cl < nch; cl += 256) {
             const int c = c_base + cl;
+            // FB replicas x 2 sums requested back to back: the fold is a chain of slots / FB dependent L2 round trips in front of
+            // the first pixel load of a launch-bound pass (round 3, tools/gpu_probe.py bnfold: 32 replicas in batches of 4 cost
+            // 3.5 us of a 10 us launch on the 32 x 40 x 256 tensors, 1 replica 0 us)
+            constexpr int FB = 16;
             double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
             int r = 0;
+            for (; r + FB <= slots; r += FB) {
+                double v1[FB], v2[FB];
+#pragma unroll
+                for (int u = 0; u < FB; ++u) { v1[u] = f.stats[(size_t)(r + u) * rs + c]; v2[u] = f.stats[(size_t)(r + u) * rs + f.C + c]; }
+#pragma unroll
+                for (int u = 0; u < FB; ++u) { a1[u & 3] += v1[u]; a2[u & 3] += v2[u]; }
+            }
             for (; r + 4 <= slots; r += 4) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { a1[u] += f.stats[(size_t)(r + u) * rs + c]; a2[u] += f.stats[(size_t)(r + u) * rs + f.C + c]; }
@@ -292,23 +303,34 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwPair pr, int
         const int c_base = blockIdx.x * CVB * EPV;
         const int nch = min(CVB * EPV, d.C - c_base);
         const int slots = d.slots > 0 ? d.slots : 1;
-        for (int idx = threadIdx.x; idx < 2 * nch; idx += 256) {
-            const int which = idx >= nch, cl = idx - which * nch;
-            const double* p = d.red + (size_t)which * d.C + c_base + cl;
-            // 8 independent loads in flight (a dependent chain of `slots` L2 round trips would cost ~10 us here)
-            double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            const size_t rs = (size_t)2 * d.C;
+        const size_t rs = (size_t)2 * d.C;
+        for (int cl = threadIdx.x; cl < nch; cl += 256) {
+            const double* p = d.red + c_base + cl;
+            // both sums of a channel, 16 replicas each, requested back to back: ONE L2 round trip in front of the pixel loop for the
+            // backward's 16 replicas (a dependent chain of `slots` round trips cost ~10 us here; batches of 8 per sum, the two
+            // sums of a 256-channel group one after the other, still cost four)
+            double a8[2][8] = {{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
             int r = 0;
+            for (; r + 16 <= slots; r += 16) {
+                double v[2][16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { v[0][u] = p[(size_t)(r + u) * rs]; v[1][u] = p[(size_t)(r + u) * rs + d.C]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { a8[0][u & 7] += v[0][u]; a8[1][u & 7] += v[1][u]; }
+            }
             for (; r + 8 <= slots; r += 8) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a8[u] += p[(size_t)(r + u) * rs];
+                for (int u = 0; u < 8; ++u) { a8[0][u] += p[(size_t)(r + u) * rs]; a8[1][u] += p[(size_t)(r + u) * rs + d.C]; }
             }
-            for (; r < slots; ++r) a8[0] += p[(size_t)r * rs];
-            const double acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
-            s_tot[which][cl] = (float)acc;
-            if (blockIdx.y == 0) {
-                float* g = which ? (float*)d.aux : (float*)d.aux2;      // sum(dact * xhat) -> dgamma, sum(dact) -> dbeta
-                if (g) g[c_base + cl] += (float)acc;
+            for (; r < slots; ++r) { a8[0][0] += p[(size_t)r * rs]; a8[1][0] += p[(size_t)r * rs + d.C]; }
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const double acc = ((a8[which][0] + a8[which][1]) + (a8[which][2] + a8[which][3])) + ((a8[which][4] + a8[which][5]) + (a8[which][6] + a8[which][7]));
+                s_tot[which][cl] = (float)acc;
+                if (blockIdx.y == 0) {
+                    float* g = which ? (float*)d.aux : (float*)d.aux2;      // sum(dact * xhat) -> dgamma, sum(dact) -> dbeta
+                    if (g) g[c_base + cl] += (float)acc;
+                }
             }
         }
         __syncthreads();

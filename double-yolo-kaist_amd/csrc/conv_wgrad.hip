@@ -301,23 +301,30 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgArgs args,
             }
             sp0 += ROWS;
         };
-        if constexpr (PIPE == 3) {
-            if (S > 0) stage_next(0);
-            if (S > 1) stage_next(1);
-            if (S > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        if constexpr (PIPE >= 3) {
+            // N-stage ring: AHEAD = N-1 steps in flight while one is computed.  (A 4-stage instantiation -- 3 x 32 KB in flight
+            // per workgroup, meant for the HBM-bound 1x1 gradients that run on a few dozen workgroups -- was offered to the tuner
+            // in round 3 and won for NO problem of the target cfg: 1.02-1.15x the 2- / 3-stage time everywhere.  Not instantiated.)
+            constexpr int AHEAD = PIPE - 1;
+            constexpr int KEEP = (AHEAD - 1) * NPW;        // DMA instructions that may still be in flight per wave
+            static_assert(KEEP <= 63, "vmcnt range");
+#pragma unroll
+            for (int i = 0; i < AHEAD; ++i)
+                if (S > i) stage_next(i);
+            if (S >= AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            int cur = 0, nxt = 2;
+            int cur = 0, nxt = AHEAD;
             for (int s = 0; s < S; ++s) {
-                const bool more = (s + 2 < S);
+                const bool more = (s + AHEAD < S);
                 if (more) stage_next(nxt);
                 compute(sA + cur * A_BYTES, sB + cur * B_BYTES);
-                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                cur = (cur == 2) ? 0 : cur + 1;
-                nxt = (nxt == 2) ? 0 : nxt + 1;
+                cur = (cur == PIPE - 1) ? 0 : cur + 1;
+                nxt = (nxt == PIPE - 1) ? 0 : nxt + 1;
             }
         } else {
             if (S > 0) stage_next(0);

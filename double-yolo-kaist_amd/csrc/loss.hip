@@ -136,6 +136,26 @@ __global__ __launch_bounds__(256) void build_targets_kernel(DykTargetsDesc d) {
     if (threadIdx.x == 0) d.counts[h] = base;
 }
 
+// One element of nn.BCEWithLogitsLoss(pos_weight=pw, reduction='none') and its derivative, optionally wrapped in the
+// reference's FocalLoss (utils.py:184-194): loss *= alpha_factor * (1 - p_t)^gamma with p = sigmoid(x),
+// p_t = z p + (1 - z)(1 - p), alpha_factor = z alpha + (1 - z)(1 - alpha).  z may be a soft target (objectness: the
+// detached IoU ratio), exactly as the reference feeds it.  d/dx: af * (bce' * m + bce * m'),
+// m' = -gamma (1 - p_t)^(gamma - 1) (2z - 1) p (1 - p).
+__device__ inline void bce_elem(float x, float z, float pw, float gamma, float alpha, float& loss, float& grad) {
+    const float lw = 1.f + (pw - 1.f) * z;
+    const float l = (1.f - z) * x + lw * (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f));
+    const float s = sigmoidf_(x);
+    const float dl = s * (1.f - z + pw * z) - pw * z;
+    if (!(gamma > 0.f)) { loss = l; grad = dl; return; }
+    const float pt = z * s + (1.f - z) * (1.f - s);
+    const float af = z * alpha + (1.f - z) * (1.f - alpha);
+    const float q = 1.f - pt;
+    const float m = powf(q, gamma);
+    const float dm = -gamma * powf(q, gamma - 1.f) * (2.f * z - 1.f) * s * (1.f - s);
+    loss = l * af * m;
+    grad = af * (dl * m + l * dm);
+}
+
 // ---------------------------------------------------------------- matched-cell terms
 // acc layout per head: [0] sum(1-iou)  [1] valid matches  [2] sum obj BCE  [3] sum cls BCE
 __global__ __launch_bounds__(256) void match_loss_kernel(DykLossDesc d, DykTargetsDesc td) {
@@ -208,10 +228,10 @@ __global__ __launch_bounds__(256) void match_loss_kernel(DykLossDesc d, DykTarge
             const float inv_cls = inv_n / (float)nc;
             for (int c = 0; c < nc; ++c) {
                 const float x = ps[5 + c], z = (c == cls) ? 1.f : 0.f;
-                const float lw = 1.f + (d.cls_pw - 1.f) * z;
-                scls += (1.f - z) * x + lw * (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f));
-                const float s = sigmoidf_(x);
-                atomicAdd(g + 5 + c, d.hyp_cls * inv_cls * (s * (1.f - z + d.cls_pw * z) - d.cls_pw * z));
+                float l, dl;
+                bce_elem(x, z, d.cls_pw, d.fl_gamma, d.fl_alpha, l, dl);
+                scls += l;
+                atomicAdd(g + 5 + c, d.hyp_cls * inv_cls * dl);
             }
         }
     }
@@ -237,10 +257,10 @@ __global__ __launch_bounds__(256) void obj_loss_kernel(DykLossDesc d, int h, lon
     float s = 0.f;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < ncell; i += (long)gridDim.x * blockDim.x) {
         const float x = p[i * no + 4], z = tobj[i];
-        const float lw = 1.f + (pw - 1.f) * z;
-        s += (1.f - z) * x + lw * (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f));
-        const float sg = sigmoidf_(x);
-        dp[i * no + 4] = gscale * (sg * (1.f - z + pw * z) - pw * z);
+        float l, dl;
+        bce_elem(x, z, pw, d.fl_gamma, d.fl_alpha, l, dl);
+        s += l;
+        dp[i * no + 4] = gscale * dl;
     }
     __shared__ float ws[4];
     s = wave_sum(s);
@@ -297,6 +317,7 @@ extern "C" int dyk_yolo_loss(const DykLossDesc* d, const DykTargetsDesc* t, void
     if (rc) return rc;
     if (!d || d->nheads != t->nheads || !d->acc || !d->out || !d->flag || d->no < 5 || d->nc != d->no - 5 || d->B <= 0)
         return DYK_ERR_ARG;
+    if (!(d->fl_gamma >= 0.f) || (d->fl_gamma > 0.f && !(d->fl_alpha >= 0.f && d->fl_alpha <= 1.f))) return DYK_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     for (int h = 0; h < d->nheads; ++h) {
         if (!d->p[h] || !d->dp[h] || !d->tobj[h]) return DYK_ERR_ARG;

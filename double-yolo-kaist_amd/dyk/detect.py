@@ -81,8 +81,6 @@ class _LossFunction(torch.autograd.Function):
     def forward(ctx, model, targets, *p):
         m = _model_of(model)
         h = m.hyp
-        if h.get("fl_gamma", 0.0) > 0:
-            raise NotImplementedError("focal loss (fl_gamma > 0) is off in both reference hyp files and not built")
         dev = p[0].device
         ps = [pi.detach().float().contiguous() for pi in p]
         t, keep = _targets_desc([tuple(pi.shape) for pi in ps], targets.to(dev), model)
@@ -102,6 +100,8 @@ class _LossFunction(torch.autograd.Function):
         d.ciou = 1 if "ciou" in h else 0
         d.hyp_box, d.hyp_obj, d.hyp_cls = float(h["box"]), float(h["obj"]), float(h["cls"])
         d.cls_pw, d.obj_pw, d.gr = float(h["cls_pw"]), float(h["obj_pw"]), float(m.gr)
+        # focal loss around both BCE terms when hyp['fl_gamma'] > 0 (utils.py:236-238: FocalLoss(BCE, g), alpha at its default)
+        d.fl_gamma, d.fl_alpha = max(0.0, float(h.get("fl_gamma", 0.0))), 0.25
         acc = torch.empty(12, dtype=torch.float64, device=dev)
         out = torch.empty(3, dtype=torch.float32, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)

@@ -146,7 +146,8 @@ class DykTargetsDesc(ctypes.Structure):
 class DykLossDesc(ctypes.Structure):
     _fields_ = [("p", _vp * 3), ("dp", _vp * 3), ("tobj", _vp * 3), ("nheads", _i32), ("B", _i32), ("no", _i32),
                 ("nc", _i32), ("v4", _i32), ("ciou", _i32), ("hyp_box", _f32), ("hyp_obj", _f32), ("hyp_cls", _f32),
-                ("cls_pw", _f32), ("obj_pw", _f32), ("gr", _f32), ("acc", _vp), ("out", _vp), ("flag", _vp)]
+                ("cls_pw", _f32), ("obj_pw", _f32), ("gr", _f32), ("fl_gamma", _f32), ("fl_alpha", _f32),
+                ("acc", _vp), ("out", _vp), ("flag", _vp)]
 
 
 class DykOptimDesc(ctypes.Structure):

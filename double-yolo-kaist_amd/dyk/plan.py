@@ -26,6 +26,7 @@ FWD_SLOTS_CAP = int(os.environ.get("DYK_FWD_SLOTS_CAP", "32"))    # most replica
 # finalize rides on its normalise launch (42 launches of 9 us fewer on the forward chain of the target cfg: -0.2 ms in an A/B
 # against 256 replicas, round 3; the 10 240 tiles of a 256 x 320 layer then put 320 fp64 atomics on an address -- the backward
 # pass has always run such layers with 16 replicas)
+FWD_SLOT_WG = int(os.environ.get("DYK_FWD_SLOT_WG", "128"))        # conv workgroups per replica of a forward statistics buffer
 STAT_SLOTS = int(os.environ.get("DYK_STAT_SLOTS", "16"))   # replicas of every per-channel fp64 reduction buffer of the backward (bounds atomic
                                                             # contention; every apply workgroup folds them: 32 -> 16 measured -0.15 ms, 64 +0.4 ms)
 
@@ -410,7 +411,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 # replicas of the fp64 statistics accumulators: keep the atomics per address at a few dozen
                 tiles = (B * Ho * Wo + 127) // 128
                 # (about 32 workgroups per replica), few enough that the consumer folds them cheaply
-                slots = min(FWD_SLOTS_CAP, max(4, 1 << max(0, (tiles * max(1, (cout + 127) // 128) // 32 - 1).bit_length())))
+                slots = min(FWD_SLOTS_CAP, max(4, 1 << max(0, (tiles * max(1, (cout + 127) // 128) // FWD_SLOT_WG - 1).bit_length())))
                 if dw:
                     slots = 32                       # 32 replicas: the finalize then rides on the normalise pass (measured
                                                      # -0.3 ms per MobileNetV3 step against up to 256 replicas + own launch)
@@ -1397,7 +1398,7 @@ def _conv_candidates(d):
 
 
 _WGRAD_CANDIDATES = [2, 3, 2 | (2 << 8), 2 | (1 << 24), 3 | (1 << 24), 2 | (2 << 8) | (1 << 24), 2 | (1 << 28)]
-# LDS ring stages | K-groups per workgroup << 8 | tile cap << 24 (1 = 64 x 64) | 1 << 28 = multi-tap 3x3 kernel
+# LDS ring stages (2 | 3; 4 exists in the kernel, measured never the fastest: DESIGN 9.4) | K-groups per workgroup << 8 | tile cap << 24 (1 = 64 x 64) | 1 << 28 = multi-tap 3x3 kernel
 
 
 def _time_launch(fn, desc, stream, reps=3):
@@ -1525,6 +1526,8 @@ def autotune(plan, cache=None):
                     combos, times = [(0, 0)], [float("inf")]
                 else:
                     times = _refine(combos, times, lambda cc, reps: trial(cc[0], cc[1], reps))
+                    if os.environ.get("DYK_TUNE_VERBOSE"):
+                        print("tune", key, " ".join("%#x/%d:%.1f" % (c[0], c[1], 1e3 * t) for t, c in sorted(zip(times, combos))[:10]), flush=True)
                 d.part, d.part_stride, d.splits, d.dw = None, 0, 0, saved_dw
                 best = combos[times.index(min(times))]
             else:

@@ -501,7 +501,8 @@ def build(plan, store, which, start, end, n_streams=None):
     pairs = []
     twin_of = getattr(plan, "twin_layer", None)
     layer_of = getattr(plan, which + "_layer", None)
-    if twin_of and layer_of is not None and os.environ.get("DYK_PAIR", "0") != "0":
+    pair_which = os.environ.get("DYK_PAIR_WHICH", "both")      # "fwd" | "bwd" | "both": which pass of the step pairs its twins
+    if twin_of and layer_of is not None and os.environ.get("DYK_PAIR", "0") != "0" and pair_which in ("both", which):
         from . import twins
         pairs = twins.find_pairs(cmds, deps, layer_of[start:end], twin_of, plan, os.environ.get("DYK_PAIR_OPS", "ew"),
                                  1e6 * float(os.environ.get("DYK_PAIR_MAX_MB", "48")))

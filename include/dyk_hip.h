@@ -554,6 +554,8 @@ typedef struct DykLossDesc {
     int32_t v4;            /* box parameterisation: 'yolov4' in cfg (utils.py:252) */
     int32_t ciou;          /* 'ciou' in hyp (utils.py:264), else GIoU */
     float hyp_box, hyp_obj, hyp_cls, cls_pw, obj_pw, gr;
+    float fl_gamma;        /* hyp['fl_gamma'] > 0: both BCE terms wrapped in FocalLoss (utils.py:174-201, :236-238); 0 = plain BCE */
+    float fl_alpha;        /* FocalLoss alpha (utils.py:176 default 0.25; read only when fl_gamma > 0) */
     double* acc;           /* [12] scratch */
     float* out;            /* [3] */
     int32_t* flag;

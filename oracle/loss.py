@@ -78,13 +78,24 @@ def build_targets(pred_shapes, targets, anchor_vecs, iou_t):
 
 def compute_loss(p, targets, anchor_vecs, hyp, nc, gr, v4):
     """utils.py:209-293.  p: list of [B,na,ny,nx,5+nc] raw logits (fp32).  hyp needs box/obj/cls,
-    cls_pw, obj_pw, iou_t, fl_gamma (must be 0) and selects CIoU by the presence of key 'ciou'
-    (:264).  Returns dict of three [1] tensors."""
+    cls_pw, obj_pw, iou_t, fl_gamma (> 0: both BCE terms become focal, :236-238) and selects CIoU by the presence of
+    key 'ciou' (:264).  Returns dict of three [1] tensors."""
     lcls, lbox, lobj = torch.zeros(1), torch.zeros(1), torch.zeros(1)
     tcls, tbox, indices, anchors = build_targets([tuple(pi.shape) for pi in p], targets, anchor_vecs, hyp["iou_t"])
-    assert hyp.get("fl_gamma", 0.0) == 0.0, "focal loss is off in both reference hyp files"
     cls_pw = torch.tensor([hyp["cls_pw"]])
     obj_pw = torch.tensor([hyp["obj_pw"]])
+    gamma = float(hyp.get("fl_gamma", 0.0))
+
+    def bce(pred, true, pw):
+        """BCEWithLogitsLoss(pos_weight, 'mean') (:229-230); with fl_gamma > 0 wrapped as FocalLoss(.., gamma) does
+        (:184-197, alpha at its default 0.25 of :176): element loss * alpha_factor * (1 - p_t) ** gamma, then the mean"""
+        if gamma <= 0:
+            return F.binary_cross_entropy_with_logits(pred, true, pos_weight=pw)
+        el = F.binary_cross_entropy_with_logits(pred, true, pos_weight=pw, reduction="none")
+        prob = torch.sigmoid(pred)                                            # :190
+        p_t = true * prob + (1 - true) * (1 - prob)                           # :191
+        el = el * (true * 0.25 + (1 - true) * 0.75) * (1.0 - p_t) ** gamma    # :192-194
+        return el.mean()                                                      # :196-197
     for i, pi in enumerate(p):
         b, a, gj, gi = indices[i]
         tobj = torch.zeros_like(pi[..., 0])
@@ -104,6 +115,6 @@ def compute_loss(p, targets, anchor_vecs, hyp, nc, gr, v4):
             if nc > 1:                                          # :274-277
                 t = torch.full_like(ps[:, 5:], 0.0)
                 t[range(nb), tcls[i]] = 1.0
-                lcls = lcls + F.binary_cross_entropy_with_logits(ps[:, 5:], t, pos_weight=cls_pw)
-        lobj = lobj + F.binary_cross_entropy_with_logits(pi[..., 4], tobj, pos_weight=obj_pw)   # :283
+                lcls = lcls + bce(ps[:, 5:], t, cls_pw)           # :277
+        lobj = lobj + bce(pi[..., 4], tobj, obj_pw)             # :283
     return {"box_loss": lbox * hyp["box"], "obj_loss": lobj * hyp["obj"], "class_loss": lcls * hyp["cls"]}

@@ -83,6 +83,18 @@ def loss_cases():
     return out
 
 
+def focal_loss_cases():
+    """hyp['fl_gamma'] > 0 (reference utils.py:236-238: both BCE terms wrapped in FocalLoss) -- off in the two shipped hyp
+    files, so the fixture overrides it (loss_focal.npz, tests/golden/make_golden_round3b.py)"""
+    out = []
+    for (name, cfg, nc, hyp, gr, gamma) in [
+            ("v4_ciou_nc2_fl15", "kaist_dyolov4_fshare_global_concat_se3.cfg", 2, "hyp.scratch.4", 0.5, 1.5),
+            ("v3_giou_nc1_fl15", "kaist_yolov3.cfg", 1, "hyp.scratch", 1.0, 1.5),
+            ("v4_ciou_nc2_fl2", "kaist_dyolov4_fshare_global_concat_se3.cfg", 2, "hyp.scratch.4", 1.0, 2.0)]:
+        out.append(dict(name=name, cfg=cfg, nc=nc, hyp=hyp, gr=gr, fl_gamma=gamma, B=3, H=128, W=160, seed=len(out) + 61))
+    return out
+
+
 def loss_preds(case):
     g = torch.Generator().manual_seed(case["seed"])
     return [torch.randn(s, generator=g) * 1.5 for s in head_shapes(case["cfg"], case["B"], case["H"], case["W"], 5 + case["nc"])]

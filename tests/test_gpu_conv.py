@@ -434,7 +434,7 @@ def test_wgrad_plane_mode_and_grad_reduce(dtype):
     lib = L.load()
     plane = k * k * Cout * Cin
     outs = []
-    for tune in (2, 2 | (2 << 8), 2 | (1 << 24), 2 | (2 << 8) | (1 << 24)):   # 4-wave / K-grouped workgroups, 64x64 tile cap
+    for tune in (2, 3, 2 | (2 << 8), 2 | (1 << 24), 3 | (1 << 24), 2 | (2 << 8) | (1 << 24)):   # ring depth 2 / 3, K-grouped workgroups, 64x64 tile cap
         d.tune, d.splits, d.part = tune, 0, None
         splits = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
         assert splits >= 2

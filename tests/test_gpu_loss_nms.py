@@ -74,6 +74,25 @@ def test_compute_loss_value_and_gradient(case):
         assert np.abs(g[..., 5:]).max() == 0.0
 
 
+@pytest.mark.parametrize("case", cases.focal_loss_cases(), ids=lambda c: c["name"])
+def test_focal_loss_value_and_gradient(case):
+    """hyp['fl_gamma'] > 0 (reference utils.py:236-238: FocalLoss around both BCE terms, :174-201): loss terms and the
+    gradient w.r.t. every head tensor against the reference's own outputs (loss_focal.npz), fp32, 1e-5."""
+    from build_utils.utils import compute_loss
+    gold = np.load(os.path.join(GOLDEN, "loss_focal.npz"))
+    hyp = dict(cases.load_hyp(case["hyp"]), fl_gamma=case["fl_gamma"])
+    model = _fake_model(case["cfg"], case["nc"], hyp, case["gr"])
+    p = [t.cuda().requires_grad_(True) for t in cases.loss_preds(case)]
+    out = compute_loss(p, cases.loss_targets(case).cuda(), model)
+    got = np.array([out["box_loss"].item(), out["obj_loss"].item(), out["class_loss"].item()], np.float32)
+    assert np.allclose(got, gold[case["name"] + "|losses"], rtol=1e-5, atol=1e-6), (got, gold[case["name"] + "|losses"])
+    (out["box_loss"] + out["obj_loss"] + out["class_loss"]).backward()
+    for i, t in enumerate(p):
+        ref = gold[case["name"] + "|dp%d" % i]
+        err = np.abs(t.grad.cpu().numpy() - ref).max()
+        assert err <= 1e-5 * max(1.0, np.abs(ref).max()) + 1e-7, (i, err, np.abs(ref).max())
+
+
 def test_loss_out_of_grid_target_sets_flag():
     from build_utils.utils import compute_loss
     case = cases.loss_cases()[0]

@@ -54,6 +54,26 @@ def test_compute_loss_matches_reference(case):
         assert np.allclose(t.grad.numpy(), gold[case["name"] + "|dp%d" % i], rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("case", cases.focal_loss_cases(), ids=lambda c: c["name"])
+def test_focal_loss_matches_reference(case):
+    """hyp['fl_gamma'] > 0: both BCE terms wrapped in the reference's FocalLoss (utils.py:174-201, :236-238); fixture
+    loss_focal.npz = the reference's compute_loss on the same seeded inputs (tests/golden/make_golden_round3b.py)"""
+    gold = np.load(os.path.join(GOLDEN, "loss_focal.npz"))
+    av, v4 = _anchor_vecs(case["cfg"])
+    p = cases.loss_preds(case)
+    for t in p:
+        t.requires_grad_(True)
+    hyp = dict(cases.load_hyp(case["hyp"]), fl_gamma=case["fl_gamma"])
+    out = oloss.compute_loss(p, cases.loss_targets(case), av, hyp, case["nc"], case["gr"], v4)
+    got = np.array([out["box_loss"].item(), out["obj_loss"].item(), out["class_loss"].item()], np.float32)
+    assert np.allclose(got, gold[case["name"] + "|losses"], rtol=1e-6, atol=1e-7)
+    plain = np.load(os.path.join(GOLDEN, "loss.npz"))
+    (out["box_loss"] + out["obj_loss"] + out["class_loss"]).backward()
+    for i, t in enumerate(p):
+        assert np.allclose(t.grad.numpy(), gold[case["name"] + "|dp%d" % i], rtol=1e-5, atol=1e-8)
+    assert not np.allclose(got[1], plain["v4_ciou_nc2|losses"][1], rtol=1e-2)      # (the focal term really is on)
+
+
 @pytest.mark.parametrize("case", cases.nms_cases(), ids=lambda c: c["name"])
 def test_nms_matches_reference(case):
     gold = np.load(os.path.join(GOLDEN, "nms.npz"))

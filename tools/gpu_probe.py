@@ -258,6 +258,47 @@ if "bnbench" in what:
         print((H, W, c), "  ".join(out), flush=True)
     res["bnbench"] = rows
 
+if "bnfold" in what:
+    # where does a launch-bound BatchNorm pass spend its time?  fused finalize + normalise with 1 / 8 / 32 statistics replicas,
+    # the plain normalise pass (no fold) and an empty launch, on the small tensors of the deep stages
+    import ctypes as C
+    from dyk import lib as L
+    lib = L.load()
+    def timed(f, n=40):
+        for _ in range(5):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            f()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+    for (H, W, c) in [(32, 40, 256), (64, 80, 128), (16, 20, 512), (128, 160, 64)]:
+        B, dt = 16, torch.bfloat16
+        y = torch.randn(B, H, W, c, device="cuda").to(dt)
+        dz = torch.randn(B, H, W, c, device="cuda").to(dt)
+        z = torch.empty_like(y)
+        vec = [torch.rand(c, device="cuda") + 0.5 for _ in range(8)]
+        out = []
+        d0 = ops.ew_desc(a=y, out=z, act="leaky", p0=vec[0], p1=vec[1])
+        out.append("plain %.1f" % timed(lambda: lib.dyk_bn_act_fwd(C.byref(d0), None)))
+        for slots in (1, 8, 32):
+            stats = torch.rand(slots * 2 * c, dtype=torch.float64, device="cuda") * 1000 + 2000
+            f = L.DykBnFinalizeDesc()
+            f.stats, f.gamma, f.beta = stats.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr()
+            f.running_mean, f.running_var = vec[4].data_ptr(), vec[5].data_ptr()
+            f.scale, f.shift, f.save_mean, f.save_rstd = vec[0].data_ptr(), vec[1].data_ptr(), vec[6].data_ptr(), vec[7].data_ptr()
+            f.C, f.count, f.momentum, f.eps, f.slots = c, B * H * W, 0.03, 1e-4, slots
+            d = ops.ew_desc(a=y, out=z, act="leaky", p0=vec[0], p1=vec[1])
+            out.append("fused/%d %.1f" % (slots, timed(lambda: lib.dyk_bn_finalize_act_fwd(C.byref(f), C.byref(d), None))))
+        for slots in (1, 16):
+            red = torch.zeros(32 * 2 * c, dtype=torch.float64, device="cuda")
+            da = ops.ew_desc(a=dz, b=y, out=z, act="leaky", p0=vec[0], p1=vec[1], p2=vec[2], p3=vec[3], red=red)
+            da.slots = slots
+            out.append("apply/%d %.1f" % (slots, timed(lambda: lib.dyk_bn_act_bwd_apply(C.byref(da), None))))
+        print("bnfold", (H, W, c), " ".join(out), "us", flush=True)
+
 if "bnbwdablate" in what:
     # data gradient with the fused BN-backward-reduce epilogue against the same GEMM with the plain epilogue, per activation
     import ctypes as C
