@@ -12,7 +12,8 @@ inline int ew_grid(long total_vec) {
 inline int epv_of(int dtype) { return dtype == DYK_BF16 ? 8 : 4; }
 
 // ------------------------------------------------------------------ axpby
-// out = sa*a (+ sb*b), sa = alpha * (p0 ? p0[0] : 1), sb = beta * (p1 ? p1[0] : 1)
+// out = sa*a (+ sb*b), sa = alpha * (p0 ? p0[0] : 1), sb = beta * (p1 ? p1[0] : 1).  alpha == 0: `a` is NOT read (the term is an
+// exact zero whatever the buffer holds: how a gradient slice nobody has written yet is cleared)
 template <typename T>
 __global__ __launch_bounds__(256) void axpby_kernel(DykEwPair pr) {
     const DykEwDesc d = pr.d[blockIdx.z];          // a COPY, not a reference (see DykEwPair in dyk_common.h)
@@ -29,9 +30,14 @@ __global__ __launch_bounds__(256) void axpby_kernel(DykEwPair pr) {
         const long p = v / CV;
         const int c = (int)(v - p * CV) * EPV;
         float x[EPV];
-        vec_unpack<T>(*(const uint4*)(a + p * d.lda + c), x);
+        if (d.alpha != 0.f) {
+            vec_unpack<T>(*(const uint4*)(a + p * d.lda + c), x);
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) x[j] *= sa;
+            for (int j = 0; j < EPV; ++j) x[j] *= sa;
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) x[j] = 0.f;
+        }
         if (b) {
             float y[EPV];
             vec_unpack<T>(*(const uint4*)(b + p * d.ldb + c), y);

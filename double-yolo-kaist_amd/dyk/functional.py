@@ -44,7 +44,8 @@ def concat(tensors):
 
 
 def weighted_fusion(x, others, w, n):
-    """WeightedFeatureFusion.forward (reference layers.py:63-85), equal channel counts"""
+    """WeightedFeatureFusion.forward (reference layers.py:63-85); with mismatched channel counts the sum covers the first
+    min(nx, na) channels and the output keeps x's channel count (:78-83)"""
     xd = _nhwc(x)
     weff = None
     if w is not None:
@@ -52,13 +53,18 @@ def weighted_fusion(x, others, w, n):
         check(load().dyk_wfuse_weights(w.detach().float().contiguous().data_ptr(), weff.data_ptr(), n, _stream()))
     out = xd
     for i, a in enumerate(others):
-        if a.shape[1] != x.shape[1]:
-            raise NotImplementedError("WeightedFeatureFusion with mismatched channel counts")
         ad = _nhwc(a)
+        nx, na = xd.shape[3], ad.shape[3]
+        C = min(nx, na)
+        vec = 16 // xd.element_size()
+        if nx != na and (C % vec or abs(nx - na) % vec):
+            raise NotImplementedError("WeightedFeatureFusion with channel counts %d / %d that are not whole 16-byte vectors" % (nx, na))
         nxt = torch.empty_like(xd)
-        d = ops.ew_desc(a=out, b=ad, out=nxt, p0=weff[0:1] if (weff is not None and i == 0) else None,
-                        p1=weff[i + 1:i + 2] if weff is not None else None)
+        w0 = weff[0:1] if (weff is not None and i == 0) else None
+        d = ops.ew_desc(a=out[..., :C], b=ad[..., :C], out=nxt[..., :C], p0=w0, p1=weff[i + 1:i + 2] if weff is not None else None)
         ops.call("dyk_axpby", d)
+        if nx > na:                                            # the rest of x passes through (scaled by w[0] on the first term)
+            ops.call("dyk_axpby", ops.ew_desc(a=out[..., C:], out=nxt[..., C:], p0=w0))
         out = nxt
     return ops.to_nchw(out)
 

@@ -27,6 +27,7 @@ FWD_SLOTS_CAP = int(os.environ.get("DYK_FWD_SLOTS_CAP", "32"))    # most replica
 # against 256 replicas, round 3; the 10 240 tiles of a 256 x 320 layer then put 320 fp64 atomics on an address -- the backward
 # pass has always run such layers with 16 replicas)
 FWD_SLOT_WG = int(os.environ.get("DYK_FWD_SLOT_WG", "128"))        # conv workgroups per replica of a forward statistics buffer
+DW_SLOTS = int(os.environ.get("DYK_DW_SLOTS", "32"))                # replicas of a depthwise conv's forward statistics buffer
 STAT_SLOTS = int(os.environ.get("DYK_STAT_SLOTS", "16"))   # replicas of every per-channel fp64 reduction buffer of the backward (bounds atomic
                                                             # contention; every apply workgroup folds them: 32 -> 16 measured -0.15 ms, 64 +0.4 ms)
 
@@ -413,7 +414,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 # (about 32 workgroups per replica), few enough that the consumer folds them cheaply
                 slots = min(FWD_SLOTS_CAP, max(4, 1 << max(0, (tiles * max(1, (cout + 127) // 128) // FWD_SLOT_WG - 1).bit_length())))
                 if dw:
-                    slots = 32                       # 32 replicas: the finalize then rides on the normalise pass (measured
+                    slots = DW_SLOTS                 # 32 replicas: the finalize then rides on the normalise pass (measured
                                                      # -0.3 ms per MobileNetV3 step against up to 256 replicas + own launch)
                 stats = st_arena.alloc(slots * 2 * cout * 8)   # fp64 replicas; the whole arena is zeroed at the start of a pass
                 vecs = new_ws(4 * cout * 4)          # scale | shift | mean | rstd
@@ -600,13 +601,22 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             if len(layers) != 1:
                 raise NotImplementedError("[shortcut] with %d sources" % len(layers))
             a = outs[layers[0]]
-            C = min(x_in.C, a.C)
-            if x_in.C != a.C:
-                raise NotImplementedError("[shortcut] with mismatched channel counts (layer %d)" % i)
+            # Mismatched channel counts (reference layers.py:78-83): the sum covers the first min(nx, na) channels; the output
+            # keeps x's channel count (nx > na: the rest of x passes through -- the unweighted reference writes that case into x
+            # IN PLACE, which also changes a routed copy of the previous layer's output; a plan whose previous layer is routed
+            # is refused rather than silently diverging).  Channel runs must be whole 16-byte vectors.
+            nx, na = x_in.C, a.C
+            C = min(nx, na)
+            if nx != na:
+                vec = 16 // es
+                if C % vec or abs(nx - na) % vec:
+                    raise NotImplementedError("[shortcut] with channel counts %d / %d that are not whole 16-byte vectors (layer %d)" % (nx, na, i))
+                if nx > na and not mod.weight and i > 0 and model.routs[i - 1]:      # (weighted: x * w[0] is a new tensor there)
+                    raise NotImplementedError("[shortcut] narrower than its routed input (layer %d): the reference adds in place" % i)
             consume(x_in)
             consume(a)
             prev = info[i - 1] if i > 0 else {}
-            fusable = (not mod.weight and prev.get("kind") == "conv" and prev.get("bn") and prev.get("z") is x_in
+            fusable = (not mod.weight and nx == na and prev.get("kind") == "conv" and prev.get("bn") and prev.get("z") is x_in
                        and not model.routs[i - 1] and a is not x_in
                        and ("bn_act_desc" in prev or "conv_desc" in prev) and not os.environ.get("DYK_DEBUG_PLAN"))
             if fusable:
@@ -628,6 +638,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 info.append(rec)
                 continue
             z = new_act(B, x_in.H, x_in.W, x_in.C)
+            xs, asl, zs = (x_in, a, z) if nx == na else (x_in.chan_slice(0, C), a.chan_slice(0, C), z.chan_slice(0, C))
+            rest = (x_in.chan_slice(na, nx - na), z.chan_slice(na, nx - na)) if nx > na else None
             if mod.weight:
                 weff = new_ws(16)
                 wd = misc()
@@ -635,12 +647,18 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 wd.i[0] = 2
                 later(lambda wd=wd, weff=weff: wd.p.__setitem__(1, ws.ptr(weff)))
                 plan.fwd.append((L.OP_WFUSE_WEIGHTS, wd))
-                e = ew_desc(a=x_in, b=a, out=z, C=C)
+                e = ew_desc(a=xs, b=asl, out=zs, C=C)
                 later(lambda e=e, weff=weff: (setattr(e, "p0", ws.ptr(weff)), setattr(e, "p1", ws.ptr(weff + 4))))
                 plan.fwd.append((L.OP_AXPBY, e))
+                if rest:
+                    e = ew_desc(a=rest[0], out=rest[1], C=nx - na)
+                    later(lambda e=e, weff=weff: setattr(e, "p0", ws.ptr(weff)))
+                    plan.fwd.append((L.OP_AXPBY, e))
                 rec.update(weighted=True, weff=weff)
             else:
-                plan.fwd.append((L.OP_AXPBY, ew_desc(a=x_in, b=a, out=z, C=C)))
+                plan.fwd.append((L.OP_AXPBY, ew_desc(a=xs, b=asl, out=zs, C=C)))
+                if rest:
+                    plan.fwd.append((L.OP_AXPBY, ew_desc(a=rest[0], out=rest[1], C=nx - na)))
                 rec.update(weighted=False)
             rec.update(x=x_in, a=a, z=z)
             cur = z
@@ -1061,12 +1079,29 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                         continue
                     plan.bwd.append((L.OP_AXPBY, ew_desc(a=dz, out=gref(a), flags=acc_flag(a))))
                     continue
+                # mismatched channel counts: x gets dz whole; a gets the first min(nx, na) channels of dz, and zeros in its
+                # remaining channels when this is the first gradient written into it (nx < na)
+                nx, na = x_in.C, a.C
+                Cm = min(nx, na)
+                dza = dz if nx <= na else dz.chan_slice(0, Cm)
+
+                def a_grad(p0_off=None):
+                    ga = gref(a)
+                    first = a.tid not in ginit
+                    e = ew_desc(a=dza, out=ga if nx >= na else ga.chan_slice(0, Cm), C=Cm, flags=acc_flag(a))
+                    if p0_off is not None:
+                        later(lambda e=e, p0_off=p0_off: setattr(e, "p0", ws.ptr(p0_off)))
+                    plan.bwd.append((L.OP_AXPBY, e))
+                    if nx < na and first:
+                        tail = ga.chan_slice(nx, na - nx)
+                        plan.bwd.append((L.OP_AXPBY, ew_desc(a=tail, out=tail, C=na - nx, alpha=0.0)))     # alpha = 0: `a` is not read
+
                 if rec["weighted"]:
                     red = new_red(16)
                     d0 = ew_desc(a=dz, b=x_in)
                     later(lambda d0=d0, red=red: setattr(d0, "red", ws.ptr(red)))
                     plan.bwd.append((L.OP_DOT, d0))
-                    d1 = ew_desc(a=dz, b=a)
+                    d1 = ew_desc(a=dza, b=a if nx >= na else a.chan_slice(0, Cm), C=Cm)
                     later(lambda d1=d1, red=red: setattr(d1, "red", ws.ptr(red + 8)))
                     plan.bwd.append((L.OP_DOT, d1))
                     pm = misc()
@@ -1075,15 +1110,13 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     later(lambda pm=pm, red=red: pm.p.__setitem__(1, ws.ptr(red)))
                     plan.bwd.append((L.OP_WFUSE_BWD_PARAMS, pm))
                     weff = rec["weff"]
-                    for (tgt, woff) in ((x_in, weff), (a, weff + 4)):
-                        g = gref(tgt)
-                        e = ew_desc(a=dz, out=g, flags=acc_flag(tgt))
-                        later(lambda e=e, woff=woff: setattr(e, "p0", ws.ptr(woff)))
-                        plan.bwd.append((L.OP_AXPBY, e))
+                    e = ew_desc(a=dz, out=gref(x_in), flags=acc_flag(x_in))
+                    later(lambda e=e, weff=weff: setattr(e, "p0", ws.ptr(weff)))
+                    plan.bwd.append((L.OP_AXPBY, e))
+                    a_grad(weff + 4)
                 else:
-                    for tgt in (x_in, a):
-                        g = gref(tgt)
-                        plan.bwd.append((L.OP_AXPBY, ew_desc(a=dz, out=g, flags=acc_flag(tgt))))
+                    plan.bwd.append((L.OP_AXPBY, ew_desc(a=dz, out=gref(x_in), flags=acc_flag(x_in))))
+                    a_grad()
             elif t == "se":
                 z = rec["z"]
                 if z.tid not in ginit:

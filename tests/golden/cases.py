@@ -95,6 +95,12 @@ def focal_loss_cases():
     return out
 
 
+def mismatch_inputs():
+    """seeded image pair of the mismatched-channel [shortcut] fixture (mismatch.npz)"""
+    g = torch.Generator().manual_seed(77)
+    return torch.rand(2, 3, 32, 64, generator=g), torch.rand(2, 3, 32, 64, generator=g)
+
+
 def loss_preds(case):
     g = torch.Generator().manual_seed(case["seed"])
     return [torch.randn(s, generator=g) * 1.5 for s in head_shapes(case["cfg"], case["B"], case["H"], case["W"], 5 + case["nc"])]

@@ -136,6 +136,37 @@ def test_axpby_dot_wfuse(dtype):
     _close(ops.to_nchw(da).cpu(), ar.grad, tol, "da")
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_weighted_fusion_module_with_mismatched_channels(weighted):
+    """WeightedFeatureFusion.forward called as a module (inference path of build_utils/layers.py) on tensors of different channel
+    counts: the reference's three branches (layers.py:78-83), restated functionally; alpha = 0 of dyk_axpby never reads `a`."""
+    from build_utils.layers import WeightedFeatureFusion
+    from dyk import ops
+    g = torch.Generator().manual_seed(9)
+    outs = [torch.randn(2, 64, 6, 10, generator=g), torch.randn(2, 32, 6, 10, generator=g), torch.randn(2, 48, 6, 10, generator=g)]
+    for xi, layers in [(0, [1]), (1, [0]), (2, [0, 1]), (0, [2, 1])]:
+        mod = WeightedFeatureFusion(layers, weight=weighted)
+        if weighted:
+            with torch.no_grad():
+                mod.w.copy_(torch.tensor([0.4, -0.6, 1.1][:mod.n]))
+        x = outs[xi]
+        ref = x.clone()
+        if weighted:
+            w = torch.sigmoid(mod.w.detach()) * (2 / mod.n)
+            ref = ref * w[0]
+        for q, j in enumerate(layers):
+            a = outs[j] * w[q + 1] if weighted else outs[j]
+            n = min(ref.shape[1], a.shape[1])
+            ref = torch.cat((ref[:, :n] + a[:, :n], ref[:, n:]), 1)
+        with torch.no_grad():
+            got = mod.cuda()(x.cuda(), [o.cuda() for o in outs])
+        assert got.shape == x.shape
+        _close(got.cpu(), ref, 1e-5, "fusion %d <- %s" % (xi, layers))
+    nan = torch.full((2, 6, 10, 32), float("nan"), device="cuda")
+    ops.call("dyk_axpby", ops.ew_desc(a=nan, out=nan, alpha=0.0))
+    assert nan.abs().max().item() == 0.0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_upsample_maxpool(dtype):
     from dyk import ops

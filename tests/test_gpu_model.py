@@ -425,3 +425,43 @@ def test_eval_pipeline_forward_nms_scale_ap():
     assert out["recall"][-1] == 1.0 and len(out["recall"]) == len(preds)
     assert 0.0 < out["ap"] <= 1.0 and 0.0 <= out["lamr"] <= 1.0
     assert int(round(out["recall"][-1] * nt)) == nt
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_mismatched_channel_shortcuts_match_reference(dtype):
+    """[shortcut] between tensors of different channel counts (reference layers.py:78-83): the plan sums the first
+    min(nx, na) channels, passes the rest of x through, and routes the gradients accordingly (zeros into the channels of `a`
+    the sum never read).  Against the reference's own outputs and parameter-gradient checksums on the tiny cfg
+    (tests/golden/mismatch.npz); bf16 at bf16 tolerances."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import cases
+    from build_utils.parse_config import parse_model_cfg
+    from models import YOLO
+    from oracle.model import OracleNet
+    cfg = os.path.join(GOLDEN, "tiny_kaist_mismatch.cfg")
+    gold = np.load(os.path.join(GOLDEN, "mismatch.npz"))
+    sd = OracleNet(parse_model_cfg(cfg), cfg).synth_state(3)
+    sd["module_list.5.w"] = torch.tensor([0.3, -0.8])
+    torch.manual_seed(0)
+    m = YOLO(cfg)
+    m.load_state_dict(sd)
+    m.dyk_dtype = dtype
+    m = m.cuda()
+    x, y = cases.mismatch_inputs()
+    tol = 2e-4 if dtype == "fp32" else 4e-2
+    m.eval()
+    with torch.no_grad():
+        io_, p = m(x.cuda(), y.cuda())
+    assert _rel(p[0].cpu().numpy(), gold["eval_p0"]) < tol and _rel(io_.cpu().numpy(), gold["eval_io"]) < tol
+    m.train()
+    out = m(x.cuda(), y.cuda())
+    assert _rel(out[0].detach().cpu().numpy(), gold["train_p0"]) < (1e-3 if dtype == "fp32" else 6e-2)
+    loss = sum((t ** 2).mean() for t in out)
+    assert abs(loss.item() - float(gold["train_loss"])) < (2e-4 if dtype == "fp32" else 3e-2) * float(gold["train_loss"])
+    loss.backward()
+    got = np.array([[q.grad.abs().sum().item(), q.grad.sum().item()] for _, q in m.named_parameters()])
+    assert got.shape == gold["grad_sums"].shape
+    gt = 5e-3 if dtype == "fp32" else 8e-2
+    assert np.allclose(got[:, 0], gold["grad_sums"][:, 0], rtol=gt, atol=1e-6), np.abs(got[:, 0] / np.maximum(gold["grad_sums"][:, 0], 1e-12) - 1).max()
+    assert np.allclose(m.module_list[5].w.grad.cpu().numpy(), gold["grad_w5"], rtol=gt, atol=1e-5)

@@ -167,9 +167,10 @@ num=3
 
 
 def test_strided_maxpool_compiles_and_unsupported_sections_fail_loudly(tmp_path):
-    """stride-2 [maxpool] (models.py:91-94: MaxPool2d(k, stride, padding=(k-1)//2)) is built; cfg features outside the
-    built path (here: a [shortcut] between tensors of different channel counts, layers.py:78-83) raise instead of
-    computing something else"""
+    """stride-2 [maxpool] (models.py:91-94: MaxPool2d(k, stride, padding=(k-1)//2)) is built; a [shortcut] between tensors of
+    different channel counts (layers.py:78-83) compiles into slice commands; what is outside the built path (here: the
+    unweighted in-place form of that shortcut on a ROUTED input, which in the reference also rewrites the routed copy) raises
+    instead of computing something else"""
     from dyk import lib as L
     from dyk.params import ParamStore
     from dyk.plan import compile_plan
@@ -189,8 +190,21 @@ def test_strided_maxpool_compiles_and_unsupported_sections_fail_loudly(tmp_path)
     m2 = YOLO(str(bad))
     st2 = ParamStore(m2)
     st2.adopt(torch.device("cpu"))
+    plan2 = compile_plan(m2, st2, 1, 64, 64, torch.bfloat16, True, torch.device("cpu"), dry=True)   # 32 + 64 -> 32 channels
+    assert [(d.C, d.lda, d.ldb, d.ldo) for op, d in plan2.fwd if op == L.OP_AXPBY] == [(32, 32, 64, 32)]
+    # backward: dz -> x (32 channels), dz -> first 32 channels of the 64-channel tensor, and -- the [shortcut] being the first
+    # writer of that gradient -- zeros (alpha = 0: nothing read) into its other 32 channels
+    ax = [d for op, d in plan2.bwd if op == L.OP_AXPBY]
+    assert [(d.C, d.alpha) for d in ax] == [(32, 1.0), (32, 1.0), (32, 0.0)] and ax[2].ldo == 64 and ax[2].out == ax[1].out + 32 * 2
+    aliased = tmp_path / "tiny_kaist_aliasshortcut.cfg"
+    aliased.write_text(TINY_MAXPOOL_CFG % ("[convolutional]\nbatch_normalize=1\nfilters=32\nsize=1\nstride=1\npad=1\nactivation=leaky\n\n"
+                                           "[convolutional]\nbatch_normalize=1\nfilters=64\nsize=1\nstride=1\npad=1\nactivation=leaky\n\n"
+                                           "[shortcut]\nfrom=-2\nactivation=linear\n\n[route]\nlayers=-2\n\n"))
+    m3 = YOLO(str(aliased))
+    st3 = ParamStore(m3)
+    st3.adopt(torch.device("cpu"))
     with pytest.raises(NotImplementedError):
-        compile_plan(m2, st2, 1, 64, 64, torch.bfloat16, False, torch.device("cpu"), dry=True)
+        compile_plan(m3, st3, 1, 64, 64, torch.bfloat16, False, torch.device("cpu"), dry=True)
 
 
 @pytest.mark.parametrize("name", [C5, MNV2])

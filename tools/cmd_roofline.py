@@ -90,12 +90,13 @@ def main():
     for k, a in sorted(fam.items(), key=lambda kv: -(kv[1][1] - kv[1][2])):
         print("%-22s %5d %10.1f %10.1f %9.1f %8.2f %8.1f" % (k, a[0], a[1], a[2], a[1] - a[2], a[3] / max(a[1], 1e-9) / 1e6,
                                                           a[4] / max(a[1], 1e-9) / 1e6))
-    print("\ntop 40 commands by time above floor")
+    top = int(__import__("os").environ.get("DYK_ROOFLINE_TOP", "40"))      # (all commands: DYK_ROOFLINE_TOP=1000)
+    print("\ntop %d commands by time above floor" % top)
     agg = collections.OrderedDict()
     for r in rows:
         a = agg.setdefault((r["pass"], r["label"]), [0, 0.0, 0.0, r])
         a[0] += 1; a[1] += r["us"]; a[2] += r["floor"]
-    for (p, lab), a in sorted(agg.items(), key=lambda kv: -(kv[1][1] - kv[1][2]))[:40]:
+    for (p, lab), a in sorted(agg.items(), key=lambda kv: -(kv[1][1] - kv[1][2]))[:top]:
         r = a[3]
         print("%-3s %-46s n=%3d us %8.1f floor %7.1f  (%.2f TB/s, %.0f TF/s)" % (
             p, lab, a[0], a[1], a[2], r["bytes"] / max(r["us"], 1e-9) / 1e6, r["flops"] / max(r["us"], 1e-9) / 1e6))
