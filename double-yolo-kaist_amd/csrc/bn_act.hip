@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(DykEwPair pr, int CVB) 
         for (int u = 0; u < U; ++u) {
             const long p = p0 + u * pstep;
             if (p < d.npix) {
-                vx[u] = *(const uint4*)(a + p * d.lda + c);
+                vx[u] = ld_stream16(a + p * d.lda + c);
                 if (r) vr[u] = *(const uint4*)(r + p * d.ldb + c);
             }
         }
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(DykFinPair fp, DykEwP
         for (int u = 0; u < U; ++u) {
             const long p = p0 + u * pstep;
             if (p < d.npix) {
-                vx[u] = *(const uint4*)(a + p * d.lda + c);
+                vx[u] = ld_stream16(a + p * d.lda + c);
                 if (r) vr[u] = *(const uint4*)(r + p * d.ldb + c);
             }
         }
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(DykEwPair pr, in
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const long p = p0 + u * pstep;
-                if (p < d.npix) { vg[u] = *(const uint4*)(dz + p * d.lda + c); vy[u] = *(const uint4*)(y + p * d.ldb + c); }
+                if (p < d.npix) { vg[u] = ld_stream16(dz + p * d.lda + c); vy[u] = ld_stream16(y + p * d.ldb + c); }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -356,8 +356,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwPair pr, int
         for (int u = 0; u < U; ++u) {
             const long p = p0 + u * pstep;
             if (p < d.npix) {
-                vg[u] = *(const uint4*)(dz + p * d.lda + c);
-                vy[u] = *(const uint4*)(y + p * d.ldb + c);
+                vg[u] = ld_stream16(dz + p * d.lda + c);
+                vy[u] = ld_stream16(y + p * d.ldb + c);
                 if (accum) vo[u] = *(const uint4*)(o + p * d.ldo + c);
             }
         }

@@ -67,6 +67,21 @@ template <> struct ElemTraits<float> {
 };
 
 // 16-byte vector <-> EPV floats
+// 16-byte load of a READ-ONCE stream (the raw conv outputs and gradients the BatchNorm passes walk): nontemporal, so that the
+// lines do not displace what other kernels re-read through the L2 (weights, activation tiles under nine taps).  Round 3,
+// in-call A/B of the whole C3 step, six interleaved runs each: plain 32.21 ms, BatchNorm passes nontemporal 31.93 ms; the same
+// hint on the optimizer state, the partial planes, axpby and the raw-output loads of the fused BatchNorm-backward epilogue
+// 32.03 ms (no further gain: not adopted); nontemporal STORES changed nothing.  -DDYK_NO_NT builds the plain form.
+typedef unsigned dyk_v4u_t __attribute__((ext_vector_type(4)));
+__device__ inline uint4 ld_stream16(const void* p) {
+#ifdef DYK_NO_NT
+    return *(const uint4*)p;
+#else
+    return __builtin_bit_cast(uint4, __builtin_nontemporal_load((const dyk_v4u_t*)p));
+#endif
+}
+__device__ inline float4 ld_stream_f4(const void* p) { return __builtin_bit_cast(float4, ld_stream16(p)); }
+
 template <typename T> __device__ inline void vec_unpack(const uint4& v, float* out);
 template <> __device__ inline void vec_unpack<bf16_t>(const uint4& v, float* out) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};

@@ -477,7 +477,7 @@ def build(plan, store, which, start, end, n_streams=None):
     """schedule of commands [start, end) of the plan's forward / backward list"""
     cmds = (plan.fwd if which == "fwd" else plan.bwd)[start:end]
     if n_streams is None:
-        n_streams = int(os.environ.get("DYK_STREAMS", "4"))
+        n_streams = int(os.environ.get("DYK_STREAMS_" + which.upper(), os.environ.get("DYK_STREAMS", "4")))
     mem = Memory(plan, store)
     deps = dependencies(cmds, mem, plan)
     costs = [estimate_cost_us(op, d, plan) for op, d in cmds]
