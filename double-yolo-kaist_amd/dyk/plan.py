@@ -1485,7 +1485,7 @@ def autotune(plan, cache=None):
     for (op, d) in plan.fwd + plan.bwd:
         if op == L.OP_CONV:
             key = ("c", d.dtype, d.B, d.Cin, d.Cout, d.Hg, d.Wg, d.ntaps, d.isy, d.osy,
-                   d.flags & (L.EPI_STATS | L.EPI_OUT_F32 | L.EPI_BNBWD), d.ncls)
+                   d.flags & (L.EPI_STATS | L.EPI_OUT_F32 | L.EPI_BNBWD | (L.EPI_ADDEND if os.environ.get("DYK_TUNE_KEY_ADDEND", "1") != "0" else 0)), d.ncls)
         elif op == L.OP_WGRAD:
             key = ("w", d.dtype, d.B, d.Cin, d.Cout, d.Ho, d.Wo, d.ntaps, d.isy)
         else:
