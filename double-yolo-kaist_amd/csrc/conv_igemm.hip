@@ -22,6 +22,16 @@ static int conv_validate(const DykConvDesc* d) {
     if ((d->flags & DYK_EPI_STATS) && !d->stats) return DYK_ERR_ARG;
     if ((d->flags & DYK_EPI_RESIDUAL) && !d->res) return DYK_ERR_ARG;
     if ((d->flags & DYK_EPI_ADDEND) && (!(d->flags & DYK_EPI_BNBWD) || !d->add || ((uintptr_t)d->add % 16))) return DYK_ERR_ARG;
+    if (d->flags & DYK_EPI_BNFWD) {
+        // conv + BatchNorm + activation in one launch: statistics on, bf16, one problem, whole 16-byte channel chunks
+        if (!(d->flags & DYK_EPI_STATS) || (d->flags & (DYK_EPI_AFFINE | DYK_EPI_ACCUM | DYK_EPI_OUT_F32 | DYK_EPI_BNBWD | DYK_EPI_ADDEND)))
+            return DYK_ERR_ARG;
+        if (d->dtype != DYK_BF16 || d->twin || d->ncls > 1 || d->bn_count <= 0) return DYK_ERR_ARG;
+        if (!d->y2 || !d->bn_counter || !d->scale || !d->shift || ((uintptr_t)d->y2 % 16) || ((uintptr_t)d->bn_counter % 8)) return DYK_ERR_ARG;
+        if (d->Cout % 8 || d->ldy % 8 || d->ldy2 % 8 || d->ldy2 < d->Cout) return DYK_ERR_ARG;
+        if ((d->flags & DYK_EPI_RESIDUAL) && (d->ldr % 4 || ((uintptr_t)d->res % 8))) return DYK_ERR_ARG;
+        if ((long)d->B * d->Ho * d->Wo * d->ldy2 >= (1L << 31)) return DYK_ERR_ARG;
+    }
     if (d->flags & DYK_EPI_BNBWD) {
         if (d->flags & (DYK_EPI_AFFINE | DYK_EPI_RESIDUAL | DYK_EPI_STATS | DYK_EPI_ACCUM | DYK_EPI_OUT_F32)) return DYK_ERR_ARG;
         if (!d->res || !d->stats || !d->scale || !d->shift || !d->aux0 || !d->aux1) return DYK_ERR_ARG;
@@ -52,6 +62,11 @@ extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     const int tile = d->dtype == DYK_BF16 ? (d->tune >> 12) & 0xf : 0;      // 80 / 160 pixel tiles are built for bf16 only
+    if (d->flags & DYK_EPI_BNFWD) {        // generic tiles only (the halo / K-grouped kernels do not carry this epilogue)
+        if (tile == 1 || tile == 3) return dyk_conv_launch_n80(d, s);
+        if (tile == 2 || tile == 4) return dyk_conv_launch_n160(d, s);
+        return dyk_conv_launch_n128(d, s);
+    }
     if (((d->tune >> 28) & 7) == 1) {      // K-grouped workgroups (conv_igemm_kg.hip); generic tiles where they do not apply
         const int rc = dyk_conv_launch_kg(d, s);
         if (rc != DYK_ERR_UNSUPPORTED) return rc;
@@ -64,4 +79,19 @@ extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
     if (tile == 1) return dyk_conv_launch_n80(d, s);
     if (tile == 2) return dyk_conv_launch_n160(d, s);
     return dyk_conv_launch_n128(d, s);
+}
+
+extern "C" int dyk_conv_bnfwd_max_grid(void) { return 256; }
+
+// workgroups of the generic-tile launch of `d` (the tile selection of dispatch_conv_bn; halo / K-grouped launches differ)
+extern "C" int dyk_conv_grid(const DykConvDesc* d) {
+    if (!d || d->B <= 0 || d->Hg <= 0 || d->Wg <= 0 || d->Cout <= 0) return DYK_ERR_ARG;
+    const int tile = d->dtype == DYK_BF16 ? (d->tune >> 12) & 0xf : 0;
+    const int bn = (tile == 1 || tile == 3) ? 80 : ((tile == 2 || tile == 4) ? 160 : 128);
+    int bm = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
+    const int bm_code = (d->tune >> 24) & 0xf;
+    if (bm_code >= 1 && bm_code <= 3) bm = 16 << bm_code;
+    if (bn == 80 && bm == 32) bm = 64;
+    const long n = (long)d->B * d->Hg * d->Wg;
+    return (int)((n + bn - 1) / bn) * ((d->Cout + bm - 1) / bm) * (d->ncls > 1 ? d->ncls : 1);
 }

@@ -46,6 +46,9 @@ __device__ inline int conv_pick_problem(const ConvArgs& args, int& blk, int& nbl
     return sel;
 }
 
+// largest DYK_EPI_BNFWD launch: with <= 80 KB of LDS and a two-wave register budget two such launches are resident together
+constexpr int DYK_BNFWD_MAX_GRID = 256;
+
 // set by the launcher when y / ldy allow 8/16-byte vector stores
 constexpr int EPI_INTERNAL_VEC = 1 << 30;
 
@@ -115,12 +118,16 @@ template <int BN> constexpr int table_bytes() { return BN * (3 * 4 + 2 * 2) + 10
 // Shared epilogue of the convolution kernels: BN statistics, affine / activation / residual / accumulate, staged
 // coalesced stores.  Called by every thread after the K loop's last barrier (the operand ring is free: sC overlays it).
 // EPIK = 0: forward / plain data-gradient epilogues (statistics, affine, activation, residual, accumulate);
-// EPIK = 1: the fused BatchNorm-backward epilogues (DYK_EPI_BNBWD).  Separate kernel instantiations: with both families in
+// EPIK = 1: the fused BatchNorm-backward epilogues (DYK_EPI_BNBWD);
+// EPIK = 3: conv + train-mode BatchNorm + activation in one launch (DYK_EPI_BNFWD: statistics, device-wide arrival counter, fold,
+//           normalise from the accumulators; bf16; `pub` = this workgroup publishes the BatchNorm vectors of its channels).
+// Separate kernel instantiations: with both families in
 // one kernel the 128 x 160 tile spilled 320-350 VGPRs (272-332 bytes of scratch per lane, also paid by the forward launches:
 // +0.4 ms per step over all forward convolutions when the LDS-DMA form of the BatchNorm-backward epilogue was added).
 template <typename T, int BM, int BN, int EPIK = 0>
 __device__ __forceinline__ void conv_epilogue(const DykConvDesc& desc, f32x4_t (&acc)[(BM / WaveGrid<BM, BN>::WM) / 16][(BN / WaveGrid<BM, BN>::WN) / 16],
-                                              char* sC, float* s_stat, const int* t_out, const int* t_res, int m0, int blk) {
+                                              char* sC, float* s_stat, const int* t_out, const int* t_res, int m0, int blk,
+                                              bool pub = false, unsigned nblk = 0) {
     // The descriptor fields this epilogue uses, in SGPRs: read through the kernel-argument reference they are re-loaded
     // (s_load + s_waitcnt lgkmcnt(0)) behind every barrier / LDS-DMA statement -- 34 scalar loads in the staged store loop of
     // the 128 x 160 tile (ISA, round 3).
@@ -150,7 +157,7 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& desc, f32x4_t (
     }
     const int flags = a.flags;
     const int mlane = (lane >> 4) * 4;
-    if (EPIK == 0 && (flags & DYK_EPI_STATS)) {
+    if ((EPIK == 0 || EPIK == 3) && (flags & DYK_EPI_STATS)) {
         // per-channel sum / sum of squares of the raw accumulators: in-lane over ni, DPP row rotate-adds over the
         // 16 pixel lanes, one LDS slot per wave (summed in wave order: the forward pass is reproducible -- with LDS
         // float atomics the order of the adds, and through the chaotic random-weight nets the outputs, changed from
@@ -188,7 +195,7 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& desc, f32x4_t (
         }
     }
     const bool affine = flags & DYK_EPI_AFFINE;
-    const bool has_res = flags & DYK_EPI_RESIDUAL;
+    const bool has_res = (flags & DYK_EPI_RESIDUAL) && EPIK != 3;     // (EPIK 3 adds the residual in its own second pass)
     const bool accum = flags & DYK_EPI_ACCUM;
     const bool out_f32 = (flags & DYK_EPI_OUT_F32) || sizeof(T) == 4;
 
@@ -559,10 +566,150 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& desc, f32x4_t (
                 *(uint4*)((T*)a.y + (long)po + mc) = *(const uint4*)(sC + row * RB + cc * 16);
             }
         };
+
+        // ---- DYK_EPI_BNFWD (EPIK 3): the raw tile has its statistics in the replicas (above) and goes to y through the staged
+        // store; then arrival counter -> wait for the whole launch -> fold the replicas of this workgroup's channels -> normalise
+        // the tile from the accumulators (rounded to the storage type first: the values a separate pass would read back from y),
+        // activation, residual, staged store to y2.  Requires every workgroup of the launch to be resident (front end: grid limit).
+        auto bn_forward = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+            static_assert(sizeof(T) == 2, "DYK_EPI_BNFWD is built for bf16");
+            constexpr int eso = 2;
+            constexpr int rstride = BM * eso + 16;
+            // Ordering without fences: an agent-scope release / acquire on this 8-XCD part writes back and invalidates the whole L2 of
+            // the XCD (measured: the launch took 73 us instead of 27 for conv + normalise).  Everything the workgroups exchange goes
+            // through agent-scope ATOMICS, which are performed at the device's coherence point: the statistics sums (fp64 atomic
+            // adds here, atomic loads below) and the counters.  s_waitcnt vmcnt(0) = this thread's atomic adds have been performed;
+            // the workgroup barrier then orders them before thread 0's arrival.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* s_flag = (int*)(s_stat + 2 * BM);
+            uint32_t* cnt = (uint32_t*)sgpr_ptr(desc.bn_counter);
+            if (tid == 0) {
+                // cnt[0] arrivals, cnt[1] error word, cnt[2] departures.  All three are zero on entry; the workgroup that leaves
+                // last puts them back to zero, so the next launch on this counter (any grid size) needs no re-arming
+                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int ok = 1;
+                const unsigned long long t0 = wall_clock64();
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblk) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (wall_clock64() - t0 > 5000000ull) {     // 50 ms of the 100 MHz clock: not every workgroup is resident --
+                        ok = 0;                                  // flag it instead of hanging (the counters stay dirty: error state)
+                        __hip_atomic_fetch_or(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                if (ok && __hip_atomic_fetch_add(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1u) {
+                    // every workgroup has passed the wait: nobody reads the counters any more
+                    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cnt + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                *s_flag = ok;
+            }
+            __syncthreads();
+            if (*s_flag == 0) return;
+            float* s_sc = s_stat;
+            float* s_sh = s_stat + BM;
+            if (tid < BM) {
+                const int c = m0 + tid;
+                float sc = 0.f, sh = 0.f;
+                if (c < a.Cout) {
+                    const int slots = a.stats_slots > 0 ? a.stats_slots : 1;
+                    const size_t rs = (size_t)2 * a.Cout;
+                    // four accumulators over r & 3, folded (0 + 1) + (2 + 3): the order of bn_fused_fwd_kernel
+                    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+                    int r = 0;
+                    for (; r + 4 <= slots; r += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            a1[u] += __hip_atomic_load(a.stats + (size_t)(r + u) * rs + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            a2[u] += __hip_atomic_load(a.stats + (size_t)(r + u) * rs + a.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    for (; r < slots; ++r) {
+                        a1[0] += __hip_atomic_load(a.stats + (size_t)r * rs + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a2[0] += __hip_atomic_load(a.stats + (size_t)r * rs + a.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const double n = (double)desc.bn_count;
+                    const double mean = ((a1[0] + a1[1]) + (a1[2] + a1[3])) / n;
+                    double var = ((a2[0] + a2[1]) + (a2[2] + a2[3])) / n - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                    const float rstd = (float)(1.0 / sqrt(var + (double)desc.bn_eps));
+                    const float g = desc.bn_gamma ? desc.bn_gamma[c] : 1.f, b = desc.bn_beta ? desc.bn_beta[c] : 0.f;
+                    sc = g * rstd;
+                    sh = b - (float)mean * sc;
+                    if (pub) {
+                        ((float*)a.scale)[c] = sc;
+                        ((float*)a.shift)[c] = sh;
+                        if (desc.bn_save_mean) desc.bn_save_mean[c] = (float)mean;
+                        if (desc.bn_save_rstd) desc.bn_save_rstd[c] = rstd;
+                        if (desc.bn_running_mean) {
+                            const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+                            desc.bn_running_mean[c] = (1.f - desc.bn_momentum) * desc.bn_running_mean[c] + desc.bn_momentum * (float)mean;
+                            desc.bn_running_var[c] = (1.f - desc.bn_momentum) * desc.bn_running_var[c] + desc.bn_momentum * (float)unb;
+                        }
+                    }
+                }
+                s_sc[tid] = sc;
+                s_sh[tid] = sh;
+            }
+            __syncthreads();                                       // (also: every thread is done with the raw tile in sC)
+            const bool res2 = (flags & DYK_EPI_RESIDUAL) != 0;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int ml = wm * WTM + mi * 16 + mlane;
+                float sc[4], sh[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sc[r] = s_sc[ml + r]; sh[r] = s_sh[ml + r]; }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int nl = wn * WTN + ni * 16 + (lane & 15);
+                    const uint32_t p0 = f32x2_to_bf16x2(acc[mi][ni][0], acc[mi][ni][1]), p1 = f32x2_to_bf16x2(acc[mi][ni][2], acc[mi][ni][3]);
+                    const float u[4] = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u),
+                                        __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = act_fwd_c<ACT>(u[r] * sc[r] + sh[r], a.act);
+                    if (res2 && t_out[nl] >= 0 && m0 + ml < a.Cout) {
+                        // the [shortcut] source in fp32 BEFORE the one rounding, as the separate normalise pass adds it
+                        const uint2 rv = *(const uint2*)((const T*)a.res + (long)t_res[nl] + m0 + ml);
+                        v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+                        v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+                    }
+                    uint2 pk;
+                    pk.x = f32x2_to_bf16x2(v[0], v[1]);
+                    pk.y = f32x2_to_bf16x2(v[2], v[3]);
+                    *(uint2*)(sC + nl * rstride + ml * eso) = pk;
+                }
+            }
+            __syncthreads();
+            constexpr int cpr = BM / 8;
+            constexpr int nchunk = BN * cpr;
+            const int ldy_s = __builtin_amdgcn_readfirstlane(desc.ldy), ldy2_s = __builtin_amdgcn_readfirstlane(desc.ldy2);
+            bf16_t* y2 = (bf16_t*)sgpr_ptr(desc.y2);
+            for (int q = tid; q < nchunk; q += 256) {
+                const int row = q / cpr, cc = q % cpr;
+                const int po = t_out[row];
+                const int mc = m0 + cc * 8;
+                if (po < 0 || mc + 8 > a.Cout) continue;
+                *(uint4*)(y2 + (long)(po / ldy_s) * ldy2_s + mc) = *(const uint4*)(sC + row * rstride + cc * 16);
+            }
+        };
         using std::integral_constant;
         using std::true_type;
         using std::false_type;
-        if constexpr (EPIK == 1) {
+        if constexpr (EPIK == 3) {
+            if constexpr (sizeof(T) == 2) {
+                staged(false_type{}, integral_constant<int, DYK_ACT_LINEAR>{}, false_type{});       // raw tile -> y
+                switch (a.act) {
+                case DYK_ACT_LINEAR: bn_forward(integral_constant<int, DYK_ACT_LINEAR>{}); break;
+                case DYK_ACT_LEAKY: bn_forward(integral_constant<int, DYK_ACT_LEAKY>{}); break;
+                case DYK_ACT_MISH: bn_forward(integral_constant<int, DYK_ACT_MISH>{}); break;
+                default: bn_forward(integral_constant<int, -1>{}); break;
+                }
+            }
+            return;
+        } else if constexpr (EPIK == 1) {
             // Measured (round 3, same box, every launch alone): the LDS-DMA form takes 10 % off the plain fused epilogue
             // (3x3 128->128 @64x80: 70 -> 64 us, 64->32 @256x320 -9 %), but in chain mode (addend + raw output = two
             // dependent DMA round trips with a barrier each) it LOSES 10-25 % against the batched register form (1x1
@@ -601,7 +748,7 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& desc, f32x4_t (
             return;
         }
     }
-    if constexpr (EPIK == 1) return;           // (the fused BatchNorm-backward epilogue exists in the staged form only: validated by the front end)
+    if constexpr (EPIK == 1 || EPIK == 3) return;   // (these epilogues exist in the staged form only: validated by the front end)
     // ---- fallback: per-lane stores straight from the MFMA layout (unaligned / odd-stride outputs)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -969,7 +1116,7 @@ void conv_igemm_kernel(const ConvArgs args) {
     }
 
     // ------------------------------------------------------------------ epilogue
-    conv_epilogue<T, BM, BN, EPIK>(a, acc, sC, s_stat, t_out, t_res, m0, blk);
+    conv_epilogue<T, BM, BN, EPIK>(a, acc, sC, s_stat, t_out, t_res, m0, blk, n0 == 0, (unsigned)nblk);
 }
 
 // ======================================================================================
@@ -1300,6 +1447,10 @@ int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     if (force_scatter < 0) { const char* e = getenv("DYK_CONV_EPI"); force_scatter = (e && e[0] == 's') ? 1 : 0; }
     if (force_scatter) vec = false;
     const unsigned grid = conv_fill_args(args, d, tiles_n * tiles_m * (d->ncls > 1 ? d->ncls : 1), vec);
+    if constexpr (EPIK == 3) {
+        // every workgroup must be resident while the launch waits on its arrival counter: bounded grid, vector epilogue, one problem
+        if (grid > (unsigned)DYK_BNFWD_MAX_GRID || !vec || d->twin || d->ncls > 1 || lds > 80 * 1024) return DYK_ERR_UNSUPPORTED;
+    }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256 * KG), lds, stream, args);
     DYK_LAUNCH_CHECK();
     return DYK_OK;

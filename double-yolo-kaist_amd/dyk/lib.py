@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(CSRC_DIR, "libdyk_hip.so")
 
 DYK_F32, DYK_BF16, DYK_U8 = 0, 1, 2
 ACT_CODES = {"linear": 0, "leaky": 1, "mish": 2, "relu": 3, "relu6": 4, "hard-sigmoid": 5, "hard-swish": 6}
-EPI_AFFINE, EPI_RESIDUAL, EPI_STATS, EPI_ACCUM, EPI_OUT_F32, EPI_BNBWD, EPI_ADDEND = 1, 2, 4, 8, 16, 32, 64
+EPI_AFFINE, EPI_RESIDUAL, EPI_STATS, EPI_ACCUM, EPI_OUT_F32, EPI_BNBWD, EPI_ADDEND, EPI_BNFWD = 1, 2, 4, 8, 16, 32, 64, 128
 EW_ACCUM = 1
 MAX_TAPS = 25
 SE_POOL_SPLITS = 16        # DYK_SE_POOL_SPLITS (include/dyk_hip.h): partial-sum planes of the pixel-split SE pool
@@ -40,6 +40,8 @@ class DykConvDesc(ctypes.Structure):
     _fields_ = [
         ("x", _vp), ("w", _vp), ("y", _vp), ("scale", _vp), ("shift", _vp), ("res", _vp), ("stats", _vp),
         ("aux0", _vp), ("aux1", _vp), ("add", _vp),
+        ("y2", _vp), ("bn_gamma", _vp), ("bn_beta", _vp), ("bn_running_mean", _vp), ("bn_running_var", _vp),
+        ("bn_save_mean", _vp), ("bn_save_rstd", _vp), ("bn_counter", _vp),
         ("dtype", _i32), ("ldx", _i32), ("ldy", _i32), ("ldr", _i32),
         ("B", _i32), ("Hi", _i32), ("Wi", _i32), ("Cin", _i32), ("Cout", _i32),
         ("Hg", _i32), ("Wg", _i32), ("Ho", _i32), ("Wo", _i32),
@@ -48,7 +50,8 @@ class DykConvDesc(ctypes.Structure):
         ("tdy", _i8 * MAX_TAPS), ("tdx", _i8 * MAX_TAPS), ("twt", _i8 * MAX_TAPS), ("_pad", _i8),
         ("ncls", _i8), ("cls_first", _i8 * 4), ("cls_ntaps", _i8 * 4), ("cls_ooy", _i8 * 4), ("cls_oox", _i8 * 4),
         ("_pad2", _i8 * 3),
-        ("act", _i32), ("flags", _i32), ("stats_slots", _i32), ("tune", _i32),
+        ("act", _i32), ("flags", _i32), ("stats_slots", _i32),
+        ("ldy2", _i32), ("bn_count", _i32), ("bn_momentum", _f32), ("bn_eps", _f32), ("tune", _i32),
         ("twin", _vp),
     ]
 
@@ -171,6 +174,8 @@ SIGNATURES = {
     "dyk_abi_version": (_i32, []),
     "dyk_error_string": (ctypes.c_char_p, [_i32]),
     "dyk_conv_igemm": (_i32, [_P(DykConvDesc), _vp]),
+    "dyk_conv_bnfwd_max_grid": (_i32, []),
+    "dyk_conv_grid": (_i32, [_P(DykConvDesc)]),
     "dyk_conv_wgrad": (_i32, [_P(DykWgradDesc), _vp]),
     "dyk_conv_wgrad_splits": (_i32, [_P(DykWgradDesc)]),
     "dyk_grad_reduce": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),

@@ -27,6 +27,19 @@ FWD_SLOTS_CAP = int(os.environ.get("DYK_FWD_SLOTS_CAP", "32"))    # most replica
 # against 256 replicas, round 3; the 10 240 tiles of a 256 x 320 layer then put 320 fp64 atomics on an address -- the backward
 # pass has always run such layers with 16 replicas)
 FWD_SLOT_WG = int(os.environ.get("DYK_FWD_SLOT_WG", "128"))        # conv workgroups per replica of a forward statistics buffer
+def _bnfwd_on():
+    """conv + BatchNorm forward in one launch on the deep stages (DYK_EPI_BNFWD).  OFF by default (DYK_BNFWD=1 enables): built,
+    bit-identical to the two-launch path, and measured NEUTRAL on MI355X (round 3, C3 at batch 16, same box: 31.79 / 31.99 ms
+    with it, 31.74 / 31.85 without).  Timed alone, the one launch takes as long as the two it replaces (1x1 256->256 @32x40:
+    28.7 us against 15.6 + 11.4; 3x3 512->1024 @16x20: 94 against 68 + 11): the device-wide wait costs three dependent
+    agent-scope round trips on this 8-XCD part (arrival atomic, poll, statistics reads that must bypass the XCD's L2) --
+    as much as the kernel boundary it removes -- and the residency contract keeps the tuner off the small / K-grouped tiles.
+    With release / acquire fences instead of bare atomics it was 73 us (whole-L2 write-back + invalidate per workgroup).
+    Never under the two-problem pairing experiments (a launch that waits on its own workgroups is single-problem)."""
+    return os.environ.get("DYK_BNFWD", "0") != "0" and os.environ.get("DYK_PAIR", "0") == "0"
+
+
+BNFWD_MAX_GRID = 256                                             # = dyk_conv_bnfwd_max_grid(): two such launches are resident together
 DW_SLOTS = int(os.environ.get("DYK_DW_SLOTS", "32"))                # replicas of a depthwise conv's forward statistics buffer
 STAT_SLOTS = int(os.environ.get("DYK_STAT_SLOTS", "16"))   # replicas of every per-channel fp64 reduction buffer of the backward (bounds atomic
                                                             # contention; every apply workgroup folds them: 32 -> 16 measured -0.15 ms, 64 +0.4 ms)
@@ -421,6 +434,23 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 d.ldy, d.stats_slots = y_raw.ld, slots
                 if not dw and not direct:
                     d.act, d.flags = 0, L.EPI_STATS
+                # conv + BatchNorm + activation in ONE launch (DYK_EPI_BNFWD) where every workgroup of the conv can be resident at
+                # once: the 32 x 40 and 16 x 20 stages (<= dyk_conv_bnfwd_max_grid() workgroups on the 160-pixel tile).  Saves the
+                # normalise launch (6-10 us + its 5-7 us gap where one stream runs alone) and the re-read of the raw output.
+                fuse_bn = (not dw and not direct and code == L.DYK_BF16 and cout % 8 == 0 and _bnfwd_on()
+                           and ((B * Ho * Wo + 159) // 160) * ((cout + 127) // 128) <= BNFWD_MAX_GRID)
+                if fuse_bn:
+                    cnt = st_arena.alloc(16)             # arrivals | error | departures | - (zeroed with the statistics arena)
+                    d.act, d.flags = act, L.EPI_STATS | L.EPI_BNFWD
+                    d.bn_gamma, d.bn_beta = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
+                    d.bn_running_mean, d.bn_running_var = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
+                    d.bn_count, d.bn_momentum, d.bn_eps = B * Ho * Wo, BN_MOMENTUM, BN_EPS
+                    d.ldy2 = z.ld
+                    later(lambda d=d, z=z, vecs=vecs, cnt=cnt: (
+                        setattr(d, "y2", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)), setattr(d, "shift", ws.ptr(vecs + 4 * cout)),
+                        setattr(d, "bn_save_mean", ws.ptr(vecs + 8 * cout)), setattr(d, "bn_save_rstd", ws.ptr(vecs + 12 * cout)),
+                        setattr(d, "bn_counter", st_arena.ptr(cnt))))
+                    plan.has_bnfwd = True
                 if direct:
                     later(lambda d=d, y_raw=y_raw, stats=stats: (
                         setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", st_arena.ptr(stats))))
@@ -428,6 +458,10 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     later(lambda d=d, x_in=x_in, y_raw=y_raw, stats=stats: (
                         setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", st_arena.ptr(stats))))
                 plan.fwd.append((conv_op, d))
+                if fuse_bn:
+                    rec.update(y_raw=y_raw, z=z, vecs=vecs, conv_desc=d)      # (conv_desc: a plain [shortcut] behind it rides on the epilogue)
+                    producer_of[z.tid] = rec
+                    return z, rec
                 f = L.DykBnFinalizeDesc()
                 plan._keep.append(f)
                 f.gamma, f.beta = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
@@ -1485,7 +1519,7 @@ def autotune(plan, cache=None):
     for (op, d) in plan.fwd + plan.bwd:
         if op == L.OP_CONV:
             key = ("c", d.dtype, d.B, d.Cin, d.Cout, d.Hg, d.Wg, d.ntaps, d.isy, d.osy,
-                   d.flags & (L.EPI_STATS | L.EPI_OUT_F32 | L.EPI_BNBWD | (L.EPI_ADDEND if os.environ.get("DYK_TUNE_KEY_ADDEND", "1") != "0" else 0)), d.ncls)
+                   d.flags & (L.EPI_STATS | L.EPI_OUT_F32 | L.EPI_BNBWD | L.EPI_BNFWD | (L.EPI_ADDEND if os.environ.get("DYK_TUNE_KEY_ADDEND", "1") != "0" else 0)), d.ncls)
         elif op == L.OP_WGRAD:
             key = ("w", d.dtype, d.B, d.Cin, d.Cout, d.Ho, d.Wo, d.ntaps, d.isy)
         else:
@@ -1498,6 +1532,17 @@ def autotune(plan, cache=None):
             if key[0] == "c":
                 cands = _conv_candidates(d)
                 fn = lib.dyk_conv_igemm
+                if d.flags & L.EPI_BNFWD:
+                    # one-launch conv + BatchNorm: generic tiles whose launch fits the residency contract (the front end refuses the others)
+                    keep = []
+                    for c in cands:
+                        if (c >> 28) & 7 or ((c >> 12) & 0xf) in (3, 4):
+                            continue
+                        d.tune = c
+                        if lib.dyk_conv_grid(ctypes.byref(d)) <= BNFWD_MAX_GRID and fn(ctypes.byref(d), stream) == 0:
+                            keep.append(c)
+                    cands = keep
+                    assert cands, "no tile configuration fits the one-launch BatchNorm contract: %s" % (key,)
             else:
                 cands, fn = _WGRAD_CANDIDATES, lib.dyk_conv_wgrad
                 if os.environ.get("DYK_WGRAD_CANDS"):

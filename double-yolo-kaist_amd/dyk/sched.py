@@ -154,6 +154,10 @@ def accesses(op, d, mem, plan):
         wr(T(d.y, d.ldy, d.Cout, eso))
         if d.flags & (L.EPI_STATS | L.EPI_BNBWD):
             wr(V(d.stats))
+        if d.flags & L.EPI_BNFWD:          # conv + BatchNorm forward in one launch: normalised output, BatchNorm vectors, arrival counter
+            wr(T(d.y2, d.ldy2, d.Cout, es))
+            for p in (d.scale, d.shift, d.bn_save_mean, d.bn_save_rstd, d.bn_counter):
+                wr(V(p))
     elif op == L.OP_WGRAD:
         es = _es(d.dtype)
         rd(T(d.x, d.ldx, d.Cin, es))
@@ -478,6 +482,8 @@ def build(plan, store, which, start, end, n_streams=None):
     cmds = (plan.fwd if which == "fwd" else plan.bwd)[start:end]
     if n_streams is None:
         n_streams = int(os.environ.get("DYK_STREAMS_" + which.upper(), os.environ.get("DYK_STREAMS", "4")))
+    if which == "fwd" and getattr(plan, "has_bnfwd", False):
+        n_streams = min(n_streams, 2)      # DYK_EPI_BNFWD launches wait on their own workgroups: at most two of them side by side
     mem = Memory(plan, store)
     deps = dependencies(cmds, mem, plan)
     costs = [estimate_cost_us(op, d, plan) for op, d in cmds]

@@ -100,6 +100,8 @@ def pair_signature(op, d, plan):
     """hashable summary of everything two commands must share to run as one two-problem launch (the conditions the
     C side checks: dyk_conv_igemm / dyk_conv_wgrad / dyk_fill_ew_pair / dyk_fill_fin_pair), None = op is not pairable"""
     if op == L.OP_CONV:
+        if d.flags & L.EPI_BNFWD:
+            return None                     # a one-launch conv + BatchNorm waits on its own workgroups: single problem only
         return (op, _bytes(d, L.DykConvDesc, "dtype", "twin"), _nulls(d, ("scale", "shift", "res", "stats", "aux0", "aux1", "add")))
     if op == L.OP_WGRAD:
         return (op, _bytes(d, L.DykWgradDesc, "part_stride", "twin"), bool(d.part))

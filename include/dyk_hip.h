@@ -84,6 +84,21 @@ enum {
                              sum(da * (res - aux0) * aux1) per channel into a `stats` replica -- the reduce pass of that
                              BatchNorm's backward, fused (`act` = its activation; scale/shift/aux0/aux1 = its
                              scale, shift, saved mean, saved rstd).  Excludes AFFINE, RESIDUAL, STATS, ACCUM, OUT_F32. */
+    DYK_EPI_BNFWD = 128,  /* with DYK_EPI_STATS, forward launches of a train-mode Conv2d + BatchNorm2d + activation block
+                             (models.py:34-62) whose workgroups are ALL resident at once: conv, batch statistics, finalize and
+                             normalise + activation in ONE launch.  Every workgroup stores its raw tile to y and adds its sums
+                             to the statistics replicas, then arrives at the device-wide counter `bn_counter` (zero on entry;
+                             the workgroup that leaves last zeroes it again, so successive launches share it without
+                             re-arming) and waits until all gridDim.x workgroups have; it folds the replicas
+                             of its own channels (same order and arithmetic as dyk_bn_finalize_act_fwd: scale = gamma * rstd,
+                             shift = beta - mean * scale), normalises the tile it still holds in its accumulators -- rounded
+                             to dtype first, i.e. exactly the values a separate pass would read back from y -- applies
+                             `act` (and the RESIDUAL, if flagged) and stores it to y2 (pixel stride ldy2).  The workgroups of
+                             the first pixel tile publish scale / shift / saved mean / saved rstd and update the running
+                             statistics.  bf16 only; launches larger than dyk_conv_bnfwd_max_grid() are refused
+                             (DYK_ERR_UNSUPPORTED): the caller may run at most TWO such launches concurrently.  A wait that
+                             does not complete within 50 ms sets bit 0 of bn_counter[1] and abandons the normalise step
+                             instead of hanging. */
     DYK_EPI_ADDEND = 64   /* with DYK_EPI_BNBWD only: dz = v + add[b, y, x, co] (`add`: the gradient arriving over a plain
                              [shortcut], same geometry and pixel stride as y).  The epilogue stores dz ITSELF (the next
                              link of the residual chain needs it), rounded to dtype, and reduces the sums of
@@ -103,6 +118,15 @@ typedef struct DykConvDesc {
     const float* aux0;    /* DYK_EPI_BNBWD: saved mean [Cout] */
     const float* aux1;    /* DYK_EPI_BNBWD: saved rstd [Cout] */
     const void* add;      /* DYK_EPI_ADDEND: gradient addend, dtype, laid out like y */
+    /* DYK_EPI_BNFWD (else ignored): */
+    void* y2;             /* normalised + activated output, dtype */
+    const float* bn_gamma;      /* [Cout] or NULL (1) */
+    const float* bn_beta;       /* [Cout] or NULL (0) */
+    float* bn_running_mean;     /* [Cout] or NULL: updated with bn_momentum (unbiased variance), as nn.BatchNorm2d does */
+    float* bn_running_var;
+    float* bn_save_mean;        /* [Cout] or NULL: batch mean / rstd for the backward pass; scale / shift above are OUTPUTS here */
+    float* bn_save_rstd;
+    uint32_t* bn_counter;       /* [4]: arrivals, error word, departures, unused; zero before the first launch */
     int32_t dtype;
     int32_t ldx, ldy, ldr;          /* pixel strides in elements */
     int32_t B, Hi, Wi, Cin, Cout;
@@ -125,6 +149,9 @@ typedef struct DykConvDesc {
     int32_t act;                    /* DYK_ACT_* applied after the affine */
     int32_t flags;                  /* DYK_EPI_* */
     int32_t stats_slots;            /* number of stats replicas (>= 1; 0 is read as 1) */
+    int32_t ldy2;                   /* DYK_EPI_BNFWD: pixel stride of y2 in elements */
+    int32_t bn_count;               /* DYK_EPI_BNFWD: values per channel (B * Ho * Wo) */
+    float bn_momentum, bn_eps;      /* DYK_EPI_BNFWD */
     int32_t tune;                   /* 0 = built-in heuristic; else tile configuration chosen by the plan compiler's
                                        per-shape measurement: bits 0..7 K-step bytes (64|128), 8..11 LDS ring stages
                                        (2|3|4|6), 12..15 pixel tile (0 = 128, 1 = 80, 2 = 160; bf16), 24..27 channel
@@ -139,6 +166,9 @@ typedef struct DykConvDesc {
 } DykConvDesc;
 
 int dyk_conv_igemm(const DykConvDesc* desc, void* stream);
+/* largest launch (workgroups) DYK_EPI_BNFWD accepts, and the workgroups the launch of `desc` (with its tune word) would take */
+int dyk_conv_bnfwd_max_grid(void);
+int dyk_conv_grid(const DykConvDesc* desc);
 
 /* ------------------------------------------------------------------------------------
  * Convolution weight gradient (split-K MFMA GEMM over output pixels, fp32 atomics):

@@ -403,6 +403,90 @@ def test_dgrad_with_fused_batchnorm_backward_reduce(dtype, act):
     assert L.load().dyk_conv_igemm(ctypes.byref(d), None) != 0
 
 
+@pytest.mark.parametrize("k,act,residual", [(1, "leaky", False), (3, "leaky", True), (3, "mish", False), (1, "linear", True)])
+def test_conv_batchnorm_forward_in_one_launch(k, act, residual):
+    """DYK_EPI_BNFWD: conv + train-mode BatchNorm + activation (+ the plain [shortcut] add) in ONE launch -- statistics, arrival
+    counter, fold, normalise from the accumulators -- against the two-launch path it replaces (conv with statistics, then
+    dyk_bn_finalize_act_fwd): raw output, normalised output, scale / shift / saved mean / rstd and running statistics are all
+    BIT-IDENTICAL, for every tile shape the front end accepts; launches above dyk_conv_bnfwd_max_grid() are refused."""
+    import ctypes
+    from dyk import lib as L
+    from dyk import ops
+    lib = L.load()
+    dtype = torch.bfloat16
+    B, Cin, Cout, H, W = 4, 64, 160, 16, 20
+    g = torch.Generator().manual_seed(31 + k)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    xd = ops.to_nhwc(x.cuda(), dtype)
+    wp = ops.pack_weight(w.cuda(), dtype)
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.3).cuda()
+    resd = ops.to_nhwc(torch.randn(B, Cout, H, W, generator=g).cuda(), dtype) if residual else None
+    slots, n = 4, B * H * W
+    zbig = torch.zeros(B, H, W, 256, dtype=dtype, device="cuda")            # y2 is a channel slice of a wider buffer
+
+    def two_launch(tune):
+        stats = torch.zeros(slots * 2 * Cout, dtype=torch.float64, device="cuda")
+        y = ops.conv2d_fwd(xd, wp, k, 1, k // 2, Cout, stats=stats, stats_slots=slots, tune=tune)
+        vec = [torch.zeros(Cout, device="cuda") for _ in range(4)]
+        rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+        f = L.DykBnFinalizeDesc()
+        f.stats, f.gamma, f.beta, f.running_mean, f.running_var = stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr()
+        f.scale, f.shift, f.save_mean, f.save_rstd = (t.data_ptr() for t in vec)
+        f.C, f.count, f.momentum, f.eps, f.slots = Cout, n, 0.03, 1e-4, slots
+        z = torch.zeros_like(zbig)
+        e = ops.ew_desc(a=y, b=resd, out=z[..., 64:64 + Cout], act=act, p0=vec[0], p1=vec[1])
+        L.check(lib.dyk_bn_finalize_act_fwd(ctypes.byref(f), ctypes.byref(e), None), "dyk_bn_finalize_act_fwd")
+        return y, z, vec, rm, rv
+
+    def one_launch(tune):
+        stats = torch.zeros(slots * 2 * Cout, dtype=torch.float64, device="cuda")
+        y = torch.empty((B, H, W, Cout), dtype=dtype, device="cuda")
+        z = torch.zeros_like(zbig)
+        vec = [torch.zeros(Cout, device="cuda") for _ in range(4)]
+        rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+        cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+        d = ops.make_conv_desc(xd, wp, y, Hi=H, Wi=W, Cin=Cin, Cout=Cout, Hg=H, Wg=W, Ho=H, Wo=W, taps=ops.fwd_taps(k, k // 2),
+                               act=act, res=resd, stats=stats)
+        d.flags |= L.EPI_BNFWD
+        d.tune, d.stats_slots = tune, slots
+        d.scale, d.shift, d.bn_save_mean, d.bn_save_rstd = (t.data_ptr() for t in vec)
+        d.bn_gamma, d.bn_beta, d.bn_running_mean, d.bn_running_var = gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr()
+        d.y2, d.ldy2, d.bn_counter = z[..., 64:64 + Cout].data_ptr(), 256, cnt.data_ptr()
+        d.bn_count, d.bn_momentum, d.bn_eps = n, 0.03, 1e-4
+        rc = lib.dyk_conv_igemm(ctypes.byref(d), None)
+        return rc, d, (y, z, vec, rm, rv), cnt
+
+    ran = 0
+    for tune in (0, 64 | (2 << 8) | (1 << 12), 64 | (2 << 8) | (2 << 12), 128 | (2 << 8) | (2 << 12), 64 | (3 << 8) | (2 << 24),
+                 64 | (2 << 8) | (2 << 12) | (2 << 24)):
+        rc, d, got, cnt = one_launch(tune)
+        grid = lib.dyk_conv_grid(ctypes.byref(d))
+        if grid > lib.dyk_conv_bnfwd_max_grid():
+            assert rc == -3, hex(tune)
+            continue
+        L.check(rc, "dyk_conv_igemm(BNFWD)")
+        ran += 1
+        ref = two_launch(tune)
+        assert cnt.tolist() == [0, 0, 0, 0], (hex(tune), cnt.tolist(), grid)          # re-armed by the last workgroup to leave
+        assert torch.equal(got[0], ref[0]), hex(tune)                               # raw conv output
+        assert torch.equal(got[1], ref[1]), (hex(tune), (got[1].float() - ref[1].float()).abs().max().item())
+        for a, b in zip(got[2], ref[2]):
+            assert torch.equal(a, b), hex(tune)
+        assert torch.equal(got[3], ref[3]) and torch.equal(got[4], ref[4]), hex(tune)
+    assert ran >= 3
+    # a launch with more workgroups than may wait on one another
+    big = ops.to_nhwc(torch.randn(16, Cin, 64, 80, generator=g).cuda(), dtype)
+    yb = torch.empty((16, 64, 80, Cout), dtype=dtype, device="cuda")
+    d = ops.make_conv_desc(big, wp, yb, Hi=64, Wi=80, Cin=Cin, Cout=Cout, Hg=64, Wg=80, Ho=64, Wo=80, taps=ops.fwd_taps(k, k // 2),
+                           act=act, stats=torch.zeros(slots * 2 * Cout, dtype=torch.float64, device="cuda"))
+    d.flags |= L.EPI_BNFWD
+    d.stats_slots, d.bn_count, d.ldy2 = slots, 16 * 64 * 80, Cout
+    keep = [torch.zeros(Cout, device="cuda") for _ in range(2)] + [torch.empty_like(yb), torch.zeros(4, dtype=torch.int32, device="cuda")]
+    d.scale, d.shift, d.y2, d.bn_counter = (t.data_ptr() for t in keep)
+    assert lib.dyk_conv_igemm(ctypes.byref(d), None) == -3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_wgrad_plane_mode_and_grad_reduce(dtype):
     """DykWgradDesc.part: every K split stores its tiles into its own plane, dyk_grad_reduce folds the planes into the

@@ -465,3 +465,32 @@ def test_mismatched_channel_shortcuts_match_reference(dtype):
     gt = 5e-3 if dtype == "fp32" else 8e-2
     assert np.allclose(got[:, 0], gold["grad_sums"][:, 0], rtol=gt, atol=1e-6), np.abs(got[:, 0] / np.maximum(gold["grad_sums"][:, 0], 1e-12) - 1).max()
     assert np.allclose(m.module_list[5].w.grad.cpu().numpy(), gold["grad_w5"], rtol=gt, atol=1e-5)
+
+
+def test_one_launch_conv_batchnorm_plan_is_bit_identical(monkeypatch):
+    """DYK_BNFWD=1: the deep-stage conv + BatchNorm + activation blocks run as ONE launch each (DYK_EPI_BNFWD: statistics,
+    device-wide arrival counter, fold, normalise from the accumulators).  Same arithmetic in the same order as the two-launch
+    path: with equal tile configurations, train-mode outputs, running statistics and every parameter gradient of the target
+    cfg are bit-identical, with the two backbone streams running such launches side by side."""
+    from dyk import lib as L
+    res = []
+    monkeypatch.setenv("DYK_AUTOTUNE", "0")        # the same (built-in) tile configuration in both plans: same summation order
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DYK_BNFWD", flag)
+        m = _model(C3, "bf16").train()
+        x, y = _inputs()
+        out = m(x.cuda(), y.cuda())
+        loss = sum((t.float() ** 2).mean() for t in out)
+        loss.backward()
+        torch.cuda.synchronize()
+        plan = next(iter(m.engine.plans.values()))
+        n_one = sum(1 for op, d in plan.fwd if op == L.OP_CONV and d.flags & L.EPI_BNFWD)
+        assert (n_one > 0) == (flag == "1")
+        res.append(([t.detach().clone() for t in out], {k: v.clone() for k, v in m.state_dict().items() if "running" in k},
+                    [p.grad.clone() for p in m.parameters()], n_one))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)

@@ -72,11 +72,12 @@ def test_param_store_roundtrip_and_flat_layout():
 
 
 @pytest.mark.parametrize("name", [C1, C2, C3])
-@pytest.mark.parametrize("training", [False, True])
-def test_plan_compiles_consistently(name, training):
+@pytest.mark.parametrize("training,one_launch", [(False, False), (True, False), (True, True)])
+def test_plan_compiles_consistently(name, training, one_launch, monkeypatch):
     from dyk import lib as L
     from dyk.params import ParamStore
     from dyk.plan import compile_plan
+    monkeypatch.setenv("DYK_BNFWD", "1" if one_launch else "0")       # conv + BatchNorm forward in one launch (off by default)
     m = _model(name)
     st = ParamStore(m)
     st.adopt(torch.device("cpu"))
@@ -91,7 +92,15 @@ def test_plan_compiles_consistently(name, training):
     assert len(plan.p_out) == 3 and [tuple(p.shape) for p in plan.p_out] == [
         (B, 3, H // s, W // s, 6) for s in ([32, 16, 8] if "yolov3" in name else [8, 16, 32])]
     if training:
-        assert ops.count(L.OP_BN_FINALIZE) == ops.count(L.OP_BN_ACT_FWD) and ops.count(L.OP_BN_FINALIZE) + ops.count(L.OP_BN_FWD_FUSED) == n_bn
+        # every BatchNorm is finalised exactly once: own launch, on its normalise pass, or inside the conv launch (DYK_EPI_BNFWD:
+        # the layers whose conv launch is small enough to have all its workgroups resident)
+        n_one = sum(1 for op, d in plan.fwd if op == L.OP_CONV and d.flags & L.EPI_BNFWD)
+        assert ops.count(L.OP_BN_FINALIZE) == ops.count(L.OP_BN_ACT_FWD)
+        assert ops.count(L.OP_BN_FINALIZE) + ops.count(L.OP_BN_FWD_FUSED) + n_one == n_bn and (n_one > 0) == one_launch
+        for op, d in plan.fwd:
+            if op == L.OP_CONV and d.flags & L.EPI_BNFWD:
+                assert d.flags & L.EPI_STATS and d.y2 and d.bn_counter and d.bn_count == B * d.Ho * d.Wo and d.ldy2 >= d.Cout
+                assert ((B * d.Ho * d.Wo + 159) // 160) * ((d.Cout + 127) // 128) <= 256
         assert ops[0] == L.OP_MEMSET
         bops = [op for op, _ in plan.bwd]
         assert bops[0] == L.OP_MEMSET

@@ -22,6 +22,7 @@ def cmd_model(L, op, d, plan=None):
         if d.res: by += px_o * d.Cout * es
         if d.add: by += px_o * d.Cout * es
         if d.aux0: by += px_o * d.Cout * es          # fused BN-backward epilogue reads the raw conv output of the producer
+        if d.flags & 128: by += px_o * d.Cout * es   # DYK_EPI_BNFWD: the normalised tensor is written by the same launch
         fl = 2.0 * px_o * d.Cin * d.Cout * d.ntaps
         return "%s %dx%d c%d>%d t%d s%d f%x" % (n, d.Hg, d.Wg, d.Cin, d.Cout, d.ntaps, d.isy, d.flags), by, fl
     if op == L.OP_WGRAD:

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-timeout 900 python -m pytest tests/test_gpu_elementwise.py -q -x -k "fusion" 2>&1 | tail -25
+timeout 200 python -m pytest tests/test_gpu_model.py -q -x -k "one_launch" 2>&1 | tail -12
