@@ -108,7 +108,29 @@ class Engine:
             total -= nbytes(self.plans.pop(k))
 
     # ------------------------------------------------------------------ execution
+    def _check_bnfwd(self, plan):
+        """one-launch conv + BatchNorm blocks (DYK_BNFWD=1): look at the error words of the PREVIOUS pass without a host sync (copy
+        to pinned memory behind the pass, examined here once it has landed) and fail loudly instead of training on tiles that
+        were never normalised"""
+        pend = plan.__dict__.get("_bnfwd_pending")
+        if pend is not None and pend[1].query():
+            if int(pend[0].max()) != 0:
+                raise L.DykError("a DYK_EPI_BNFWD launch gave up waiting for its own workgroups (more than two such launches "
+                                 "in flight, or not all of them resident): rerun with DYK_BNFWD=0")
+            plan.__dict__["_bnfwd_pending"] = None
+
+    def _post_bnfwd(self, plan):
+        if plan.__dict__.get("_bnfwd_pending") is None:
+            words = plan.bnfwd_error_words()
+            host = torch.zeros(words.numel(), dtype=torch.int32).pin_memory()
+            host.copy_(words, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            plan.__dict__["_bnfwd_pending"] = (host, ev)
+
     def _run_forward(self, plan, x, y):
+        if plan.has_bnfwd:
+            self._check_bnfwd(plan)
         stream = torch.cuda.current_stream().cuda_stream
         self.store.compute_weights(plan.dtype, force=False)
         xs = {"x": x, "y": y if y is not None else x}
@@ -135,6 +157,8 @@ class Engine:
             desc.p[0] = t.data_ptr()
         plan._dyn_keep = keep
         plan.run("fwd", stream)
+        if plan.has_bnfwd:
+            self._post_bnfwd(plan)
         if plan.training and len(self.store.nbt):
             self.store.NBT += 1
 

@@ -106,6 +106,16 @@ class Plan:
         self._keep = []
         self._cfwd = self._cbwd = None
         self._cmd_us, self._rw_extra, self._part_extent = {}, {}, {}
+        self.has_bnfwd, self.bnfwd_counters = False, []      # one-launch conv + BatchNorm blocks (DYK_EPI_BNFWD): counter offsets in `ws`
+
+    def bnfwd_error_words(self):
+        """device tensor (int32, one element per DYK_EPI_BNFWD launch of the plan): non-zero where the launch gave up waiting for
+        its own workgroups (residency contract violated) and skipped the normalise step; None if the plan has no such launch"""
+        if not self.bnfwd_counters:
+            return None
+        words = self.arenas["ws"].tensor.view(torch.int32)
+        idx = torch.tensor([off // 4 + 1 for off in self.bnfwd_counters], device=words.device)
+        return words[idx]
 
     def _pack(self, cmds, lanes):
         arr = (L.DykCommand * max(len(cmds), 1))()
@@ -440,7 +450,10 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 fuse_bn = (not dw and not direct and code == L.DYK_BF16 and cout % 8 == 0 and _bnfwd_on()
                            and ((B * Ho * Wo + 159) // 160) * ((cout + 127) // 128) <= BNFWD_MAX_GRID)
                 if fuse_bn:
-                    cnt = st_arena.alloc(16)             # arrivals | error | departures | - (zeroed with the statistics arena)
+                    cnt = new_ws(16)                     # arrivals | error | departures | - : zero at plan creation, re-armed by the
+                                                         # launch itself; NOT in the statistics arena (zeroed every pass), so that an
+                                                         # error word survives until Plan.bnfwd_error() has looked at it
+                    plan.bnfwd_counters.append(cnt)
                     d.act, d.flags = act, L.EPI_STATS | L.EPI_BNFWD
                     d.bn_gamma, d.bn_beta = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
                     d.bn_running_mean, d.bn_running_var = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
@@ -449,7 +462,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     later(lambda d=d, z=z, vecs=vecs, cnt=cnt: (
                         setattr(d, "y2", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)), setattr(d, "shift", ws.ptr(vecs + 4 * cout)),
                         setattr(d, "bn_save_mean", ws.ptr(vecs + 8 * cout)), setattr(d, "bn_save_rstd", ws.ptr(vecs + 12 * cout)),
-                        setattr(d, "bn_counter", st_arena.ptr(cnt))))
+                        setattr(d, "bn_counter", ws.ptr(cnt))))
                     plan.has_bnfwd = True
                 if direct:
                     later(lambda d=d, y_raw=y_raw, stats=stats: (

@@ -488,6 +488,15 @@ def test_one_launch_conv_batchnorm_plan_is_bit_identical(monkeypatch):
         assert (n_one > 0) == (flag == "1")
         res.append(([t.detach().clone() for t in out], {k: v.clone() for k, v in m.state_dict().items() if "running" in k},
                     [p.grad.clone() for p in m.parameters()], n_one))
+        if flag == "1":
+            # the error words of the launches: all clear; a set word (a launch that gave up waiting for its workgroups) makes the
+            # NEXT forward call fail loudly instead of training on tiles that were never normalised
+            assert int(plan.bnfwd_error_words().max()) == 0 and plan.bnfwd_error_words().numel() == n_one
+            plan.arenas["ws"].tensor.view(torch.int32)[plan.bnfwd_counters[3] // 4 + 1] = 1
+            m(x.cuda(), y.cuda())                      # (posts the words of this pass)
+            torch.cuda.synchronize()
+            with pytest.raises(L.DykError):
+                m(x.cuda(), y.cuda())
     for a, b in zip(res[0][0], res[1][0]):
         assert torch.equal(a, b)
     for k in res[0][1]:
