@@ -29,7 +29,7 @@ import torch  # noqa: E402
 CFG = "kaist_dyolov4_fshare_global_concat_se3"
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
-PROFILE_TAG = "r03"            # profiles/<tag>_*.json written by tools/run_gpu_round.sh for this round
+PROFILE_TAG = "r04"            # profiles/<tag>_*.json written by tools/run_gpu_round.sh for this round
 
 
 def synth_batch(B, H, W, rank, device):
@@ -432,19 +432,27 @@ def main():
                 with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_step_kernels.json")) as f:
                     kj = json.load(f)
                 if kj.get("code_sha") == sha:
-                    fam = kj["families"]["conv_igemm_kernel"]
-                    t_us = fam["total_us"] + kj["families"].get("conv_halo_kernel", {"total_us": 0.0})["total_us"]
+                    fams = [kj["families"][k] for k in ("conv_igemm_kernel", "conv_halo_kernel", "conv_lt_kernel") if k in kj["families"]]
+                    t_us = sum(f_["total_us"] for f_ in fams)
                     in_step = {"tflops": 2.0 * f1 / (t_us * 1e-6) / 1e12, "frac": 2.0 * f1 / (t_us * 1e-6) / 1e12 / peak,
-                               "launches": fam["n"] + kj["families"].get("conv_halo_kernel", {"n": 0})["n"], "total_us": t_us,
+                               "launches": sum(f_["n"] for f_ in fams), "total_us": t_us,
                                "source": "profiles/%s_step_kernels.json (rocprofv3 kernel trace of one step, three streams "
                                          "running concurrently: durations include time shared with other kernels)" % PROFILE_TAG}
             except Exception:
                 pass
+            # `frac` follows from profiles/ whenever the committed rocprofv3 trace is of the running code: the
+            # in-step figure; the isolated-launch figure of this run is always reported beside it
+            frac_rocprof = in_step["frac"] if in_step else None
             out["roofline"] = {
-                "bound": "mfma", "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                "bound": "mfma", "kernel": "conv_igemm_kernel + conv_lt_kernel + conv_halo_kernel (forward + data-gradient launches)",
+                "achieved": (in_step["tflops"] if in_step else ach), "peak": peak, "unit": "TFLOP/s",
+                "frac": (frac_rocprof if frac_rocprof is not None else ach / peak), "traffic": traffic,
                 "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % src if src else None,
-                "frac_is": "isolated-kernel fraction: every launch timed alone on the chip with HIP events (this run)",
+                "frac_is": ("rocprofv3 in-step fraction (profiles/%s_step_kernels.json, code hash matches this run)" % PROFILE_TAG) if in_step
+                           else "isolated-kernel fraction: every launch timed alone on the chip with HIP events (this run; no rocprofv3 "
+                                "trace of this code hash under profiles/)",
+                "frac_rocprof": frac_rocprof,
+                "frac_isolated": ach / peak, "achieved_isolated": ach,
                 "in_step": in_step,
                 "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1),
                 "flops_per_launch": 2.0 * f1 / max(ig_n, 1),

@@ -7,8 +7,9 @@ runs from the last layer to the first, so the tail of the buffer is final first.
 a few segments; as soon as a segment's kernels are enqueued, the matching contiguous slice of the buffer
 is all-reduced asynchronously (RCCL's stream waits on the compute stream at enqueue time), overlapping
 the exchange of late-layer gradients with the differentiation of early layers.  xGMI is point-to-point, so
-buckets are kept large (default 8 buckets of ~58 MB for the 464 MB of the target model): few, bandwidth-
-bound collectives instead of many latency-bound ones.  The 1/world_size averaging is folded into the fused
+buckets are few and geometric (default 5: 50 | 30 | 15 | 4 | 1 % of the 464 MB of the target model, late layers
+first -- the deep layers hold the parameters, the early layers the time of a backward pass): large, bandwidth-
+bound collectives early, a small exposed tail.  The 1/world_size averaging is folded into the fused
 optimizer step (FusedAdam.grad_scale).
 """
 import os
@@ -144,8 +145,11 @@ class GradAllReduce:
             marks = plan.bwd_marks                    # (commands emitted before layer i's backward, i), descending i
             # twin sections (dyk/twins.py) run as two-problem launches: a cut between the backward of section t and that
             # of its twin l < t would leave both halves unpaired, so no bucket closes at a layer in (l, t]
-            twin_spans = sorted((l, t) for l, t in getattr(plan, "twin_layer", {}).items() if l < t) \
-                if os.environ.get("DYK_PAIR", "0") != "0" else []
+            # (only when the BACKWARD schedule really pairs launches: DYK_PAIR_WHICH=fwd / DYK_PAIR_OPS=none leave it unpaired, and
+            # forbidding every cut inside the backbones would collapse the overlap into one or two buckets -- ADVICE r3)
+            bwd_paired = (os.environ.get("DYK_PAIR", "0") != "0" and os.environ.get("DYK_PAIR_WHICH", "both") in ("both", "bwd")
+                          and os.environ.get("DYK_PAIR_OPS", "ew") != "none")
+            twin_spans = sorted((l, t) for l, t in getattr(plan, "twin_layer", {}).items() if l < t) if bwd_paired else []
             for k in range(1, len(marks)):
                 c_end, layer_done = marks[k][0], marks[k - 1][1]     # commands [.., c_end) finish layer `layer_done`
                 lo = min((o for l, o in first_off.items() if l >= layer_done), default=hi)

@@ -237,6 +237,9 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 2          # = DYK_ABI_VERSION of include/dyk_hip.h: a stale .so with older descriptor layouts is refused
+
+
 def load(path=None):
     """Load (once) and return the ctypes handle of libdyk_hip.so."""
     global _lib
@@ -258,7 +261,7 @@ def load(path=None):
             raise DykLibraryError("%s does not export %s (stale build?)" % (p, name))
         fn.restype = res
         fn.argtypes = args
-    if lib.dyk_abi_version() != 1:
+    if lib.dyk_abi_version() != ABI_VERSION:
         raise DykLibraryError("ABI version mismatch")
     _lib = lib
     return lib

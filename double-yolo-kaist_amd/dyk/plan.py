@@ -1545,7 +1545,13 @@ def autotune(plan, cache=None):
             if key[0] == "c":
                 cands = _conv_candidates(d)
                 fn = lib.dyk_conv_igemm
+                bn_saved = None
                 if d.flags & L.EPI_BNFWD:
+                    # The trial launches run the REAL descriptor: every one of them would EMA-update the layer's running statistics
+                    # (from replica sums that keep accumulating across trials: k x the mean, variance clamped to 0) and rewrite its
+                    # saved mean / rstd.  Trials run without those outputs and on freshly zeroed replicas.
+                    bn_saved = (d.bn_running_mean, d.bn_running_var, d.bn_save_mean, d.bn_save_rstd)
+                    d.bn_running_mean = d.bn_running_var = d.bn_save_mean = d.bn_save_rstd = None
                     # one-launch conv + BatchNorm: generic tiles whose launch fits the residency contract (the front end refuses the others)
                     keep = []
                     for c in cands:
@@ -1556,6 +1562,7 @@ def autotune(plan, cache=None):
                             keep.append(c)
                     cands = keep
                     assert cands, "no tile configuration fits the one-launch BatchNorm contract: %s" % (key,)
+                    plan.arenas["stats"].tensor.zero_()          # (the filter launches above left sums in the replicas)
             else:
                 cands, fn = _WGRAD_CANDIDATES, lib.dyk_conv_wgrad
                 if os.environ.get("DYK_WGRAD_CANDS"):
@@ -1624,9 +1631,13 @@ def autotune(plan, cache=None):
             else:
                 def trial_c(c, reps=3):
                     d.tune = c
+                    if bn_saved is not None:
+                        plan.arenas["stats"].tensor.zero_()
                     return _time_launch(fn, d, stream, reps)
                 times = _refine(cands, [trial_c(c) for c in cands], trial_c)
                 best = cands[times.index(min(times))]
+                if bn_saved is not None:
+                    d.bn_running_mean, d.bn_running_var, d.bn_save_mean, d.bn_save_rstd = bn_saved
                 if os.environ.get("DYK_TUNE_VERBOSE"):   # analysis: every candidate's time, fastest first
                     print("tune", key, " ".join("%#x:%.1f" % (c, 1e3 * t) for t, c in sorted(zip(times, cands))[:12]), flush=True)
             cache[key] = best

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DYK_ABI_VERSION 1
+#define DYK_ABI_VERSION 2   /* 2: round-3 descriptor layouts (twin / cmd2 fields, BNFWD block, focal-loss fields) */
 
 enum {
     DYK_OK = 0,

@@ -503,3 +503,24 @@ def test_one_launch_conv_batchnorm_plan_is_bit_identical(monkeypatch):
         assert torch.equal(res[0][1][k], res[1][1][k]), k
     for a, b in zip(res[0][2], res[1][2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_plan_compilation_leaves_running_statistics_alone(monkeypatch):
+    """with DYK_BNFWD=1 the autotuner's trial launches ran the real descriptor, whose one-launch BatchNorm epilogue
+    EMA-updates the layer's running statistics (from replica sums that kept accumulating across trials).  Compiling a training
+    plan -- autotuning included -- must not touch any running_mean / running_var / num_batches_tracked."""
+    monkeypatch.setenv("DYK_BNFWD", "1")
+    monkeypatch.setenv("DYK_AUTOTUNE", "1")
+    m = _model(C3, "bf16").train()
+    x, y = _inputs()
+    m.engine._prepare(x.cuda())
+    before = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    B, _, H, W = x.shape
+    plan = m.engine.get_plan(B, H, W, torch.bfloat16, True, torch.device("cuda", torch.cuda.current_device()))
+    torch.cuda.synchronize()
+    from dyk import lib as L
+    assert any(op == L.OP_CONV and d.flags & L.EPI_BNFWD for op, d in plan.fwd)
+    after = m.state_dict()
+    for k, v in before.items():
+        assert torch.equal(v, after[k]), k
