@@ -9,6 +9,7 @@ int dyk_conv_launch_n80(const DykConvDesc* d, hipStream_t s);
 int dyk_conv_launch_n160(const DykConvDesc* d, hipStream_t s);
 int dyk_conv_launch_halo(const DykConvDesc* d, hipStream_t s, int th);
 int dyk_conv_launch_kg(const DykConvDesc* d, hipStream_t s);
+int dyk_conv_launch_lt(const DykConvDesc* d, hipStream_t s);
 
 static int conv_validate(const DykConvDesc* d) {
     if (!d || !d->x || !d->w || !d->y) return DYK_ERR_ARG;
@@ -66,6 +67,11 @@ extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
         if (tile == 1 || tile == 3) return dyk_conv_launch_n80(d, s);
         if (tile == 2 || tile == 4) return dyk_conv_launch_n160(d, s);
         return dyk_conv_launch_n128(d, s);
+    }
+    if (tile == 5) {                       // large-tile 3x3 kernels (conv_lt_kernel.h); generic 160-pixel tiles where they do not apply
+        const int rc = dyk_conv_launch_lt(d, s);
+        if (rc != DYK_ERR_UNSUPPORTED || ((d->tune >> 23) & 1)) return rc;       // (bit 23, analysis: no fallback)
+        return dyk_conv_launch_n160(d, s);
     }
     if (((d->tune >> 28) & 7) == 1) {      // K-grouped workgroups (conv_igemm_kg.hip); generic tiles where they do not apply
         const int rc = dyk_conv_launch_kg(d, s);

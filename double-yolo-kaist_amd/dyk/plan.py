@@ -1468,6 +1468,16 @@ def _conv_candidates(d):
                     if t in (3, 4) and pipe != 2:
                         continue                      # the halo kernel has a fixed pipeline
                     out.append(bkb | (pipe << 8) | (t << 12) | (bm << 24))
+    if (d.dtype == L.DYK_BF16 and d.ntaps == 9 and d.isy == 1 and d.osy == 1 and d.Hg == d.Hi and d.Wg == d.Wi and d.ncls <= 1
+            and d.Cin % 32 == 0 and d.Wi % 20 == 0 and not (d.flags & (L.EPI_OUT_F32 | L.EPI_BNFWD))
+            and os.environ.get("DYK_CONV_LT", "1") != "0"):
+        # large-tile 3x3 kernels (csrc/conv_lt_kernel.h): 8 waves, 128 x 320 / 256 x 160 / 128 x 160 with two K-groups, halo patch of
+        # the fewest rows (the patch width moved no time in tools/lt_probe.py).  The front end falls back to the generic
+        # 160-pixel tile where a shape does not fit the map.
+        for shape in (1, 2, 3):
+            if shape == 2 and d.Cout < 256:
+                continue
+            out.append((5 << 12) | (shape << 8))
     if d.dtype == L.DYK_BF16 and (d.Cin * es) % 128 == 0 and d.Cin >= 128 and os.environ.get("DYK_CONV_KG", "1") != "0":
         # K-grouped workgroups (two 4-wave groups over the two halves of Cin): for tiles that leave a CU one workgroup
         for t in (1, 2):

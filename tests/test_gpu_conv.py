@@ -631,3 +631,95 @@ def test_wgrad_multi_tap_kernel(case):
     got = part.view(splits, 9, Cout, Cin).sum(0)
     assert bool(torch.isfinite(got).all())
     assert (got.cpu() - ref).abs().max().item() <= tol
+
+
+LT_CASES = [  # (B, Cin, Cout, H, W): forward conv Cin -> Cout, 3x3 / stride 1 / pad 1
+    (2, 64, 128, 16, 20), (1, 96, 192, 8, 40), (2, 128, 64, 16, 40), (1, 160, 96, 16, 80), (3, 256, 128, 8, 20),
+]
+
+
+@pytest.mark.parametrize("case", LT_CASES)
+def test_large_tile_conv_kernels(case):
+    """csrc/conv_lt_kernel.h: the 8-wave large-tile 3x3 kernels (128 x 320, 256 x 160, 128 x 160 with two K-groups;
+    halo patches of every admissible width) against torch CPU fp32 on the same bf16-rounded operands: forward with
+    statistics, forward with affine + activation + residual, data gradient with the fused BatchNorm-backward epilogue (plain
+    and residual-chain form).  Tune bit 23 makes the front end refuse instead of falling back to the generic tiles, so every
+    configuration counted below really ran the large-tile kernel; ragged channel tiles (Cout = 192, 136) included."""
+    import ctypes
+    from dyk import lib as L
+    from dyk import ops
+    B, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).bfloat16().float()
+    r = torch.randn(B, Cout, H, W, generator=g).bfloat16().float()
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    y_ref = F.conv2d(x, w, padding=1)
+    z_ref = F.leaky_relu(y_ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0.1) + r
+    xd, rd = ops.to_nhwc(x.cuda(), torch.bfloat16), ops.to_nhwc(r.cuda(), torch.bfloat16)
+    wp = ops.pack_weight(w.cuda(), torch.bfloat16)
+    # data gradient of the same conv, producing dz of a BatchNorm + Mish block whose raw output is u
+    dy = torch.randn(B, Cout, H, W, generator=g).bfloat16().float()
+    u = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    gadd = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    mean, var = u.mean((0, 2, 3)), u.var((0, 2, 3), unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    sc2, sh2 = gamma * rstd, beta - mean * gamma * rstd
+    xhat = (u - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1)
+    dz = torch.nn.grad.conv2d_input((B, Cin, H, W), w, dy, padding=1)
+
+    def bn_ref(dzv):
+        t = (u * sc2.view(1, -1, 1, 1) + sh2.view(1, -1, 1, 1)).requires_grad_(True)
+        F.mish(t).backward(dzv)
+        return t.grad, t.grad.double().sum((0, 2, 3)), (t.grad.double() * xhat.double()).sum((0, 2, 3))
+    da_ref, s1_ref, s2_ref = bn_ref(dz.bfloat16().float())
+    dzc = (dz + gadd).bfloat16().float()
+    _, s1c, s2c = bn_ref(dzc)
+    dyd, ud, addd = (ops.to_nhwc(t.cuda(), torch.bfloat16) for t in (dy, u, gadd))
+    wpt = ops.pack_weight(w.cuda(), torch.bfloat16, transposed=True)
+    out = torch.empty((B, H, W, Cin), dtype=torch.bfloat16, device="cuda")
+    red = torch.zeros(4, 2, Cin, dtype=torch.float64, device="cuda")
+    vec = [t.cuda().contiguous() for t in (sc2, sh2, mean, rstd)]
+    (py, px, Hg, Wg, taps), = ops.dgrad_classes(3, 1, 1, H, W)
+    d = ops.make_conv_desc(dyd, wpt, out, Hi=H, Wi=W, Cin=Cout, Cout=Cin, Hg=Hg, Wg=Wg, Ho=H, Wo=W, taps=taps, act="mish")
+    d.res, d.ldr = ud.data_ptr(), Cin
+    d.scale, d.shift, d.aux0, d.aux1 = (t.data_ptr() for t in vec)
+    d.stats, d.stats_slots, d.add = red.data_ptr(), 4, addd.data_ptr()
+    n = B * H * W
+    ran_f = ran_b = 0
+    for shape in (1, 2, 3):
+        for tw in (0, 1, 2, 3, 4):
+            tune = (5 << 12) | (shape << 8) | (tw << 24) | (1 << 23)
+            # ---- forward
+            stats = torch.zeros(4, 2, Cout, dtype=torch.float64, device="cuda")
+            try:
+                y = ops.conv2d_fwd(xd, wp, 3, 1, 1, Cout, stats=stats, stats_slots=4, tune=tune)
+            except L.DykError:
+                y = None                                   # this shape / patch width does not fit the problem
+            if y is not None:
+                ran_f += 1
+                err = (ops.to_nchw(y).cpu() - y_ref).abs().max().item()
+                assert err <= 1.2e-2 * max(1.0, y_ref.abs().max().item()), (hex(tune), err)
+                st = stats.sum(0).cpu()
+                assert torch.allclose(st[0], y_ref.double().sum((0, 2, 3)), rtol=1e-3, atol=2e-2 * n ** 0.5), hex(tune)
+                assert torch.allclose(st[1], (y_ref.double() ** 2).sum((0, 2, 3)), rtol=2e-3, atol=1e-2), hex(tune)
+                z = ops.conv2d_fwd(xd, wp, 3, 1, 1, Cout, act="leaky", scale=scale.cuda(), shift=shift.cuda(), res=rd, tune=tune)
+                err = (ops.to_nchw(z).cpu() - z_ref).abs().max().item()
+                assert err <= 1.5e-2 * max(1.0, z_ref.abs().max().item()), (hex(tune), err)
+            # ---- data gradient + fused BatchNorm-backward reduce, plain and residual chain
+            for flags, ref, r1, r2 in ((L.EPI_BNBWD, da_ref, s1_ref, s2_ref), (L.EPI_BNBWD | L.EPI_ADDEND, dzc, s1c, s2c)):
+                d.flags, d.tune = flags, tune
+                red.zero_()
+                out.zero_()
+                rc = L.load().dyk_conv_igemm(ctypes.byref(d), None)
+                if rc == -3:                            # DYK_ERR_UNSUPPORTED: this shape / patch width does not fit
+                    continue
+                assert rc == 0, (hex(tune), rc)
+                ran_b += 1
+                err = (ops.to_nchw(out).cpu() - ref).abs().max().item()
+                assert err <= 1.5e-2 * max(1.0, ref.abs().max().item()), (hex(tune), flags, err)
+                st = red.sum(0).cpu()
+                assert torch.allclose(st[0], r1, rtol=2e-3, atol=5e-2 * n ** 0.5), (hex(tune), flags)
+                assert torch.allclose(st[1], r2, rtol=2e-3, atol=5e-2 * n ** 0.5), (hex(tune), flags)
+    assert ran_f >= 2 and ran_b >= 4, (ran_f, ran_b)
