@@ -20,6 +20,7 @@
 #pragma once
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 #include "dyk_common.h"
 
 namespace {
@@ -48,6 +49,18 @@ __device__ inline int conv_pick_problem(const ConvArgs& args, int& blk, int& nbl
 
 // largest DYK_EPI_BNFWD launch: with <= 80 KB of LDS and a two-wave register budget two such launches are resident together
 constexpr int DYK_BNFWD_MAX_GRID = 256;
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a compile-time constant in the body
+template <typename F, int... I> __device__ __forceinline__ void dyk_static_for_impl(F& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void dyk_static_for(F& f) { dyk_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// LDS the sliced BatchNorm-backward epilogue needs in the staging region: BatchNorm vectors + three slice buffers per streamed
+// tensor (raw output; chain mode: + the addend); WN = wave columns of the tile
+template <typename T, int BM, int WN> constexpr size_t bnbwd_sliced_bytes(bool chain) {
+    return (size_t)4 * BM * 4 + (size_t)(chain ? 6 : 3) * 16 * WN * BM * sizeof(T);
+}
 
 // set by the launcher when y / ldy allow 8/16-byte vector stores
 constexpr int EPI_INTERNAL_VEC = 1 << 30;
@@ -448,138 +461,169 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& desc, f32x4_t (
                 }
             }
         };
-        // ---- BatchNorm-backward epilogue, round-3 form: the raw conv output of the tile (and, in chain mode, the addend)
-        // arrives by LDS-DMA in ONE memory round trip -- the batched form above walks nchunk/256 chunks per thread with two
-        // loads in flight (5 dependent round trips for a 128 x 160 tile: 128->128 3x3 @64x80 forward 36 us, data gradient
-        // 63 us).  The tile lands lane-linear in the staging area (dense rows of BM elements, which the ring no longer
-        // needs); every lane then picks up the four channels of each of its accumulator fragments (ds_read_b64 / b128),
-        // forms da = dz * act'(u) in registers FROM THE FP32 ACCUMULATORS, reduces sum(da), sum(da * xhat) like the
-        // forward statistics (in-lane over the pixel fragments, DPP row sums over the 16 pixel lanes, waves in order,
-        // one fp64 atomic per channel and workgroup) and writes the result back over the bytes it read; the tile leaves
-        // through the same 16-byte coalesced stores as every other epilogue.
-        auto dma_bnbwd = [&](auto actb_tag) {
+        // ---- BatchNorm-backward epilogue, round-4 form: SLICED and software-pipelined.  The round-3 form fetched the raw conv
+        // output of the whole tile by LDS-DMA, waited, computed, then stored: three serial phases (tools/lt_probe.py: 15 us behind
+        // an 18.6 us K loop on 3x3 128->128 @64x80), and its per-lane cell reads (16 pixel lanes x 256-byte dense rows) were 16-way
+        // bank conflicts.  Here the tile is walked in NI slices of 16 pixels per wave column (slice ni = accumulator column ni of
+        // every wave): the raw output (and the chain addend) of slice ni+2 is in flight by LDS-DMA while slice ni is computed and
+        // the coalesced stores of slices ni-1, ni-2 drain -- one counted s_waitcnt vmcnt per slice (stores count too: every
+        // thread issues the same number per slice, so the immediates are exact), raw s_barrier (a __syncthreads() would drain
+        // vmcnt(0)).  Rows are dense (a DMA instruction fills whole rows) with the 16-byte chunk XOR-swizzled by the row index on
+        // the SOURCE side: the 16 pixel lanes of a cell read hit 16 different chunks.  BatchNorm vectors sit in LDS; sums are kept
+        // in registers across the slices and folded once (DPP row sums, waves in order, one fp64 atomic per channel).
+        // Full tiles only (every pixel and channel of the tile valid -- the caller checks); ragged tiles take staged_bnbwd.
+        auto sliced_bnbwd = [&](auto actb_tag, auto chain_tag) __attribute__((always_inline)) {
             constexpr int ACTB = decltype(actb_tag)::value;
+            constexpr bool CH = decltype(chain_tag)::value;
             constexpr int eso = (int)sizeof(T);
-            constexpr int RB = BM * eso;                          // dense tile row (bytes)
-            constexpr int CPRW = RB / 16;                         // 16-byte chunks per row
-            constexpr int RPI = 64 / CPRW;                        // tile rows per DMA wave instruction
-            constexpr int NIY = BN * CPRW / 64;                   // DMA instructions per tile
             constexpr int EPVT = 16 / eso;
-            static_assert(64 % CPRW == 0 && (BN * CPRW) % 64 == 0, "tile must be whole DMA instructions");
+            constexpr int RB = BM * eso;                          // dense row (bytes)
+            constexpr int CPRW = RB / 16;                         // 16-byte chunks per row
+            constexpr int RPI = 64 / CPRW;                        // rows per DMA instruction
+            constexpr int SLP = 16 * WN;                          // pixels per slice
+            constexpr int SB = SLP * RB;                          // bytes per slice buffer
+            constexpr int NIS = SB / 1024;                        // DMA instructions per slice and tensor
+            constexpr int NDU = NIS / NWV;                        // ... per wave (= 16-byte stores per thread and slice)
+            constexpr int D = NDU * (CH ? 2 : 1);                 // DMA instructions per wave and slice
+            static_assert(NIS % NWV == 0 && NDU >= 1 && 64 % CPRW == 0, "sliced epilogue: uniform DMA / store counts");
             const int wv = __builtin_amdgcn_readfirstlane(wid);
-            const bool chain = (flags & DYK_EPI_ADDEND) != 0;
-            const T* zero = (const T*)dyk_zero_page;
-            auto dma_tile = [&](const T* base, const int* t_pix) {
+            float* s_par = (float*)sC;                            // [4][BM]: scale, shift, mean, rstd of the tile's channels
+            char* ubuf = sC + 4 * BM * 4;                         // [3][SB] raw output slices; chain mode: + [3][SB] addend slices
+            const unsigned ubuf_u = lds_addr_of(ubuf);
+            for (int e = tid; e < 4 * BM; e += NT) {
+                const int k = e / BM, c = e - k * BM;
+                const float* src = k == 0 ? a.scale : (k == 1 ? a.shift : (k == 2 ? a.aux0 : a.aux1));
+                s_par[e] = src[m0 + c];
+            }
+            // slice-local row r -> tile pixel: wave column r / 16, accumulator column ni, lane pixel r % 16
+            auto dma_slice = [&](int ni, int buf) __attribute__((always_inline)) {
 #pragma unroll
-                for (int j = 0; j < (NIY + NWV - 1) / NWV; ++j) {
+                for (int j = 0; j < NDU; ++j) {
                     const int inst = j * NWV + wv;
-                    if (inst < NIY) {
-                        const int row = inst * RPI + lane / CPRW, ch = (lane % CPRW) * EPVT;
-                        const bool ok = t_out[row] >= 0 && m0 + ch + EPVT <= a.Cout;
-                        const T* src = ok ? base + (long)t_pix[row] + m0 + ch : zero;
-                        glds16(src, lds_addr_of(sC + inst * 1024));
-                    }
+                    const int r = inst * RPI + lane / CPRW, pc = lane % CPRW;
+                    const int nl = (r >> 4) * WTN + ni * 16 + (r & 15);
+                    const int ch = (pc ^ (r & (CPRW - 1))) * EPVT;          // logical chunk stored at physical chunk pc
+                    glds16((const T*)a.res + (long)t_res[nl] + m0 + ch, ubuf_u + buf * SB + inst * 1024);
+                    if constexpr (CH) glds16((const T*)a.add + (long)t_out[nl] + m0 + ch, ubuf_u + (3 + buf) * SB + inst * 1024);
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
             };
-            if (chain) {
-                // dz = acc + addend, rounded to the storage type: the apply pass will see the rounded value, so da below is
-                // formed from it
-                dma_tile((const T*)a.add, t_out);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // (the vector loads above)
+            __builtin_amdgcn_s_barrier();                          // tables / parameters visible; the rings are free
+            dma_slice(0, 0);
+            if constexpr (NI > 1) dma_slice(1, 1);
+            float s1[MI][4], s2[MI][4];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s1[mi][r] = s2[mi][r] = 0.f;
+            const int prow = wn * 16 + (lane & 15);               // this lane's row of a slice buffer
+            auto slice = [&](auto ni_tag) __attribute__((always_inline)) {
+                constexpr int ni = decltype(ni_tag)::value;
+                constexpr int buf = ni % 3;
+                // everything older than the DMA of slice ni has completed: younger are the stores of slices ni-2, ni-1 and the
+                // DMA of slice ni+1
+                constexpr int young = (ni == 0 ? (NI > 1 ? D : 0)
+                                               : (ni == 1 ? NDU + (NI > 2 ? D : 0) : 2 * NDU + (ni + 1 < NI ? D : 0)));
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(young) : "memory");
+                __builtin_amdgcn_s_barrier();                      // the whole slice has landed; slice ni-1's buffer reads are done
+                if constexpr (ni + 2 < NI) dma_slice(ni + 2, (ni + 2) % 3);
+                char* ub = ubuf + buf * SB + prow * RB;
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const int ml = wm * WTM + mi * 16 + mlane;
+                    const int off = (((ml * eso) >> 4) ^ (prow & (CPRW - 1))) * 16 + ((ml * eso) & 15);
+                    // (opaque per slice: the compiler otherwise reads the 16 x MI BatchNorm values once and keeps them live across
+                    // all slices -- spills, and a scratch reload waits vmcnt(0): it would drain the DMA pipeline)
+                    int po = ml;
+                    asm volatile("" : "+v"(po));
+                    const float4 sc = *(const float4*)(s_par + po), sh = *(const float4*)(s_par + BM + po);
+                    const float4 mu = *(const float4*)(s_par + 2 * BM + po), rs = *(const float4*)(s_par + 3 * BM + po);
+                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+                    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+                    float yv[4], g[4];
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        const int nl = wn * WTN + ni * 16 + (lane & 15);
-                        const char* src = sC + nl * RB + ml * eso;
-                        if constexpr (sizeof(T) == 4) {
-                            const float4 v = *(const float4*)src;
-                            acc[mi][ni][0] += v.x; acc[mi][ni][1] += v.y; acc[mi][ni][2] += v.z; acc[mi][ni][3] += v.w;
-                        } else {
-                            const uint2 v = *(const uint2*)src;
-                            acc[mi][ni][0] += __uint_as_float(v.x << 16); acc[mi][ni][1] += __uint_as_float(v.x & 0xffff0000u);
-                            acc[mi][ni][2] += __uint_as_float(v.y << 16); acc[mi][ni][3] += __uint_as_float(v.y & 0xffff0000u);
-                            const uint32_t p0 = f32x2_to_bf16x2(acc[mi][ni][0], acc[mi][ni][1]), p1 = f32x2_to_bf16x2(acc[mi][ni][2], acc[mi][ni][3]);
-                            acc[mi][ni][0] = __uint_as_float(p0 << 16); acc[mi][ni][1] = __uint_as_float(p0 & 0xffff0000u);
-                            acc[mi][ni][2] = __uint_as_float(p1 << 16); acc[mi][ni][3] = __uint_as_float(p1 & 0xffff0000u);
-                        }
-                    }
-                }
-                __syncthreads();                                  // everybody has read the addend: the tile area is free again
-            }
-            dma_tile((const T*)a.res, t_res);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int ml = wm * WTM + mi * 16 + mlane;
-                const int m = m0 + ml;
-                float sc[4], sh[4], mu[4], rs[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool okc = m + r < a.Cout;
-                    sc[r] = okc ? a.scale[m + r] : 0.f; sh[r] = okc ? a.shift[m + r] : 0.f;
-                    mu[r] = okc ? a.aux0[m + r] : 0.f; rs[r] = okc ? a.aux1[m + r] : 0.f;
-                }
-                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int nl = wn * WTN + ni * 16 + (lane & 15);
-                    char* cell = sC + nl * RB + ml * eso;
-                    float yv[4];
+                    for (int r = 0; r < 4; ++r) g[r] = acc[mi][ni][r];
                     if constexpr (sizeof(T) == 4) {
-                        const float4 v = *(const float4*)cell;
+                        const float4 v = *(const float4*)(ub + off);
                         yv[0] = v.x; yv[1] = v.y; yv[2] = v.z; yv[3] = v.w;
+                        if constexpr (CH) {
+                            const float4 w = *(const float4*)(ub + 3 * SB + off);
+                            g[0] += w.x; g[1] += w.y; g[2] += w.z; g[3] += w.w;
+                        }
                     } else {
-                        const uint2 v = *(const uint2*)cell;
+                        const uint2 v = *(const uint2*)(ub + off);
                         yv[0] = __uint_as_float(v.x << 16); yv[1] = __uint_as_float(v.x & 0xffff0000u);
                         yv[2] = __uint_as_float(v.y << 16); yv[3] = __uint_as_float(v.y & 0xffff0000u);
+                        if constexpr (CH) {
+                            // dz = acc + addend, rounded to the storage type: the apply pass will see the rounded value
+                            const uint2 w = *(const uint2*)(ub + 3 * SB + off);
+                            g[0] += __uint_as_float(w.x << 16); g[1] += __uint_as_float(w.x & 0xffff0000u);
+                            g[2] += __uint_as_float(w.y << 16); g[3] += __uint_as_float(w.y & 0xffff0000u);
+                            const uint32_t p0 = f32x2_to_bf16x2(g[0], g[1]), p1 = f32x2_to_bf16x2(g[2], g[3]);
+                            g[0] = __uint_as_float(p0 << 16); g[1] = __uint_as_float(p0 & 0xffff0000u);
+                            g[2] = __uint_as_float(p1 << 16); g[3] = __uint_as_float(p1 & 0xffff0000u);
+                        }
                     }
-                    const bool livep = t_out[nl] >= 0;            // (ragged tile rows: zero page, accumulators of padding pixels)
                     float outv[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float g = acc[mi][ni][r];
-                        const float da = g * act_bwd_c<ACTB>(yv[r] * sc[r] + sh[r], a.act);
-                        if (livep) { s1[r] += da; s2[r] += da * ((yv[r] - mu[r]) * rs[r]); }
-                        outv[r] = chain ? g : da;
+                        const float da = g[r] * act_bwd_c<ACTB>(yv[r] * scv[r] + shv[r], a.act);
+                        s1[mi][r] += da;
+                        s2[mi][r] += da * ((yv[r] - muv[r]) * rsv[r]);
+                        outv[r] = CH ? g[r] : da;
                     }
                     if constexpr (sizeof(T) == 4) {
-                        *(float4*)cell = make_float4(outv[0], outv[1], outv[2], outv[3]);
+                        *(float4*)(ub + off) = make_float4(outv[0], outv[1], outv[2], outv[3]);
                     } else {
                         uint2 pk;
                         pk.x = f32x2_to_bf16x2(outv[0], outv[1]);
                         pk.y = f32x2_to_bf16x2(outv[2], outv[3]);
-                        *(uint2*)cell = pk;
+                        *(uint2*)(ub + off) = pk;
                     }
+                    // (the running sums are made opaque here: the optimizer otherwise sinks the whole chain of adds to the end of the
+                    // epilogue and keeps every slice's da / da * xhat products live until then -- 35 more registers per slice)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(s1[mi][r]), "+v"(s2[mi][r]));
                 }
+                // (pin the slice: register-only arithmetic is free to move across barriers and asm statements, and the scheduler
+                // otherwise defers the derivative / sum arithmetic of ALL slices to the end of the block, keeping every slice's
+                // operands live -- 1 450 spilled registers in the 128 x 160 kernels)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                      // the slice's results are in its buffer
+#pragma unroll
+                for (int j = 0; j < NDU; ++j) {
+                    const int q = tid + j * NT;
+                    const int r = q / CPRW, pc = q % CPRW;
+                    const int nl = (r >> 4) * WTN + ni * 16 + (r & 15);
+                    const int mc = m0 + (pc ^ (r & (CPRW - 1))) * EPVT;
+                    *(uint4*)((T*)a.y + (long)t_out[nl] + mc) = *(const uint4*)(ubuf + buf * SB + r * RB + pc * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            dyk_static_for<NI>(slice);
+            // fold the sums: DPP row sums over the 16 pixel lanes, one LDS slot per wave column, waves in order
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int ml = wm * WTM + mi * 16 + mlane;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float t1 = row16_sum(s1[r]), t2 = row16_sum(s2[r]);
+                    const float t1 = row16_sum(s1[mi][r]), t2 = row16_sum(s2[mi][r]);
                     if ((lane & 15) == 0) {
                         s_stat[(wn * 2 + 0) * BM + ml + r] = t1;
                         s_stat[(wn * 2 + 1) * BM + ml + r] = t2;
                     }
                 }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             for (int e = tid; e < 2 * BM; e += NT) {
                 const int ml = e % BM, which = e / BM;
-                if (m0 + ml < a.Cout) {
-                    float tot = 0.f;
+                float tot = 0.f;
 #pragma unroll
-                    for (int q = 0; q < WN; ++q) tot += s_stat[(q * 2 + which) * BM + ml];
-                    double* st = a.stats + (size_t)((unsigned)blk % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
-                    atomicAdd(st + which * a.Cout + m0 + ml, (double)tot);
-                }
-            }
-            constexpr int nchunk = BN * CPRW;
-            for (int q = tid; q < nchunk; q += NT) {
-                const int row = q / CPRW, cc = q % CPRW;
-                const int po = t_out[row];
-                const int mc = m0 + cc * EPVT;
-                if (po < 0 || mc + EPVT > a.Cout) continue;
-                *(uint4*)((T*)a.y + (long)po + mc) = *(const uint4*)(sC + row * RB + cc * 16);
+                for (int q = 0; q < WN; ++q) tot += s_stat[(q * 2 + which) * BM + ml];
+                double* st = a.stats + (size_t)((unsigned)blk % (unsigned)(a.stats_slots > 0 ? a.stats_slots : 1)) * 2 * a.Cout;
+                atomicAdd(st + which * a.Cout + m0 + ml, (double)tot);
             }
         };
 
@@ -726,25 +770,37 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& desc, f32x4_t (
             }
             return;
         } else if constexpr (EPIK == 1) {
-            // Measured (round 3, same box, every launch alone): the LDS-DMA form takes 10 % off the plain fused epilogue
-            // (3x3 128->128 @64x80: 70 -> 64 us, 64->32 @256x320 -9 %), but in chain mode (addend + raw output = two
-            // dependent DMA round trips with a barrier each) it LOSES 10-25 % against the batched register form (1x1
-            // 128->128 @64x80: 32 -> 38 us): each mode keeps its faster form.  tune bit 21 forces the register form.
-            if ((flags & DYK_EPI_ADDEND) || ((a.tune >> 21) & 1)) {
-                switch (a.act) {
-                case DYK_ACT_LINEAR: staged_bnbwd(integral_constant<int, DYK_ACT_LINEAR>{}); break;
-                case DYK_ACT_LEAKY: staged_bnbwd(integral_constant<int, DYK_ACT_LEAKY>{}); break;
-                case DYK_ACT_MISH: staged_bnbwd(integral_constant<int, DYK_ACT_MISH>{}); break;
-                default: staged_bnbwd(integral_constant<int, -1>{}); break;
+            // full tiles: the sliced, pipelined form (plain and residual-chain); ragged tiles (a pixel or channel of the tile
+            // outside the problem), tile shapes whose slices do not split evenly over the waves, and tune bit 21: the batched
+            // register form
+            constexpr bool SLICED_OK = ((16 * WN * BM * (int)sizeof(T)) / 1024) % NWV == 0 && (16 * WN * BM * (int)sizeof(T)) / 1024 >= NWV
+                                       && 64 % (BM * (int)sizeof(T) / 16) == 0;
+            const bool full = m0 + BM <= a.Cout && t_out[BN - 1] >= 0;
+#ifndef DYK_X_NOSLICED
+            if constexpr (SLICED_OK) {
+                if (full && !((a.tune >> 21) & 1)) {
+                    const bool chain = (flags & DYK_EPI_ADDEND) != 0;
+#ifdef DYK_X_ONLY1
+                    sliced_bnbwd(integral_constant<int, DYK_ACT_MISH>{}, false_type{}); return;
+#endif
+                    switch (a.act) {
+                    case DYK_ACT_LINEAR: if (chain) sliced_bnbwd(integral_constant<int, DYK_ACT_LINEAR>{}, true_type{}); else sliced_bnbwd(integral_constant<int, DYK_ACT_LINEAR>{}, false_type{}); break;
+                    case DYK_ACT_LEAKY: if (chain) sliced_bnbwd(integral_constant<int, DYK_ACT_LEAKY>{}, true_type{}); else sliced_bnbwd(integral_constant<int, DYK_ACT_LEAKY>{}, false_type{}); break;
+                    case DYK_ACT_MISH: if (chain) sliced_bnbwd(integral_constant<int, DYK_ACT_MISH>{}, true_type{}); else sliced_bnbwd(integral_constant<int, DYK_ACT_MISH>{}, false_type{}); break;
+                    default: if (chain) sliced_bnbwd(integral_constant<int, -1>{}, true_type{}); else sliced_bnbwd(integral_constant<int, -1>{}, false_type{}); break;
+                    }
+                    return;
                 }
-                return;
             }
+#endif
+#ifndef DYK_X_NOSTAGED
             switch (a.act) {
-            case DYK_ACT_LINEAR: dma_bnbwd(integral_constant<int, DYK_ACT_LINEAR>{}); break;
-            case DYK_ACT_LEAKY: dma_bnbwd(integral_constant<int, DYK_ACT_LEAKY>{}); break;
-            case DYK_ACT_MISH: dma_bnbwd(integral_constant<int, DYK_ACT_MISH>{}); break;
-            default: dma_bnbwd(integral_constant<int, -1>{}); break;
+            case DYK_ACT_LINEAR: staged_bnbwd(integral_constant<int, DYK_ACT_LINEAR>{}); break;
+            case DYK_ACT_LEAKY: staged_bnbwd(integral_constant<int, DYK_ACT_LEAKY>{}); break;
+            case DYK_ACT_MISH: staged_bnbwd(integral_constant<int, DYK_ACT_MISH>{}); break;
+            default: staged_bnbwd(integral_constant<int, -1>{}); break;
             }
+#endif
             return;
         } else {
             if (out_f32) {
@@ -1393,13 +1449,18 @@ int launch_conv_halo(const DykConvDesc* d, hipStream_t stream) {
     constexpr size_t ring = 3 * (size_t)BM * BKB + 2 * (size_t)NB * 1024;
     constexpr size_t hsrc = (size_t)NB * 64 * 4;
     const bool of32 = (d->flags & DYK_EPI_OUT_F32) != 0;
-    const size_t stage_c = (size_t)BN * (BM * (of32 ? 4 : 2) + 16);
+    size_t stage_c = (size_t)BN * (BM * (of32 ? 4 : 2) + 16);
+    if constexpr (EPIK == 1) {
+        const size_t need = bnbwd_sliced_bytes<T, BM, WaveGrid<BM, BN>::WN>((d->flags & DYK_EPI_ADDEND) != 0);
+        if (need > stage_c) stage_c = need;
+    }
     const size_t body = ring + hsrc > stage_c ? ring + hsrc : stage_c;
     const size_t lds = halo_table_bytes<BM, TH>() + body;
     static bool attr_set = false;
     auto kfn = conv_halo_kernel<T, BM, TH, BKB, EPIK>;
     if (!attr_set) {
-        constexpr size_t sc_max = (size_t)BN * (BM * 4 + 16);
+        constexpr size_t sc_max = (size_t)BN * (BM * 4 + 16) > bnbwd_sliced_bytes<T, BM, WaveGrid<BM, BN>::WN>(true)
+                                      ? (size_t)BN * (BM * 4 + 16) : bnbwd_sliced_bytes<T, BM, WaveGrid<BM, BN>::WN>(true);
         constexpr size_t lds_max = halo_table_bytes<BM, TH>() + (ring + hsrc > sc_max ? ring + hsrc : sc_max);
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_set = true;
@@ -1443,12 +1504,18 @@ int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     static_assert(KG == 1 || ring >= (size_t)BM * BN * 4, "park area");
     static_assert(table_bytes<BN>() + ring <= 160 * 1024 || KG == 1, "LDS budget");
     const bool of32 = (d->flags & DYK_EPI_OUT_F32) || sizeof(T) == 4;
-    const size_t stage_c = (size_t)BN * (BM * (of32 ? 4 : 2) + 16);
+    size_t stage_c = (size_t)BN * (BM * (of32 ? 4 : 2) + 16);
+    if constexpr (EPIK == 1) {
+        const size_t need = bnbwd_sliced_bytes<T, BM, WaveGrid<BM, BN>::WN>((d->flags & DYK_EPI_ADDEND) != 0);
+        if (need > stage_c) stage_c = need;
+    }
     const size_t lds = TABLE_BYTES + (ring > stage_c ? ring : stage_c);
     static bool attr_set = false;
     auto kfn = conv_igemm_kernel<T, BM, BN, BKB, PIPE, KG, EPIK>;
     if (!attr_set) {
-        constexpr size_t lds_max = TABLE_BYTES + (ring > (size_t)BN * (BM * 4 + 16) ? ring : (size_t)BN * (BM * 4 + 16));
+        constexpr size_t sc_max = (size_t)BN * (BM * 4 + 16) > bnbwd_sliced_bytes<T, BM, WaveGrid<BM, BN>::WN>(true)
+                                      ? (size_t)BN * (BM * 4 + 16) : bnbwd_sliced_bytes<T, BM, WaveGrid<BM, BN>::WN>(true);
+        constexpr size_t lds_max = TABLE_BYTES + (ring > sc_max ? ring : sc_max);
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_set = true;
     }

@@ -336,7 +336,11 @@ int launch_conv_lt(const DykConvDesc* d, hipStream_t stream) {
     LtGeom g;
     if (!lt_pick_patch(d->Hi, d->Wi, BN, GW, (d->tune >> 24) & 0xf, g)) return DYK_ERR_UNSUPPORTED;
     const size_t ring = (size_t)lt_rings_off<BM, BN>() + (size_t)KG * (LT_NA * (size_t)BM * LT_ROWB + 2 * (size_t)g.NB * 1024);
-    const size_t stage_c = lt_table_bytes<BM, BN>() + (size_t)BN * (BM * 2 + 16);
+    size_t stage_c = lt_table_bytes<BM, BN>() + (size_t)BN * (BM * 2 + 16);
+    if constexpr (EPIK == 1) {
+        const size_t need = lt_table_bytes<BM, BN>() + bnbwd_sliced_bytes<bf16_t, BM, WNn>((d->flags & DYK_EPI_ADDEND) != 0);
+        if (need > stage_c) stage_c = need;
+    }
     const size_t park = KG > 1 ? lt_table_bytes<BM, BN>() + (size_t)GW * 64 * 20 * 16 : 0;
     size_t lds = ring > stage_c ? ring : stage_c;
     if (park > lds) lds = park;

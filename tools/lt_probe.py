@@ -21,6 +21,8 @@ SHAPES = [  # (Cin, Cout, H, W) of the forward conv, B = 16
 ]
 if "quick" in what:
     SHAPES = SHAPES[:3]
+if "thin" in what:
+    SHAPES = [(32, 64, 256, 320), (64, 128, 128, 160), (64, 64, 128, 160)]
 B = 16
 fn = L.load().dyk_conv_igemm
 
@@ -88,6 +90,8 @@ for (ci, co, H, W) in SHAPES:
         gen.sort()
         d.tune = gen[0][1]
         tg = timeit(d)
+        if "thin" in what:
+            print("   top generic:", " ".join("%#x:%.1f" % (c, t) for t, c in gen[:8]), flush=True)
         row = "%-16s c%d>%d @%dx%d  generic %#x %.1f us (%.0f TF) |" % (name, ci, co, H, W, gen[0][1], tg, fl / tg / 1e6)
         best = None
         for c in lt_tunes():
