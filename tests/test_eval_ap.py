@@ -166,3 +166,100 @@ def test_bf16_path_layer_by_layer_against_bf16_emulating_oracle(monkeypatch):
     # heads: fp32 outputs of the last convs, computed by the oracle from the HIP path's own inputs
     for a_, b_ in zip(p, p_e):
         assert float((a_.cpu() - b_).abs().max()) <= 2e-2 * float(b_.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Round 4: AP parity on a network with SEPARATED scores.  tests/golden/evalap_trained.npz was written by the
+# reference (make_golden_round4.py): the target cfg with seeded, WELL-CONDITIONED weights (identity tap + 0.3 x He noise:
+# R4.conditioned_state -- pure random weights are chaotic, bf16 rounding alone reaches 55-80 % of the tensor norm at the head
+# inputs of the reference's own arithmetic), BatchNorm statistics calibrated on a synthetic set of upright bright rectangles
+# (labelled) and flat ones (distractors), its three head convs trained for 150 Adam steps with the reference's own
+# compute_loss, then the reference's evaluation chain: AP 0.865, LAMR 0.297, scores bimodal.  Measured on this fixture:
+# the oracle in bf16-emulating arithmetic gives AP 0.8615 (-0.31 AP points: what bf16 storage of activations costs on
+# this network in ANY implementation); the bf16 MFMA path is held to the fp32 REFERENCE within 1 AP point and to the
+# emulating oracle within half a point; the fp32 path to the reference within 0.1 point.
+import make_golden_round4 as R4  # noqa: E402
+
+GOLD4 = np.load(os.path.join(GOLDEN, "evalap_trained.npz"))
+
+
+def _state4():
+    net = oracle_net(R4.CFG)
+    sd = R4.conditioned_state(net.synth_state(R4.SEED_W))
+    for k in GOLD4.files:
+        if k.startswith(("bn|", "head|")):
+            sd[k.split("|", 1)[1]] = torch.from_numpy(GOLD4[k])
+    return net, sd
+
+
+def _preds4(dets, scale_coords):
+    preds = []
+    for idx, p in enumerate(dets):
+        if p is None:
+            continue
+        boxes = scale_coords((R4.H, R4.W), p[:, :4].clone(), R4.SHAPE0, R4.RATIO_PAD)
+        boxes, conf = boxes.cpu().numpy(), p[:, 4].cpu().numpy()
+        preds += [{"img_id": idx, "conf": float(conf[i]), "bbox": boxes[i]} for i in range(boxes.shape[0])]
+    preds.sort(key=lambda q: q["conf"], reverse=True)
+    return preds
+
+
+def test_oracle_eval_chain_reproduces_the_trained_reference_ap():
+    from oracle import metrics as ometrics, nms as onms
+    net, sd = _state4()
+    v, l, targets = R4.dataset()
+    assert targets.shape[0] == int(GOLD4["n_targets"])
+    with torch.no_grad():
+        io, _ = net.forward(sd, v.float() / 255.0, l.float() / 255.0, training=False)
+    assert np.allclose(io.numpy(), GOLD4["io"], rtol=2e-4, atol=2e-4)
+    dets = onms.non_max_suppression(io, conf_thres=R4.CONF, iou_thres=R4.IOU, multi_label=False)
+    labels, shapes = R4.labels_of(targets)
+    res = ometrics.compute_ap_lamr(_preds4(dets, onms.scale_coords), [lb.copy() for lb in labels], shapes)
+    assert abs(res["ap"] - float(GOLD4["ap"])) < 1e-6 and abs(res["lamr"] - float(GOLD4["lamr"])) < 1e-6
+    # the fixture is what it claims to be: an informative AP (not saturated) on separated scores
+    assert 0.8 < float(GOLD4["ap"]) < 0.99
+    hist = GOLD4["score_hist"]
+    assert hist[0] > 100 * hist[1:].sum() / 10 and hist[5:].sum() >= 25      # a background mode and a confident mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_hip_eval_chain_matches_trained_reference_ap(dtype):
+    """north_star: "eval AP@IoU=0.5 within +-0.1 of the reference on identical inputs".  fp32 path: 0.1 AP POINTS (1e-3 absolute)
+    of the fp32 reference.  bf16 MFMA path: within 1 AP point of the fp32 reference (bf16 storage itself costs 0.31 points on
+    this network: emulating oracle) and within half a point of the oracle run with the same roundings."""
+    from build_utils.parse_config import materialize_cfg
+    from build_utils.utils import non_max_suppression, scale_coords
+    from models import YOLO
+    from other_utils.metrics import compute_ap_lamr
+    _, sd = _state4()
+    torch.manual_seed(0)
+    m = YOLO(materialize_cfg(R4.CFG))
+    m.load_state_dict(sd)
+    m.dyk_dtype = dtype
+    m = m.cuda().eval()
+    v, l, targets = R4.dataset()
+    with torch.no_grad():
+        io, _ = m(v.cuda().float() / 255.0, l.cuda().float() / 255.0)
+    dets = non_max_suppression(io, conf_thres=R4.CONF, iou_thres=R4.IOU, multi_label=False)
+    labels, shapes = R4.labels_of(targets)
+    res = compute_ap_lamr(_preds4(dets, scale_coords), [lb.copy() for lb in labels], shapes)
+    ndet = sum(0 if d is None else d.shape[0] for d in dets)
+    print("trained-head net, %s: AP %.5f (reference %.5f)  LAMR %.5f (reference %.5f)  %d detections (reference %d)"
+          % (dtype, res["ap"], GOLD4["ap"], res["lamr"], GOLD4["lamr"], ndet, int(GOLD4["ndet"].sum())))
+    tol_ap, tol_lamr = (1e-3, 5e-3) if dtype == "fp32" else (1e-2, 4e-2)
+    assert abs(res["ap"] - float(GOLD4["ap"])) <= tol_ap, (res["ap"], float(GOLD4["ap"]))
+    assert abs(res["lamr"] - float(GOLD4["lamr"])) <= tol_lamr, (res["lamr"], float(GOLD4["lamr"]))
+    if dtype == "bf16":
+        # second anchor: the oracle with the same roundings (conv operands and stored activations in bf16)
+        from oracle import metrics as ometrics, nms as onms
+        net, _ = _state4()
+        with torch.no_grad():
+            io_e, _ = net.forward(sd, v.float() / 255.0, l.float() / 255.0, training=False, emulate_bf16=True)
+        dets_e = onms.non_max_suppression(io_e, conf_thres=R4.CONF, iou_thres=R4.IOU, multi_label=False)
+        emu = ometrics.compute_ap_lamr(_preds4(dets_e, onms.scale_coords), [lb.copy() for lb in labels], shapes)
+        print("bf16-emulating oracle: AP %.5f LAMR %.5f" % (emu["ap"], emu["lamr"]))
+        assert abs(res["ap"] - emu["ap"]) <= 5e-3, (res["ap"], emu["ap"])
+    if dtype == "fp32":
+        rel = float((io.cpu() - torch.from_numpy(GOLD4["io"])).abs().max()) / float(np.abs(GOLD4["io"]).max())
+        assert rel < 2e-4, rel
