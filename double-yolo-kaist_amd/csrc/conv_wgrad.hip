@@ -745,6 +745,10 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(float* __restrict__ G,
 
 }  // namespace
 
+// row-block 3x3 kernel (conv_wgrad_rb.hip): tune bits 28..30 == 2; bits 8..15 == 2 selects 256-pixel K steps
+bool dyk_wgrad_rb_eligible(const DykWgradDesc* d);
+int dyk_wgrad_rb_dispatch(const DykWgradDesc* d, hipStream_t s, int* query);
+
 static int wgrad_validate(const DykWgradDesc* d) {
     if (!d || !d->x || !d->dy || !d->dw) return DYK_ERR_ARG;
     if (d->ntaps <= 0 || d->ntaps > DYK_MAX_TAPS) return DYK_ERR_ARG;
@@ -770,6 +774,7 @@ extern "C" int dyk_conv_wgrad(const DykWgradDesc* d, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     if (((d->tune >> 28) & 7) == 1 && mt_eligible(d)) return dispatch_wgrad_mt(d, s, nullptr);    // multi-tap 3x3 variant
+    if (((d->tune >> 28) & 7) == 2 && dyk_wgrad_rb_eligible(d)) return dyk_wgrad_rb_dispatch(d, s, nullptr);   // row-block 3x3 variant
     if (d->dtype == DYK_BF16) return dispatch_wgrad<bf16_t>(d, s, nullptr);
     if (d->dtype == DYK_F32) return dispatch_wgrad<float>(d, s, nullptr);
     return DYK_ERR_ARG;
@@ -781,9 +786,17 @@ extern "C" int dyk_conv_wgrad_splits(const DykWgradDesc* d) {
     int q = 0;
     int rc = DYK_ERR_ARG;
     if (((d->tune >> 28) & 7) == 1 && mt_eligible(d)) rc = dispatch_wgrad_mt(d, nullptr, &q);
+    else if (((d->tune >> 28) & 7) == 2 && dyk_wgrad_rb_eligible(d)) rc = dyk_wgrad_rb_dispatch(d, nullptr, &q);
     else if (d->dtype == DYK_BF16) rc = dispatch_wgrad<bf16_t>(d, nullptr, &q);
     else if (d->dtype == DYK_F32) rc = dispatch_wgrad<float>(d, nullptr, &q);
     return rc == DYK_OK ? q : rc;
+}
+
+extern "C" int dyk_conv_wgrad_variant(const DykWgradDesc* d) {
+    if (!d || d->ntaps <= 0 || d->ntaps > DYK_MAX_TAPS) return DYK_ERR_ARG;
+    if (((d->tune >> 28) & 7) == 1 && mt_eligible(d)) return 1;
+    if (((d->tune >> 28) & 7) == 2 && dyk_wgrad_rb_eligible(d)) return 2;
+    return 0;
 }
 
 extern "C" int dyk_grad_reduce(float* G, const float* part, const DykGradReduceEntry* tab, int32_t n_entries,

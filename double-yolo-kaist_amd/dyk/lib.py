@@ -178,6 +178,7 @@ SIGNATURES = {
     "dyk_conv_grid": (_i32, [_P(DykConvDesc)]),
     "dyk_conv_wgrad": (_i32, [_P(DykWgradDesc), _vp]),
     "dyk_conv_wgrad_splits": (_i32, [_P(DykWgradDesc)]),
+    "dyk_conv_wgrad_variant": (_i32, [_P(DykWgradDesc)]),
     "dyk_grad_reduce": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dyk_bn_finalize": (_i32, [_P(DykBnFinalizeDesc), _vp]),
     "dyk_bn_finalize_act_fwd": (_i32, [_P(DykBnFinalizeDesc), _P(DykEwDesc), _vp]),

@@ -1487,8 +1487,13 @@ def _conv_candidates(d):
     return out
 
 
+WGRAD_EXCLUSIVE = 1 << 20      # the plan's weight gradients have one writer each (store.g_ptr per weight, commands ordered by
+                                # their write sets): a single-split row-block launch may read-add-write instead of atomics
 _WGRAD_CANDIDATES = [2, 3, 2 | (2 << 8), 2 | (1 << 24), 3 | (1 << 24), 2 | (2 << 8) | (1 << 24), 2 | (1 << 28)]
+if os.environ.get("DYK_WGRAD_RB", "1") != "0":
+    _WGRAD_CANDIDATES.append(2 | (1 << 8) | (2 << 28) | WGRAD_EXCLUSIVE)
 # LDS ring stages (2 | 3; 4 exists in the kernel, measured never the fastest: DESIGN 9.4) | K-groups per workgroup << 8 | tile cap << 24 (1 = 64 x 64) | 1 << 28 = multi-tap 3x3 kernel
+# | 2 << 28 = row-block 3x3 kernel (round 4: 128-pixel block steps, 64 x 32 x 9-tap tiles)
 
 
 def _time_launch(fn, desc, stream, reps=3):

@@ -200,8 +200,12 @@ typedef struct DykWgradDesc {
     int32_t lddw;                   /* row stride of dw in floats; <= 0 means Cin */
     int32_t tune;                   /* 0 = default; else LDS ring stages (2 | 3) | K-groups per workgroup (1 | 2) << 8 | tile cap << 24
                                        (1 = tiles of at most 64 x 64: more tiles, fewer K splits for small GEMMs) | 1 << 28: multi-tap
-                                       kernel (3x3 / pad 1, bf16, Wo % 32 == 0: dy and the x halo tile staged once for all nine
-                                       taps; ignored where it does not apply) */
+                                       kernel (3x3 / pad 1, bf16: dy and the x halo tile of a row segment staged once for all nine
+                                       taps; ignored where it does not apply) | 2 << 28: row-block kernel (3x3 / pad 1, bf16:
+                                       K steps of 128 pixels -- 256 with K-groups field = 2 -- shaped nimg x rows x columns to
+                                       fit the map, 64 x 32 x 9-tap tiles; ignored where it does not apply) | 1 << 20: the caller vouches
+                                       that nothing else adds to dw while the launch runs -- a launch with ONE K split may then
+                                       read-add-write its tiles instead of issuing atomics (row-block kernel) */
     const struct DykWgradDesc* twin;/* HOST pointer or NULL: second problem of identical geometry / splits / tune whose x, dy, dw, part
                                        are used (two-problem launch, see DykConvDesc.twin) */
 } DykWgradDesc;
@@ -210,6 +214,10 @@ int dyk_conv_wgrad(const DykWgradDesc* desc, void* stream);
 /* Number of K splits (> 0) dyk_conv_wgrad will use for this descriptor (its `splits` and `tune` included): the
  * number of planes a `part` buffer must hold.  Negative = error code. */
 int dyk_conv_wgrad_splits(const DykWgradDesc* desc);
+/* Which kernel dyk_conv_wgrad runs for this descriptor (its `tune` included): 0 = per-tap split-K kernel, 1 = multi-tap
+ * 3x3 kernel (row segments), 2 = row-block 3x3 kernel (conv_wgrad_rb.hip).  A tune word that asks for a 3x3 variant the
+ * problem is not eligible for falls back to 0.  Negative = error code. */
+int dyk_conv_wgrad_variant(const DykWgradDesc* desc);
 
 /* G[g_off + i] += sum_s part[part_off + s * plane + i], i < n, for every entry of a device table: folds the per-split
  * planes written by dyk_conv_wgrad into the flat gradient buffer, one launch for many layers.  n is a multiple of 4;

@@ -633,6 +633,74 @@ def test_wgrad_multi_tap_kernel(case):
     assert (got.cpu() - ref).abs().max().item() <= tol
 
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # (B, Cin, Cout, Hi, Wi, stride, kkw): K step = nimg x rows x columns of output pixels
+    (2, 32, 64, 16, 16, 1, 1),      # 16 x 8 rows ... one image per step
+    (2, 128, 128, 16, 80, 1, 1),    # the 64x80 maps: 8-column blocks
+    (2, 64, 128, 16, 40, 1, 1),     # the 32x40 maps
+    (4, 64, 64, 16, 20, 1, 1),      # the 16x20 maps: 4-column blocks, two images per step
+    (2, 96, 192, 8, 32, 1, 1),      # three Cin tiles, three Cout tiles
+    (2, 24, 40, 16, 16, 1, 1),      # channel counts off the tiles (zero page, guarded stores)
+    (2, 32, 64, 32, 32, 2, 1),      # stride 2 (halo of 2 x rows + 1)
+    (2, 64, 128, 16, 80, 2, 1),     # stride 2 onto a 40-pixel row
+    (2, 64, 64, 16, 32, 1, 2),      # 256-pixel steps
+    (2, 128, 64, 32, 40, 1, 2),     # 256-pixel steps on a 40-pixel row
+    (1, 32, 64, 128, 160, 1, 1),    # many steps per workgroup, K splits
+])
+def test_wgrad_row_block_kernel(case):
+    """tune bits 28-30 == 2 (conv_wgrad_rb.hip): a K step is a block of 128 / 256 output pixels whose dy tile and x halo tile
+    are staged once for all nine taps; 8 waves = 2 channel halves x 4 K-quarters folded through LDS.  Atomic mode and
+    plane mode against torch's conv2d_weight on the same rounded operands; the kernel must be the one that ran."""
+    import ctypes
+    from dyk import lib as L
+    from dyk import ops
+    B, Cin, Cout, H, W, s, kkw = case
+    k, dtype = 3, torch.bfloat16
+    g = torch.Generator().manual_seed(37)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g).bfloat16().float()
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, stride=s, padding=1).permute(2, 3, 0, 1).reshape(9, Cout, Cin)
+    xd, dyd = ops.to_nhwc(x.cuda(), dtype), ops.to_nhwc(dy.cuda(), dtype)
+    tol = 2e-4 * ref.abs().max().item()
+    tune = 2 | (kkw << 8) | (2 << 28)
+    d = L.DykWgradDesc()
+    d.x, d.dy = xd.data_ptr(), dyd.data_ptr()
+    d.dtype = ops.dtype_code(dtype)
+    d.ldx, d.lddy = ops.nhwc_ld(xd), ops.nhwc_ld(dyd)
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, Cin, Ho, Wo, Cout
+    d.isy = d.isx = s
+    taps = ops.fwd_taps(k, 1)
+    d.ntaps = len(taps)
+    for i, (ty, tx, wt) in enumerate(taps):
+        d.tdy[i], d.tdx[i], d.twt[i] = ty, tx, wt
+    d.tune = tune
+    lib = L.load()
+    assert lib.dyk_conv_wgrad_variant(ctypes.byref(d)) == 2, "the row-block kernel does not cover this case"
+    rb = ops.conv2d_wgrad(xd, dyd, k, s, 1, tune=tune)
+    err = (rb.cpu() - ref).abs().max().item()
+    assert err <= tol, (err, tol)
+    # one K split with the caller's word that dw has no other writer (tune bit 20): read-add-write instead of atomics --
+    # it ACCUMULATES like the atomic form
+    acc0 = torch.full((9, Cout, Cin), 0.5, device="cuda")
+    one = ops.conv2d_wgrad(xd, dyd, k, s, 1, tune=tune | (1 << 20), splits=1, dw=acc0.clone())
+    assert ((one - 0.5).cpu() - ref).abs().max().item() <= tol
+    for want in (0, 3):             # the kernel's own split count, then a given one
+        d.splits, d.part, d.part_stride = want, None, 0
+        splits = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
+        assert splits >= 1 and (want == 0 or splits <= want)
+        plane = 9 * Cout * Cin
+        part = torch.full((max(splits, want) * plane,), float("nan"), device="cuda")
+        G = torch.zeros(plane, device="cuda")
+        d.dw, d.part, d.part_stride, d.splits = G.data_ptr(), part.data_ptr(), plane, max(splits, want)
+        L.check(lib.dyk_conv_wgrad(ctypes.byref(d), None), "dyk_conv_wgrad(row-block, planes)")
+        got = part.view(-1, 9, Cout, Cin).sum(0)
+        assert bool(torch.isfinite(got).all())
+        assert (got.cpu() - ref).abs().max().item() <= tol
+
+
 LT_CASES = [  # (B, Cin, Cout, H, W): forward conv Cin -> Cout, 3x3 / stride 1 / pad 1
     (2, 64, 128, 16, 20), (1, 96, 192, 8, 40), (2, 128, 64, 16, 40), (1, 160, 96, 16, 80), (3, 256, 128, 8, 20),
 ]
