@@ -143,17 +143,50 @@ __device__ inline float act_bwd(int act, float x) {
     switch (act) {
     case DYK_ACT_LEAKY: return x > 0.f ? 1.f : 0.1f;
     case DYK_ACT_MISH: {
+#ifdef DYK_MISH_OLD
         const float e = __expf(fminf(x, 20.f));               // x > 20: t == 1, derivative == 1 (see act_fwd)
         const float n = e * (e + 2.f);
         const float t = n * __builtin_amdgcn_rcpf(n + 2.f);   // tanh(softplus(x))
         const float sg = e * __builtin_amdgcn_rcpf(1.f + e);  // sigmoid(x)
         return t + x * (1.f - t * t) * sg;
+#else
+        // mish(x) = x n / (n + 2), n = e (e + 2), e = exp(x); n' = 2 e (e + 1), so
+        //   mish'(x) = [n (n + 2) + 4 x e (e + 1)] / (n + 2)^2
+        // ONE exponential and ONE reciprocal (the tanh / sigmoid form above takes two reciprocals; the transcendental unit
+        // runs at a quarter of the VALU rate and the step evaluates this ~8 G times: every fused BatchNorm-backward
+        // epilogue and apply pass).  Exponent clamped at 20 as in act_fwd: (n + 2)^2 <= e^80 stays inside fp32, the value is
+        // 1 + O(x e^-40) there.
+        const float e = __expf(fminf(x, 20.f));
+        const float n = e * (e + 2.f);
+        const float d = n + 2.f;
+        const float num = n * d + (4.f * x) * (e * e + e);
+        return num * __builtin_amdgcn_rcpf(d * d);
+#endif
     }
     case DYK_ACT_RELU: return x > 0.f ? 1.f : 0.f;
     case DYK_ACT_RELU6: return (x > 0.f && x < 6.f) ? 1.f : 0.f;
     case DYK_ACT_HSIGMOID: return (x > -3.f && x < 3.f) ? (1.f / 6.f) : 0.f;
     case DYK_ACT_HSWISH: return x < -3.f ? 0.f : (x <= 3.f ? (x * (1.f / 3.f) + 0.5f) : 1.f);
     default: return 1.f;
+    }
+}
+
+// Two values at once (packed fp32 VALU: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process two floats per lane and
+// instruction).  Mish: the same formula as act_bwd above, the exponential and the reciprocal per element (the transcendental
+// unit has no packed form); other activations fall back to the scalar function.
+template <int ACT> __device__ inline dyk_f32x2_t act_bwd2_c(dyk_f32x2_t x, int runtime_act = 0) {
+    if constexpr (ACT == DYK_ACT_MISH) {
+        const dyk_f32x2_t xc = {fminf(x[0], 20.f), fminf(x[1], 20.f)};
+        const dyk_f32x2_t e = {__expf(xc[0]), __expf(xc[1])};
+        const dyk_f32x2_t two = {2.f, 2.f}, four = {4.f, 4.f};
+        const dyk_f32x2_t n = e * (e + two);
+        const dyk_f32x2_t d = n + two;
+        const dyk_f32x2_t num = n * d + (four * x) * (e * e + e);
+        const dyk_f32x2_t dd = d * d;
+        const dyk_f32x2_t r = {__builtin_amdgcn_rcpf(dd[0]), __builtin_amdgcn_rcpf(dd[1])};
+        return num * r;
+    } else {
+        return (dyk_f32x2_t){act_bwd_c<ACT>(x[0], runtime_act), act_bwd_c<ACT>(x[1], runtime_act)};
     }
 }
 

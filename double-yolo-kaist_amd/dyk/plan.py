@@ -1478,6 +1478,11 @@ def _conv_candidates(d):
             if shape == 2 and d.Cout < 256:
                 continue
             out.append((5 << 12) | (shape << 8))
+    if (d.dtype == L.DYK_BF16 and d.ntaps == 9 and d.Cout == 32 and d.Cin == 64 and d.flags == L.EPI_BNBWD and d.isy == 1
+            and d.Hg % 8 == 0 and d.Wg % 16 == 0 and os.environ.get("DYK_CONV_SC", "1") != "0"):
+        # resident-weight 3x3 data gradient into 32-channel tensors (csrc/conv_sc.hip): one patch per tile for every tap and
+        # parity class, epilogue from the accumulators; the front end falls back to the generic tile where it does not apply
+        out.append(6 << 12)
     if d.dtype == L.DYK_BF16 and (d.Cin * es) % 128 == 0 and d.Cin >= 128 and os.environ.get("DYK_CONV_KG", "1") != "0":
         # K-grouped workgroups (two 4-wave groups over the two halves of Cin): for tiles that leave a CU one workgroup
         for t in (1, 2):

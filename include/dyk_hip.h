@@ -154,7 +154,8 @@ typedef struct DykConvDesc {
     float bn_momentum, bn_eps;      /* DYK_EPI_BNFWD */
     int32_t tune;                   /* 0 = built-in heuristic; else tile configuration chosen by the plan compiler's
                                        per-shape measurement: bits 0..7 K-step bytes (64|128), 8..11 LDS ring stages
-                                       (2|3|4|6), 12..15 pixel tile (0 = 128, 1 = 80, 2 = 160; bf16), 24..27 channel
+                                       (2|3|4|6), 12..15 pixel tile (0 = 128, 1 = 80, 2 = 160, 3 / 4 = halo kernel, 5 = large-tile kernels,
+                                       6 = resident-weight 3x3 data gradient into 32-channel tensors; bf16), 24..27 channel
                                        tile (0 = by Cout, 1 = 32, 2 = 64, 3 = 128); bits 16..23 analysis switches; 1 << 28 = two K-groups per
                                        workgroup (512 threads, halves of Cin, bf16 / 128-byte K step / 80|160-pixel tiles) */
     const struct DykConvDesc* twin; /* HOST pointer or NULL.  Two-problem launch: a second problem of IDENTICAL geometry, flags and

@@ -701,6 +701,78 @@ def test_wgrad_row_block_kernel(case):
         assert (got.cpu() - ref).abs().max().item() <= tol
 
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("act", ["mish", "leaky", "relu6"])
+def test_small_channel_dgrad_kernel(stride, act):
+    """pixel-tile code 6 (conv_sc.hip): the 3x3 data gradient into a 32-channel tensor with the fused BatchNorm-backward
+    epilogue -- resident weights, one gradient patch per tile for all taps and (stride 2) all four parity classes in one
+    workgroup, epilogue from the accumulators.  Against torch autograd on the same rounded operands, and against the generic
+    kernel's sums; bit 23 of the tune word forbids the fallback, so the kernel under test is the one that ran."""
+    import ctypes
+    from dyk import lib as L
+    from dyk import ops
+    acts = {"mish": F.mish, "leaky": lambda t: F.leaky_relu(t, 0.1), "relu6": F.relu6}
+    dtype = torch.bfloat16
+    B, Cin, Cout, k = 3, 32, 64, 3                           # the conv whose data gradient is launched: 32 -> 64
+    H, W = (16, 48) if stride == 1 else (32, 64)             # its input; the gradient grid is 16 x 48 | 16 x 32
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    g = torch.Generator().manual_seed(41)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * 9) ** 0.5).bfloat16().float()
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g).bfloat16().float()
+    y_prev = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    mean = y_prev.mean((0, 2, 3))
+    rstd = (y_prev.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt()
+    scale, shift = gamma * rstd, beta - mean * gamma * rstd
+    dz = torch.nn.grad.conv2d_input((B, Cin, H, W), w, dy, stride=stride, padding=1).bfloat16().float()
+    u = (y_prev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).requires_grad_(True)
+    acts[act](u).backward(dz)
+    da_ref = u.grad
+    xhat = (y_prev - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1)
+    s1_ref, s2_ref = da_ref.double().sum((0, 2, 3)), (da_ref.double() * xhat.double()).sum((0, 2, 3))
+
+    dyd = ops.to_nhwc(dy.cuda(), dtype)
+    wpt = ops.pack_weight(w.cuda(), dtype, transposed=True)
+    yd = ops.to_nhwc(y_prev.cuda(), dtype)
+    out = torch.empty((B, H, W, Cin), dtype=dtype, device="cuda")
+    slots = 4
+    red = torch.zeros(slots, 2, Cin, dtype=torch.float64, device="cuda")
+    vec = [t.cuda().contiguous() for t in (scale, shift, mean, rstd)]
+    classes = ops.dgrad_classes(k, 1, stride, H, W)
+    d = ops.make_conv_desc(dyd, wpt, out, Hi=Ho, Wi=Wo, Cin=Cout, Cout=Cin, Hg=classes[0][2], Wg=classes[0][3], Ho=H, Wo=W,
+                           taps=[t for c in classes for t in c[4]], osy=stride, osx=stride, act=act)
+    if stride == 2:
+        d.ncls, q0 = len(classes), 0
+        for c, (py, px, _, _, taps) in enumerate(classes):
+            d.cls_first[c], d.cls_ntaps[c], d.cls_ooy[c], d.cls_oox[c] = q0, len(taps), py, px
+            q0 += len(taps)
+    d.flags = L.EPI_BNBWD
+    d.res, d.ldr = yd.data_ptr(), Cin
+    d.scale, d.shift, d.aux0, d.aux1 = (t.data_ptr() for t in vec)
+    d.stats, d.stats_slots = red.data_ptr(), slots
+    res = {}
+    for name, tune in (("generic", 0), ("sc", (6 << 12) | (1 << 23))):
+        red.zero_()
+        out.fill_(float("nan"))
+        d.tune = tune
+        L.check(L.load().dyk_conv_igemm(ctypes.byref(d), None), "dyk_conv_igemm(%s)" % name)
+        got = ops.to_nchw(out).float().cpu()
+        assert bool(torch.isfinite(got).all()), name
+        err = (got - da_ref).abs().max().item()
+        assert err <= 1.5e-2 * max(1.0, da_ref.abs().max().item()), (name, err)
+        st = red.sum(0).cpu()
+        n = B * H * W
+        assert torch.allclose(st[0], s1_ref, rtol=2e-3, atol=5e-2 * n ** 0.5), name
+        assert torch.allclose(st[1], s2_ref, rtol=2e-3, atol=5e-2 * n ** 0.5), name
+        res[name] = (got, st)
+    # same arithmetic as the generic kernel (gradient rounded to bf16 before act'; the MFMA summation order differs, which
+    # flips single roundings): outputs agree to one bf16 ulp of the largest value, the fp64 sums accordingly
+    assert (res["sc"][0] - res["generic"][0]).abs().max().item() <= 2.0 ** -7 * max(1.0, da_ref.abs().max().item())
+    assert torch.allclose(res["sc"][1], res["generic"][1], rtol=1e-3, atol=2e-2 * n ** 0.5)
+
+
 LT_CASES = [  # (B, Cin, Cout, H, W): forward conv Cin -> Cout, 3x3 / stride 1 / pad 1
     (2, 64, 128, 16, 20), (1, 96, 192, 8, 40), (2, 128, 64, 16, 40), (1, 160, 96, 16, 80), (3, 256, 128, 8, 20),
 ]
