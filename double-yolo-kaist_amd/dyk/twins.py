@@ -102,8 +102,13 @@ def pair_signature(op, d, plan):
     if op == L.OP_CONV:
         if d.flags & L.EPI_BNFWD:
             return None                     # a one-launch conv + BatchNorm waits on its own workgroups: single problem only
+        if ((d.tune >> 12) & 0xf) == 6:
+            return None                     # resident-weight data gradient (csrc/conv_sc.hip): single problem only -- as one half of a
+                                            # two-problem launch it would fall back to the generic kernel, whose epilogue rounds differently
         return (op, _bytes(d, L.DykConvDesc, "dtype", "twin"), _nulls(d, ("scale", "shift", "res", "stats", "aux0", "aux1", "add")))
     if op == L.OP_WGRAD:
+        if ((d.tune >> 28) & 7) == 2:
+            return None                     # row-block 3x3 kernel (csrc/conv_wgrad_rb.hip): single problem only
         return (op, _bytes(d, L.DykWgradDesc, "part_stride", "twin"), bool(d.part))
     if op in (L.OP_BN_ACT_FWD, L.OP_BN_BWD_REDUCE, L.OP_BN_BWD_APPLY, L.OP_AXPBY):
         return (op, _bytes(d, L.DykEwDesc, "dtype", "twin"), _nulls(d, _EW_PTRS))
