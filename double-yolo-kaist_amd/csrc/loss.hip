@@ -247,7 +247,9 @@ __global__ __launch_bounds__(256) void match_loss_kernel(DykLossDesc d, DykTarge
 }
 
 // ---------------------------------------------------------------- dense objectness BCE (:283)
-__global__ __launch_bounds__(256) void obj_loss_kernel(DykLossDesc d, int h, long ncell) {
+__global__ __launch_bounds__(256) void obj_loss_kernel(DykLossDesc d, DykTargetsDesc td) {
+    const int h = blockIdx.y;                                   // one launch for the heads (was one per head)
+    const long ncell = (long)d.B * td.na * td.ny[h] * td.nx[h];
     const float* p = d.p[h];
     float* dp = d.dp[h];
     const float* tobj = d.tobj[h];
@@ -286,7 +288,15 @@ __global__ void loss_finalize_kernel(DykLossDesc d, DykTargetsDesc td) {
     d.out[2] = (float)(lcls * d.hyp_cls);
 }
 
-// dp[..., 0:4] *= g[0]; dp[..., 4] *= g[1]; dp[..., 5:] *= g[2]
+// dp[..., 0:4] *= g[0]; dp[..., 4] *= g[1]; dp[..., 5:] *= g[2]; the three factors from separate device scalars (NULL = 0:
+// that loss term was not part of the differentiated sum)
+__global__ void loss_scale_grads3_kernel(float* dp, long n, int no, const float* gb, const float* go, const float* gc) {
+    const float g0 = gb ? gb[0] : 0.f, g1 = go ? go[0] : 0.f, g2 = gc ? gc[0] : 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % no);
+        dp[i] *= (c < 4) ? g0 : (c == 4 ? g1 : g2);
+    }
+}
 __global__ void loss_scale_grads_kernel(float* dp, long n, int no, const float* g) {
     const float g0 = g[0], g1 = g[1], g2 = g[2];
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -319,26 +329,56 @@ extern "C" int dyk_yolo_loss(const DykLossDesc* d, const DykTargetsDesc* t, void
         return DYK_ERR_ARG;
     if (!(d->fl_gamma >= 0.f) || (d->fl_gamma > 0.f && !(d->fl_alpha >= 0.f && d->fl_alpha <= 1.f))) return DYK_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    // dp / tobj / acc start from zero.  A caller that lays them out back to back (dp[0] | dp[1] | .. | tobj[0] | .. | acc: what
+    // dyk/detect.py allocates) gets ONE fill instead of 2 * nheads + 1
+    size_t ncells[3] = {0, 0, 0};
+    bool contiguous = true;
+    char* expect = (char*)d->dp[0];
     for (int h = 0; h < d->nheads; ++h) {
         if (!d->p[h] || !d->dp[h] || !d->tobj[h]) return DYK_ERR_ARG;
-        const size_t ncell = (size_t)d->B * t->na * t->ny[h] * t->nx[h];
-        DYK_HIP_TRY(hipMemsetAsync(d->dp[h], 0, ncell * d->no * sizeof(float), s));
-        DYK_HIP_TRY(hipMemsetAsync(d->tobj[h], 0, ncell * sizeof(float), s));
+        ncells[h] = (size_t)d->B * t->na * t->ny[h] * t->nx[h];
+        contiguous = contiguous && (char*)d->dp[h] == expect;
+        expect += ncells[h] * d->no * sizeof(float);
     }
-    DYK_HIP_TRY(hipMemsetAsync(d->acc, 0, 12 * sizeof(double), s));
+    for (int h = 0; h < d->nheads; ++h) {
+        contiguous = contiguous && (char*)d->tobj[h] == expect;
+        expect += ncells[h] * sizeof(float);
+    }
+    contiguous = contiguous && (char*)d->acc == expect;
+    if (contiguous) {
+        // (a flag word placed right behind acc is cleared with them; anywhere else the caller clears it)
+        const size_t tail = 12 * sizeof(double) + ((char*)d->flag == expect + 12 * sizeof(double) ? sizeof(int32_t) : 0);
+        DYK_HIP_TRY(hipMemsetAsync(d->dp[0], 0, (size_t)(expect - (char*)d->dp[0]) + tail, s));
+    } else {
+        for (int h = 0; h < d->nheads; ++h) {
+            DYK_HIP_TRY(hipMemsetAsync(d->dp[h], 0, ncells[h] * d->no * sizeof(float), s));
+            DYK_HIP_TRY(hipMemsetAsync(d->tobj[h], 0, ncells[h] * sizeof(float), s));
+        }
+        DYK_HIP_TRY(hipMemsetAsync(d->acc, 0, 12 * sizeof(double), s));
+    }
     hipLaunchKernelGGL(build_targets_kernel, dim3(t->nheads), dim3(256), 0, s, *t);
     DYK_LAUNCH_CHECK();
     hipLaunchKernelGGL(match_loss_kernel, dim3(d->nheads), dim3(256), 0, s, *d, *t);
     DYK_LAUNCH_CHECK();
-    for (int h = 0; h < d->nheads; ++h) {
-        const long ncell = (long)d->B * t->na * t->ny[h] * t->nx[h];
-        long g = (ncell + 1023) / 1024;
+    {
+        size_t big = ncells[0] > ncells[1] ? ncells[0] : ncells[1];
+        if (ncells[2] > big) big = ncells[2];
+        long g = ((long)big + 1023) / 1024;
         if (g > 512) g = 512;
         if (g < 1) g = 1;
-        hipLaunchKernelGGL(obj_loss_kernel, dim3((int)g), dim3(256), 0, s, *d, h, ncell);
+        hipLaunchKernelGGL(obj_loss_kernel, dim3((int)g, d->nheads), dim3(256), 0, s, *d, *t);
         DYK_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, *d, *t);
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_loss_scale_grads3(float* dp, int64_t n, int32_t no, const float* gbox, const float* gobj, const float* gcls, void* stream) {
+    if (!dp || n <= 0 || no < 5) return DYK_ERR_ARG;
+    long g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(loss_scale_grads3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, dp, (long)n, no, gbox, gobj, gcls);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

@@ -40,11 +40,13 @@ def _targets_desc(shapes, targets, model):
         for q, v in enumerate(av):
             t.anchor_vec[h][q] = v
     t.iou_t = float(m.hyp["iou_t"])
-    keep["counts"] = torch.zeros(nheads, dtype=torch.int32, device=dev)
-    keep["indices"] = torch.zeros((nheads, 4, cap), dtype=torch.int64, device=dev)
-    keep["tbox"] = torch.zeros((nheads, cap, 4), dtype=torch.float32, device=dev)
-    keep["anch"] = torch.zeros((nheads, cap, 2), dtype=torch.float32, device=dev)
-    keep["tcls"] = torch.zeros((nheads, cap), dtype=torch.int64, device=dev)
+    # (torch.empty: no fill launches inside the train step -- build_targets_kernel writes counts[h] unconditionally and the
+    # match lists are only ever read up to counts[h])
+    keep["counts"] = torch.empty(nheads, dtype=torch.int32, device=dev)
+    keep["indices"] = torch.empty((nheads, 4, cap), dtype=torch.int64, device=dev)
+    keep["tbox"] = torch.empty((nheads, cap, 4), dtype=torch.float32, device=dev)
+    keep["anch"] = torch.empty((nheads, cap, 2), dtype=torch.float32, device=dev)
+    keep["tcls"] = torch.empty((nheads, cap), dtype=torch.int64, device=dev)
     t.counts, t.indices, t.tbox = keep["counts"].data_ptr(), keep["indices"].data_ptr(), keep["tbox"].data_ptr()
     t.anch, t.tcls = keep["anch"].data_ptr(), keep["tcls"].data_ptr()
     return t, keep
@@ -85,13 +87,23 @@ class _LossFunction(torch.autograd.Function):
         ps = [pi.detach().float().contiguous() for pi in p]
         t, keep = _targets_desc([tuple(pi.shape) for pi in ps], targets.to(dev), model)
         d = L.DykLossDesc()
-        dps, tobjs = [], []
+        # ONE buffer for everything dyk_yolo_loss wants zeroed: dp of every head | tobj of every head | acc (12 doubles) | flag,
+        # back to back -- one fill launch instead of 2 * nheads + 2 (and the backward scales all heads' gradients in one launch)
+        n_dp = [pi.numel() for pi in ps]
+        n_to = [pi.numel() // pi.shape[4] for pi in ps]
+        flat = torch.empty(sum(n_dp) + sum(n_to) + 24 + 2, dtype=torch.float32, device=dev)
+        dps, tobjs, off = [], [], 0
+        for pi, n in zip(ps, n_dp):
+            dps.append(flat[off:off + n].view(pi.shape))
+            off += n
+        for pi, n in zip(ps, n_to):
+            tobjs.append(flat[off:off + n].view(pi.shape[:4]))
+            off += n
+        assert off % 2 == 0, "acc must be 8-byte aligned"
+        acc = flat[off:off + 24].view(torch.float64)
+        flag = flat[off + 24:off + 25].view(torch.int32)
         for i, pi in enumerate(ps):
-            dp = torch.empty_like(pi)
-            tobj = torch.empty(pi.shape[:4], dtype=torch.float32, device=dev)
-            d.p[i], d.dp[i], d.tobj[i] = pi.data_ptr(), dp.data_ptr(), tobj.data_ptr()
-            dps.append(dp)
-            tobjs.append(tobj)
+            d.p[i], d.dp[i], d.tobj[i] = pi.data_ptr(), dps[i].data_ptr(), tobjs[i].data_ptr()
         d.nheads, d.B, d.no = len(ps), ps[0].shape[0], ps[0].shape[4]
         d.nc = d.no - 5
         if m.nc != d.nc:
@@ -102,13 +114,16 @@ class _LossFunction(torch.autograd.Function):
         d.cls_pw, d.obj_pw, d.gr = float(h["cls_pw"]), float(h["obj_pw"]), float(m.gr)
         # focal loss around both BCE terms when hyp['fl_gamma'] > 0 (utils.py:236-238: FocalLoss(BCE, g), alpha at its default)
         d.fl_gamma, d.fl_alpha = max(0.0, float(h.get("fl_gamma", 0.0))), 0.25
-        acc = torch.empty(12, dtype=torch.float64, device=dev)
         out = torch.empty(3, dtype=torch.float32, device=dev)
-        flag = torch.zeros(1, dtype=torch.int32, device=dev)
         d.acc, d.out, d.flag = acc.data_ptr(), out.data_ptr(), flag.data_ptr()
-        check(load().dyk_yolo_loss(ctypes.byref(d), ctypes.byref(t), _stream()), "dyk_yolo_loss")
+        lib = load()
+        # the fill of `flat` covers the flag word: 8 bytes behind the 12 doubles of acc
+        rc = lib.dyk_yolo_loss(ctypes.byref(d), ctypes.byref(t), _stream())
+        check(rc, "dyk_yolo_loss")
         ctx.dps = dps
+        ctx.dp_flat = flat[:sum(n_dp)]
         ctx.no = d.no
+        ctx.set_materialize_grads(False)        # an unused loss term arrives as None (no zeros tensor: a fill launch)
         # bit 0: a target fell outside the grid (the reference raises IndexError there).  Copied to pinned host memory
         # behind the loss kernels; examined without a host sync by raise_if_target_outside_grid (optimizer.step())
         ring = m.__dict__.get("_dyk_flag_ring")
@@ -125,15 +140,20 @@ class _LossFunction(torch.autograd.Function):
         pend.append((host, ev, flag))
         m._dyk_loss_flag = flag
         m._dyk_loss_keep = (keep, tobjs, acc, ps)
-        return out[0:1].clone(), out[1:2].clone(), out[2:3].clone()
+        # three views of `out` (no clone launches).  They are outputs of a custom Function: in-place arithmetic ON them is refused
+        # by autograd; the reference's harness only sums / stacks them (kaist_train_eval_utils.py:70-85)
+        return out[0:1], out[1:2], out[2:3]
 
     @staticmethod
     def backward(ctx, gbox, gobj, gcls):
-        dev = ctx.dps[0].device
-        g = torch.cat([x.reshape(1).float() if x is not None else torch.zeros(1, device=dev) for x in (gbox, gobj, gcls)])
-        lib = load()
-        for dp in ctx.dps:
-            check(lib.dyk_loss_scale_grads(dp.data_ptr(), dp.numel(), ctx.no, g.data_ptr(), _stream()), "dyk_loss_scale_grads")
+        gs = []
+        for x in (gbox, gobj, gcls):
+            if x is not None and (x.dtype != torch.float32 or not x.is_contiguous()):
+                x = x.float().contiguous()
+            gs.append(x)
+        ptr = [x.data_ptr() if x is not None else None for x in gs]
+        check(load().dyk_loss_scale_grads3(ctx.dp_flat.data_ptr(), ctx.dp_flat.numel(), ctx.no, ptr[0], ptr[1], ptr[2], _stream()),
+              "dyk_loss_scale_grads3")
         return (None, None) + tuple(ctx.dps)
 
 

@@ -230,6 +230,7 @@ SIGNATURES = {
     "dyk_sgd_step": (_i32, [_P(DykOptimDesc), _vp]),
     "dyk_run_commands_timed": (_i32, [_P(DykCommand), _i32, _vp, _P(_f32)]),
     "dyk_loss_scale_grads": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "dyk_loss_scale_grads3": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "dyk_stem_conv_fwd": (_i32, [_P(DykStemDesc), _vp]),
     "dyk_stem_conv_wgrad": (_i32, [_P(DykStemDesc), _vp]),
     "dyk_stem_wgrad_planes": (_i32, [_P(DykStemDesc)]),

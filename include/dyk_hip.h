@@ -597,12 +597,18 @@ typedef struct DykLossDesc {
     float fl_alpha;        /* FocalLoss alpha (utils.py:176 default 0.25; read only when fl_gamma > 0) */
     double* acc;           /* [12] scratch */
     float* out;            /* [3] */
-    int32_t* flag;
+    int32_t* flag;         /* bit 0 is SET when a target falls outside the grid; the caller clears it -- except in the
+                              back-to-back layout dp[0] | dp[1] | .. | tobj[0] | .. | acc | flag, which dyk_yolo_loss recognises
+                              and zeroes with one fill (otherwise: one fill per dp / tobj buffer and one for acc) */
 } DykLossDesc;
 
 int dyk_build_targets(const DykTargetsDesc* desc, void* stream);
 int dyk_yolo_loss(const DykLossDesc* desc, const DykTargetsDesc* targets, void* stream);
 int dyk_loss_scale_grads(float* dp, int64_t n, int32_t no, const float* g3, void* stream);
+/* The same with the three upstream gradients as separate device scalars (NULL = 0: the term is not in the differentiated sum) --
+ * autograd hands them over separately (reference utils.py:287-293 returns three tensors), no concatenation launch; dp may be the
+ * back-to-back gradient buffers of all heads (one launch). */
+int dyk_loss_scale_grads3(float* dp, int64_t n, int32_t no, const float* gbox, const float* gobj, const float* gcls, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * non_max_suppression (build_utils/utils.py:387-464) incl. torchvision.ops.nms (:448), one
