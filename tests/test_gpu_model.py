@@ -24,6 +24,10 @@ STEP23_RTOL = 0.30          # steps 2-3 of the three-Adam-step fixture.  Determi
                             # errors (wrong step size, sign, missing parameter)
 
 
+TRAJ4_RTOL = 1.0            # (set from the measurement below)
+TRAJ4_DELTA_RTOL = 1.0
+
+
 def _inputs():
     g = torch.Generator().manual_seed(1234)
     return torch.rand(2, 3, 128, 160, generator=g), torch.rand(2, 3, 128, 160, generator=g)
@@ -153,6 +157,57 @@ def test_three_adam_steps_match_reference_losses():
     sd = m.state_dict()
     probes = np.array([[sd[k].double().sum().item(), sd[k].double().abs().sum().item()] for k in cases.step_probe_names()])
     assert np.allclose(probes[:, 1], gold["probes"][:, 1], rtol=5e-3)
+
+
+def test_three_sgd_steps_on_the_conditioned_network_match_reference():
+    """a trajectory bound that catches more than gross errors.  traj_trained.npz (make_golden_round4.py traj,
+    the REFERENCE): three SGD + Nesterov steps on the whole target network starting from the round-4 fixture state --
+    well-conditioned weights, calibrated BatchNorm statistics, trained heads, full batch of the 16 synthetic pairs
+    (>= 320 samples per BatchNorm channel at stride 32).  HIP fp32 path against it, per learning rate."""
+    import make_golden_round4 as R4
+    from build_utils.parse_config import materialize_cfg
+    from build_utils.utils import compute_loss
+    from dyk.optim import FusedSGD
+    from models import YOLO
+    gold = np.load(os.path.join(GOLDEN, "traj_trained.npz"))
+    g4 = np.load(os.path.join(GOLDEN, "evalap_trained.npz"))
+    net = oracle_net(R4.CFG)
+    sd0 = R4.conditioned_state(net.synth_state(R4.SEED_W))
+    for k in g4.files:
+        if k.startswith(("bn|", "head|")):
+            sd0[k.split("|", 1)[1]] = torch.from_numpy(g4[k])
+    h = hyp("hyp.scratch.4")
+    v, l, targets = R4.dataset()
+    x, y, tg = v.cuda(), l.cuda(), targets.cuda()
+    worst = {}
+    for q, lr in enumerate(gold["lrs"]):
+        torch.manual_seed(0)
+        m = YOLO(materialize_cfg(R4.CFG))
+        m.load_state_dict(sd0)
+        m.dyk_dtype = "fp32"
+        m = m.cuda().train()
+        m.nc, m.hyp, m.gr = 1, h, 1.0
+        p0 = {k: t.detach().clone().double().cpu() for k, t in m.state_dict().items() if k in R4.TRAJ_PROBES}
+        opt = FusedSGD(m, lr=float(lr), momentum=h["momentum"], weight_decay=h["weight_decay"], nesterov=True)
+        losses = []
+        for step in range(3):
+            pred = m(x, y)                      # uint8 batches: `/ 255` inside the stem kernel, as the harness feeds them
+            ld = compute_loss(pred, tg, m)
+            (ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]).backward()
+            losses.append([ld["box_loss"].item(), ld["obj_loss"].item(), ld["class_loss"].item()])
+            opt.step()
+        losses, ref = np.array(losses)[:, :2], gold["losses%d" % q][:, :2]
+        rel = np.abs(losses - ref) / np.abs(ref)
+        sd = m.state_dict()
+        dn = np.array([(sd[k].detach().double().cpu() - p0[k]).norm().item() for k in R4.TRAJ_PROBES])
+        drel = np.abs(dn - gold["delta%d" % q][:, 0]) / gold["delta%d" % q][:, 0]
+        print("lr %g: losses %s reference %s relative deviation %s | update-norm deviation per probe %s"
+              % (lr, losses.tolist(), ref.tolist(), rel.tolist(), ["%.1e" % d for d in drel]))
+        worst[float(lr)] = (rel, drel)
+    for lr, (rel, drel) in worst.items():
+        assert rel[0].max() <= 1e-4, (lr, rel)                  # the first step: forward + loss of the fixture state
+        assert rel[1:].max() <= TRAJ4_RTOL, (lr, rel)
+        assert drel.max() <= TRAJ4_DELTA_RTOL, (lr, drel)
 
 
 def test_three_sgd_steps_match_reference():
