@@ -20,12 +20,22 @@ STEP23_RTOL = 0.30          # steps 2-3 of the three-Adam-step fixture.  Determi
                             # summation ORDER anywhere in the backward pass draws a new sample: 0.7 % / 1.8 % (box) and 10.8 % / 11.2 % (obj)
                             # in round 2; 2.9 % / 0.8 % and 5.1 % / 17.7 % after the SE column sums went from 4 to 16 partial sums
                             # (round 3) -- Adam's first steps move every weight by lr * sign(g), noise-level gradients included.  The
-                            # well-conditioned trajectory test is test_three_sgd_steps_match_reference below; this one catches gross
+                            # well-conditioned trajectory test is test_three_sgd_steps_on_the_conditioned_network_match_reference below (round 4:
+                            # 1e-5 ... 1e-3); this one catches gross
                             # errors (wrong step size, sign, missing parameter)
 
 
-TRAJ4_RTOL = 1.0            # (set from the measurement below)
-TRAJ4_DELTA_RTOL = 1.0
+# Bounds of test_three_sgd_steps_on_the_conditioned_network_match_reference, per learning rate: (losses of steps 2-3, norm of the
+# three-step update per probed parameter), relative.  Measured on MI355X (HIP fp32 vs the reference, round 4): losses 2.5e-6 /
+# 2.3e-5 / 6.1e-4 and updates 4.6e-4 / 4.9e-2 / 8.0e-2 at lr 1e-6 / 1e-5 / 1e-4 -- three to five orders below the 0.3 of the
+# random-weight Adam fixture above.  (The update bound grows with lr: the two-element fusion weight `module_list.113.w` and the
+# BatchNorm scale move by sums of signed products over whole tensors.)
+TRAJ4_TOL = {1e-6: (2e-5, 2e-3), 1e-5: (1e-4, 0.15), 1e-4: (2.5e-3, 0.25)}
+# bf16 MFMA path against the same fp32 reference: bf16 storage of activations alone moves the train-mode box loss of this state
+# by 3.9 % in the FIRST forward (29 targets, CIoU), steps 2-3 by 6-13 % (box) / 1-9 % (objectness); conv / BatchNorm updates
+# within 6-49 % of their norm (the 2-element fusion weight is noise there and not bounded).  A smoke bound by construction --
+# the sharp bf16 statements are the per-section backward test (test_gpu_bwd_bf16.py) and the AP test on this same state.
+TRAJ4_TOL_BF16 = {1e-6: (0.2, 0.7), 1e-5: (0.2, 0.7), 1e-4: (0.2, 0.7)}
 
 
 def _inputs():
@@ -159,7 +169,8 @@ def test_three_adam_steps_match_reference_losses():
     assert np.allclose(probes[:, 1], gold["probes"][:, 1], rtol=5e-3)
 
 
-def test_three_sgd_steps_on_the_conditioned_network_match_reference():
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_three_sgd_steps_on_the_conditioned_network_match_reference(dtype):
     """a trajectory bound that catches more than gross errors.  traj_trained.npz (make_golden_round4.py traj,
     the REFERENCE): three SGD + Nesterov steps on the whole target network starting from the round-4 fixture state --
     well-conditioned weights, calibrated BatchNorm statistics, trained heads, full batch of the 16 synthetic pairs
@@ -184,7 +195,7 @@ def test_three_sgd_steps_on_the_conditioned_network_match_reference():
         torch.manual_seed(0)
         m = YOLO(materialize_cfg(R4.CFG))
         m.load_state_dict(sd0)
-        m.dyk_dtype = "fp32"
+        m.dyk_dtype = dtype
         m = m.cuda().train()
         m.nc, m.hyp, m.gr = 1, h, 1.0
         p0 = {k: t.detach().clone().double().cpu() for k, t in m.state_dict().items() if k in R4.TRAJ_PROBES}
@@ -201,13 +212,16 @@ def test_three_sgd_steps_on_the_conditioned_network_match_reference():
         sd = m.state_dict()
         dn = np.array([(sd[k].detach().double().cpu() - p0[k]).norm().item() for k in R4.TRAJ_PROBES])
         drel = np.abs(dn - gold["delta%d" % q][:, 0]) / gold["delta%d" % q][:, 0]
-        print("lr %g: losses %s reference %s relative deviation %s | update-norm deviation per probe %s"
-              % (lr, losses.tolist(), ref.tolist(), rel.tolist(), ["%.1e" % d for d in drel]))
+        print("%s lr %g: losses %s reference %s relative deviation %s | update-norm deviation per probe %s"
+              % (dtype, lr, losses.tolist(), ref.tolist(), rel.tolist(), ["%.1e" % d for d in drel]))
         worst[float(lr)] = (rel, drel)
+    tol = TRAJ4_TOL if dtype == "fp32" else TRAJ4_TOL_BF16
     for lr, (rel, drel) in worst.items():
-        assert rel[0].max() <= 1e-4, (lr, rel)                  # the first step: forward + loss of the fixture state
-        assert rel[1:].max() <= TRAJ4_RTOL, (lr, rel)
-        assert drel.max() <= TRAJ4_DELTA_RTOL, (lr, drel)
+        key = min(tol, key=lambda t: abs(t - lr))
+        assert rel[0].max() <= (1e-4 if dtype == "fp32" else tol[key][0]), (lr, rel)     # the first step: forward + loss of the fixture state
+        assert rel[1:].max() <= tol[key][0], (lr, rel)
+        bounded = [i for i, k in enumerate(R4.TRAJ_PROBES) if dtype == "fp32" or not k.endswith(".w")]
+        assert drel[bounded].max() <= tol[key][1], (lr, drel)
 
 
 def test_three_sgd_steps_match_reference():
