@@ -26,6 +26,8 @@ for (ci, co, Ho, Wo, s) in SHAPES:
     out = []
     for name, tune in [("tap", 2), ("tap3", 3), ("tapkg2", 2 | (2 << 8)), ("mt", 2 | (1 << 28)), ("rb", 2 | (1 << 8) | (2 << 28) | (1 << 20)), ("rb256", 2 | (2 << 8) | (2 << 28)),
                        ("rb-noloop", 2 | (1 << 8) | (2 << 28) | (1 << 17))]:
+        if os.environ.get("RB_ONLY") and name != os.environ["RB_ONLY"]:
+            continue
         d = L.DykWgradDesc()
         d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
         d.dtype = L.DYK_BF16
