@@ -432,7 +432,7 @@ def main():
                 with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_step_kernels.json")) as f:
                     kj = json.load(f)
                 if kj.get("code_sha") == sha:
-                    fams = [kj["families"][k] for k in ("conv_igemm_kernel", "conv_halo_kernel", "conv_lt_kernel") if k in kj["families"]]
+                    fams = [kj["families"][k] for k in ("conv_igemm_kernel", "conv_halo_kernel", "conv_lt_kernel", "conv_sc_kernel") if k in kj["families"]]
                     t_us = sum(f_["total_us"] for f_ in fams)
                     in_step = {"tflops": 2.0 * f1 / (t_us * 1e-6) / 1e12, "frac": 2.0 * f1 / (t_us * 1e-6) / 1e12 / peak,
                                "launches": sum(f_["n"] for f_ in fams), "total_us": t_us,
@@ -444,7 +444,7 @@ def main():
             # in-step figure; the isolated-launch figure of this run is always reported beside it
             frac_rocprof = in_step["frac"] if in_step else None
             out["roofline"] = {
-                "bound": "mfma", "kernel": "conv_igemm_kernel + conv_lt_kernel + conv_halo_kernel (forward + data-gradient launches)",
+                "bound": "mfma", "kernel": "conv_igemm_kernel + conv_lt_kernel + conv_halo_kernel + conv_sc_kernel (forward + data-gradient launches)",
                 "achieved": (in_step["tflops"] if in_step else ach), "peak": peak, "unit": "TFLOP/s",
                 "frac": (frac_rocprof if frac_rocprof is not None else ach / peak), "traffic": traffic,
                 "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % src if src else None,
