@@ -116,18 +116,23 @@ class GradAllReduce:
     # the target cfg), and five segments cost the one-rank step +0.15..0.3 ms where eight equal ones cost +0.9 ms.
     GEOMETRIC = (0.5, 0.8, 0.95, 0.99)
 
-    def __init__(self, model, dist, n_buckets=None):
+    def __init__(self, model, dist, n_buckets=None, attach=True):
         if n_buckets is None:
             n_buckets = int(os.environ.get("DYK_DDP_BUCKETS", "0"))       # 0: the geometric cuts above; n: n equal buckets
         self.model, self.dist, self.n_buckets = model, dist, n_buckets
         self.engine = model.engine
-        self.engine.grad_sync = self
+        if attach:                          # (attach=False: only the segment arithmetic is wanted, dyk/optim.py)
+            self.engine.grad_sync = self
         self._works = []
 
-    def segments(self, plan):
+    def segments(self, plan, fractions=None):
+        """[(c0, c1, lo, hi)]: backward commands [c0, c1) complete the gradients G[lo, hi).  fractions: cumulative fractions of the
+        gradient buffer at which a segment closes (default: this object's buckets); dyk/optim.py asks for one cut at 95 % to
+        start the optimizer on the deep layers while the early layers are still being differentiated."""
         # cached on the plan object itself: a plan evicted under multi-scale training takes its cuts with it (an
         # id()-keyed table could hand them to a later plan that re-uses the address)
-        segs = plan.__dict__.get("_ddp_segs", {}).get(self.n_buckets)
+        ckey = self.n_buckets if fractions is None else tuple(fractions)
+        segs = plan.__dict__.get("_ddp_segs", {}).get(ckey)
         if segs is None:
             store = self.engine.store
             total = store.total
@@ -135,7 +140,9 @@ class GradAllReduce:
             first_off = {}
             for e in store.entries:
                 first_off.setdefault(e.layer, e.offset)
-            if self.n_buckets > 0:
+            if fractions is not None:
+                cuts = [total - int(f * total) for f in fractions]
+            elif self.n_buckets > 0:
                 cuts = [total - (q * total) // self.n_buckets for q in range(1, self.n_buckets)]
             else:
                 cuts = [total - int(f * total) for f in self.GEOMETRIC]
@@ -166,7 +173,7 @@ class GradAllReduce:
                         cuts.pop(0)
             if c_prev < len(plan.bwd):
                 segs.append((c_prev, len(plan.bwd), 0, hi))
-            plan.__dict__.setdefault("_ddp_segs", {})[self.n_buckets] = segs
+            plan.__dict__.setdefault("_ddp_segs", {})[ckey] = segs
         return segs
 
     def bucket_ready(self, lo, hi):

@@ -61,6 +61,8 @@ class Engine:
         self.store = ParamStore(model)
         self.plans = {}
         self.grad_sync = None           # set by dyk.ddp.GradAllReduce
+        self.opt_overlap = None         # set by the fused optimizers (dyk/optim.py): segment arithmetic for the early optimizer start
+        self._early = self._early_event = None
         self._anchor = None
 
     # ------------------------------------------------------------------ helpers
@@ -164,6 +166,9 @@ class Engine:
 
     def _run_backward(self, plan, dps):
         stream = torch.cuda.current_stream().cuda_stream
+        if self.store.wt_ready is not None:          # transposed packs rebuilt on the optimizer's side stream (dyk/optim.py)
+            torch.cuda.current_stream().wait_event(self.store.wt_ready)
+            self.store.wt_ready = None
         self.store.attach_grads()
         self.store.grads_dirty = True
         keep = []
@@ -176,7 +181,22 @@ class Engine:
             keep.append(g)
             desc.p[0] = g.data_ptr()
         plan._dyn_keep_b = keep
-        if self.grad_sync is None:
+        self._early = None
+        if self.grad_sync is None and self.opt_overlap is not None:
+            # single GPU, fused optimizer attached (dyk/optim.py): the backward runs in two segments; an event after the first marks
+            # the point where the gradients of the deep layers (95 % of the parameters) are final -- optimizer.step() starts on
+            # them on a side stream while the second segment (the early layers: most of the TIME of a backward pass) still runs
+            segs = self.opt_overlap.segments(plan, fractions=(0.95,))
+            if len(segs) == 2 and segs[0][2] % 8 == 0 and segs[0][2] > 0:
+                (c0, c1, lo, hi), (d0, d1, _, _) = segs
+                plan.run("bwd", stream, c0, c1)
+                ev = self._early_event = self._early_event or torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                plan.run("bwd", stream, d0, d1)
+                self._early = (ev, lo)
+            else:
+                plan.run("bwd", stream)
+        elif self.grad_sync is None:
             plan.run("bwd", stream)
         else:
             # data parallel: launch the backward in segments and hand every finished gradient bucket to
