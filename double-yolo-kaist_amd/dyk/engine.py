@@ -186,7 +186,7 @@ class Engine:
             # single GPU, fused optimizer attached (dyk/optim.py): the backward runs in two segments; an event after the first marks
             # the point where the gradients of the deep layers (95 % of the parameters) are final -- optimizer.step() starts on
             # them on a side stream while the second segment (the early layers: most of the TIME of a backward pass) still runs
-            segs = self.opt_overlap.segments(plan, fractions=(0.95,))
+            segs = self.opt_overlap.segments(plan, fractions=(float(os.environ.get("DYK_OPT_OVERLAP_FRAC", "0.95")),))
             if len(segs) == 2 and segs[0][2] % 8 == 0 and segs[0][2] > 0:
                 (c0, c1, lo, hi), (d0, d1, _, _) = segs
                 plan.run("bwd", stream, c0, c1)
