@@ -17,8 +17,14 @@ def family(name):
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
-    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Stream_Id"]) for r in rows)
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Stream_Id"], int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)) for r in rows)
     opt = [i for i, e in enumerate(ev) if "adam_kernel" in e[2] or "sgd_kernel" in e[2]]
+    # round 4: two optimizer launches per step (deep layers early on a side stream, the rest behind the backward): the step
+    # ends with the SMALLER one
+    grids = sorted({ev[i][4] for i in opt})
+    if len(grids) > 1:
+        opt = [i for i in opt if ev[i][4] == grids[0]]
+    ev = [e[:4] for e in ev]
     a0, a1 = opt[-2], opt[-1]
     seg = ev[a0 + 1:a1 + 1]
     T = (ev[a1][1] - ev[a0][1]) / 1e3

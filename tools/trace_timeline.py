@@ -6,8 +6,14 @@ import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Stream_Id"]) for r in rows)
-adam = [i for i, e in enumerate(ev) if "adam_kernel" in e[2]]
+ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Stream_Id"], int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)) for r in rows)
+adam = [i for i, e in enumerate(ev) if "adam_kernel" in e[2] or "sgd_kernel" in e[2]]
+# round 4: the optimizer runs as two launches per step (deep layers early on a side stream, the rest behind the backward):
+# the step ends with the SMALLER one
+grids = sorted({ev[i][4] for i in adam})
+if len(grids) > 1:
+    adam = [i for i in adam if ev[i][4] == grids[0]]
+ev = [e[:4] for e in ev]
 a0, a1 = adam[-2], adam[-1]
 seg = ev[a0 + 1:a1 + 1]
 t0 = ev[a0][1]
