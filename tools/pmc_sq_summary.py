@@ -29,9 +29,12 @@ def collect(d):
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for r in csv.DictReader(f):
-                rows.append((int(r["Dispatch_Id"]), family(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"])))
+                rows.append((int(r["Dispatch_Id"]), family(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"]), int(r.get("Grid_Size", 0) or 0)))
     rows.sort()
-    ids = sorted({r[0] for r in rows if r[1] in ("adam_kernel", "sgd_kernel")})
+    # round 4: two optimizer launches per step, enqueued back to back: a step ends with the SMALLER one
+    grids = sorted({r[4] for r in rows if r[1] in ("adam_kernel", "sgd_kernel")})
+    ids = sorted({r[0] for r in rows if r[1] in ("adam_kernel", "sgd_kernel") and (len(grids) < 2 or r[4] == grids[0])})
+    rows = [r[:4] for r in rows]
     lo, hi = (ids[-2], ids[-1]) if len(ids) >= 2 else (-1, 1 << 62)
     out = {}
     for did, fam, cn, val in rows:

@@ -23,7 +23,13 @@ def collect(d, counter):
         with open(path) as f:
             rows += [r for r in csv.DictReader(f) if r.get("Counter_Name") == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    adam = [int(r["Dispatch_Id"]) for r in rows if family(r["Kernel_Name"]) in ("adam_kernel", "sgd_kernel")]
+    opt = [r for r in rows if family(r["Kernel_Name"]) in ("adam_kernel", "sgd_kernel")]
+    # round 4: two optimizer launches per step (deep layers on a side stream, the rest behind the backward; enqueued back to back):
+    # a step ends with the SMALLER one
+    grids = sorted({int(r.get("Grid_Size", 0) or 0) for r in opt})
+    if len(grids) > 1:
+        opt = [r for r in opt if int(r.get("Grid_Size", 0) or 0) == grids[0]]
+    adam = [int(r["Dispatch_Id"]) for r in opt]
     lo, hi = (adam[-2], adam[-1]) if len(adam) >= 2 else (-1, 1 << 62)
     out = {}
     for r in rows:
