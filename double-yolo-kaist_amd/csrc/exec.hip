@@ -235,6 +235,7 @@ extern "C" int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream,
 // dual-stream net, reference models.py:288,299-303) as ONE two-problem launch: a copy of a's descriptor gets `twin` = b's.
 extern "C" int dyk_run_command_pair(const DykCommand* a, const DykCommand* b, void* stream) {
     if (!a || !b || !a->desc || !b->desc || a->op != b->op) return DYK_ERR_ARG;
+    if (a->desc == b->desc) return DYK_ERR_ARG;          // two problems: one descriptor twice would write its outputs twice (in-place / accumulate forms: wrong) -- ADVICE r3
     switch (a->op) {
     case DYK_OP_CONV: {
         DykConvDesc t = *(const DykConvDesc*)a->desc;
