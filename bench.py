@@ -333,7 +333,7 @@ def main():
         loss.backward()
         if host_tl: tl.append(time.perf_counter())
         if reducer is not None:
-            reducer.all_reduce()
+            reducer.all_reduce(optimizer=opt)        # step() updates each bucket's range behind its own all-reduce (dyk/ddp.py)
         opt.step()
         if host_tl:
             tl.append(time.perf_counter())

@@ -179,10 +179,19 @@ class GradAllReduce:
     def bucket_ready(self, lo, hi):
         if hi > lo and not os.environ.get("DYK_DDP_NOREDUCE"):          # (analysis switch: segmentation without the collective)
             g = self.engine.store.G[lo:hi]
-            self._works.append(self.dist.all_reduce(g, op=self.dist.ReduceOp.SUM, async_op=True))
+            self._works.append((self.dist.all_reduce(g, op=self.dist.ReduceOp.SUM, async_op=True), lo, hi))
 
-    def all_reduce(self):
-        """wait for the bucketed exchange started during backward (call before optimizer.step())"""
-        for w in self._works:
+    def all_reduce(self, optimizer=None):
+        """wait for the bucketed exchange started during backward (call before optimizer.step()).
+        optimizer: a dyk.optim fused optimizer whose step() is the NEXT thing done with the gradients -- the buckets are then
+        handed to it instead of being waited for here: step() updates each bucket's parameter range on a side stream as soon as
+        that bucket's all-reduce has completed, while the backward pass of the early layers is still running (the one-GPU step does
+        the same with a single cut, dyk/optim.py); the caller's stream waits for the side stream at the end of step().  Anything
+        else that reads the gradients between the two calls (clipping, logging) needs the plain form."""
+        if (optimizer is not None and hasattr(optimizer, "_take_buckets") and os.environ.get("DYK_OPT_OVERLAP", "1") != "0"
+                and self._works and optimizer._take_buckets(self._works, self.engine.store.total)):
+            self._works = []
+            return
+        for w, _, _ in self._works:
             w.wait()
         self._works = []

@@ -29,6 +29,7 @@ class _FusedBase(torch.optim.Optimizer):
         self.grad_scale = 1.0
         self.zero_in_step = True
         self._side = None
+        self._buckets = None
         self._fresh = True
         import os
         if os.environ.get("DYK_OPT_OVERLAP", "1") != "0":
@@ -76,6 +77,16 @@ class _FusedBase(torch.optim.Optimizer):
                 self._fresh = True
         return self._mask
 
+    def _take_buckets(self, works, total):
+        """GradAllReduce.all_reduce(optimizer=self): [(work, lo, hi)] of the data-parallel exchange; accepted when the ranges tile
+        the flat buffer in whole 8-element groups (else the caller waits as usual)"""
+        spans = sorted((lo, hi) for _, lo, hi in works)
+        ok = spans and spans[0][0] == 0 and spans[-1][1] == total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        if not ok or any(lo % 8 for lo, _ in spans):
+            return False
+        self._buckets = list(works)
+        return True
+
     def _launch(self, fn, name, d, bf):
         """one launch over the whole flat buffer -- or, when the last backward left an event behind its first segment
         (engine._early: gradients of G[lo:] final, single GPU), two: [lo, total) on a side stream as soon as that event has
@@ -83,11 +94,11 @@ class _FusedBase(torch.optim.Optimizer):
         element; the 0.66 ms HBM-bound step of the target cfg no longer runs alone after the backward's tail."""
         eng = self.model.engine
         early, eng._early = eng._early, None
+        buckets, self._buckets = self._buckets, None
         main = torch.cuda.current_stream()
-        if early is None or self.model.engine.grad_sync is not None:
+        if buckets is None and (early is None or self.model.engine.grad_sync is not None):
             check(fn(ctypes.byref(d), ctypes.c_void_p(main.cuda_stream)), name)
             return
-        ev, lo = early
         n = d.n
         if self._side is None:
             self._side = torch.cuda.Stream()
@@ -109,6 +120,18 @@ class _FusedBase(torch.optim.Optimizer):
             first.record(main)
             side.wait_event(first)
             self._fresh = False
+        if buckets is not None:
+            # data parallel: every bucket's range on the side stream behind ITS all-reduce (Work.wait() orders the current stream
+            # behind the collective, it does not block the host); the caller's stream joins at the end
+            for w, lo, hi in buckets:
+                with torch.cuda.stream(side):
+                    w.wait()
+                check(fn(ctypes.byref(sub(lo, hi - lo)), ctypes.c_void_p(side.cuda_stream)), name)
+            done = torch.cuda.Event()
+            done.record(side)
+            main.wait_event(done)
+            return
+        ev, lo = early
         side.wait_event(ev)
         check(fn(ctypes.byref(sub(lo, n - lo)), ctypes.c_void_p(side.cuda_stream)), name)
         done = torch.cuda.Event()

@@ -125,6 +125,34 @@ def test_two_rank_emulation_matches_sum_of_independent_ranks(nccl_world1):
     assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
 
 
+def test_optimizer_step_behind_each_bucket_equals_the_plain_order_bitwise(nccl_world1):
+    """GradAllReduce.all_reduce(optimizer=opt): the fused step updates every bucket's parameter range on a side stream behind
+    that bucket's collective instead of after all of them -- the same parameters, moments and zeroed gradients bit for bit,
+    over two steps (the second one with warm moment buffers); a second backward before the step falls back to the plain wait."""
+    from dyk.ddp import GradAllReduce
+    from dyk.optim import FusedAdam
+    res = []
+    for deferred in (False, True):
+        m = _model(C3, "bf16")
+        red = GradAllReduce(m, nccl_world1)
+        opt = FusedAdam(m, lr=1e-3, betas=(0.937, 0.999), weight_decay=5e-4)
+        for step in range(2):
+            _backward(m, _batch(step))
+            red.all_reduce(optimizer=opt if deferred else None)
+            assert (opt._buckets is not None) == deferred
+            opt.step()
+            assert opt._buckets is None
+        torch.cuda.synchronize()
+        res.append((m.engine.store.P.clone(), opt._m.clone(), opt._v.clone(), m.engine.store.G.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert float(res[0][3].abs().sum()) == 0.0
+    # two backward passes before the step (gradient accumulation): the buckets no longer tile the buffer once -> plain wait
+    _backward(m, _batch(0)); _backward(m, _batch(1))
+    red.all_reduce(optimizer=opt)
+    assert opt._buckets is None and not red._works
+
+
 @pytest.mark.parametrize("name,dtype", [(C3, "bf16"), (C5, "bf16"), (C3, "fp32")])
 def test_dependency_scheduled_streams_equal_serial_execution_bitwise(name, dtype, monkeypatch):
     """the multi-stream dependency schedule (dyk/sched.py + dyk_run_schedule) must not change a single bit relative to
