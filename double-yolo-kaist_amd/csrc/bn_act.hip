@@ -523,6 +523,7 @@ extern "C" int dyk_bn_bwd_params(double* red, float* dgamma, float* dbeta, int32
 extern "C" int dyk_bn_act_bwd_apply(const DykEwDesc* d, void* stream) {
     const int rc = ew_check(d, true);
     if (rc) return rc;
+    if (d->flags & DYK_EW_SKIP) return DYK_OK;          // done inside the consumer (DykStemDesc.bn_fused)
     if (!d->red || !d->p0 || !d->p1 || !d->p2 || !d->p3) return DYK_ERR_ARG;
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     int gx, gy;

@@ -408,17 +408,59 @@ __global__ __launch_bounds__(64) void stem_wgrad_u8_kernel(const DykStemDesc d, 
     constexpr int VPP = COUT / 8;                                 // 16-byte vectors per pixel (tight rows: lddy == COUT)
     constexpr int NV = STEM_SEG * VPP / 64;                       // per lane and segment: 4 (16 channels) | 8 (32)
     const int wpr = (Wseg + 3 + 3) / 4;                           // words per patch row, from the aligned start x0 - 4
-    uint4 t[NV];
+    uint4 t[NV], ty[NV];
     uint32_t iw[9][2];
     const uint8_t* img8 = (const uint8_t*)d.img;
+    // ---- fused BatchNorm-backward apply (DykStemDesc.bn_fused): fold the two reduction sums of the replicas (lane = (sum, channel):
+    //      one batch of loads, in flight together with the first segment's), workgroup 0 adds them to dgamma / dbeta, every lane
+    //      keeps the constants of ITS eight channels (a lane always parks the same channel group: 64 % VPP == 0)
+    const bool fused = d.bn_fused != 0;
+    float* s_tot = (float*)(smem + 32 * RS * 2 + 9 * (STEM_SEG * 2 + 2 + 8) * 2 + 64);       // [2][32], behind the largest patch
+    float f_sc[8], f_mu[8], f_rs[8], f_m1[8], f_m2[8];
+    auto fold = [&]() {
+        const int which = lane >> 5, ch = lane & 31;
+        double acc2 = 0.0;
+        if (ch < COUT) {
+            const int slots = d.bn_slots > 0 ? d.bn_slots : 1;
+            double a4[4] = {0.0, 0.0, 0.0, 0.0};
+            int r = 0;
+            for (; r + 4 <= slots; r += 4) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = d.bn_red[((size_t)(r + u) * 2 + which) * COUT + ch];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a4[u] += v[u];
+            }
+            for (; r < slots; ++r) a4[0] += d.bn_red[((size_t)r * 2 + which) * COUT + ch];
+            acc2 = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+            if (blockIdx.x == 0) {
+                float* gp = which ? d.bn_dgamma : d.bn_dbeta;          // sum(da * xhat) -> dgamma, sum(da) -> dbeta
+                if (gp) gp[ch] += (float)acc2;
+            }
+        }
+        s_tot[lane] = (float)acc2;
+        __syncthreads();
+        const float invn = 1.f / (float)((long)d.B * d.Ho * d.Wo);
+        const int c0 = (lane % VPP) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f_sc[j] = d.bn_vecs[c0 + j]; f_mu[j] = d.bn_vecs[2 * COUT + c0 + j]; f_rs[j] = d.bn_vecs[3 * COUT + c0 + j];
+            f_m1[j] = s_tot[c0 + j] * invn; f_m2[j] = s_tot[32 + c0 + j] * invn;
+        }
+    };
     auto fetch = [&](int sg) {
         const int row = sg / segs_per_row, x_begin = (sg - row * segs_per_row) * STEM_SEG;
         const int b = row / d.Ho, yo = row - b * d.Ho;
         const int npx = min(STEM_SEG, d.Wo - x_begin);
-        const T* dyseg = (const T*)d.dy + ((long)row * d.Wo + x_begin) * d.lddy;
+        const T* dyseg = (const T*)(fused ? d.bn_da : d.dy) + ((long)row * d.Wo + x_begin) * d.lddy;
         const int nvec = npx * VPP;
 #pragma unroll
         for (int u = 0; u < NV; ++u) { const int v = lane + u * 64; t[u] = ((const uint4*)dyseg)[v < nvec ? v : 0]; }
+        if (fused) {
+            const T* yseg = (const T*)d.bn_yraw + ((long)row * d.Wo + x_begin) * d.lddy;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) { const int v = lane + u * 64; ty[u] = ((const uint4*)yseg)[v < nvec ? v : 0]; }
+        }
         const int a0 = x_begin * d.stride - 4;                   // aligned start: the patch begins at a0 + 3
 #pragma unroll
         for (int rr = 0; rr < 9; ++rr) {
@@ -445,7 +487,22 @@ __global__ __launch_bounds__(64) void stem_wgrad_u8_kernel(const DykStemDesc d, 
             const int v = lane + u * 64;
             if (v < nvec) {
                 const int px = v / VPP, c0 = (v % VPP) * 8;
-                const uint32_t w4[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+                uint32_t w4[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+                if (fused) {
+                    // dz = scale * (da - S1/N - xhat * S2/N), xhat = (yraw - mean) * rstd: bn_act_bwd_apply_kernel's expression with
+                    // act' already in da, rounded to bf16 as that pass stores it
+                    const uint32_t y4[4] = {ty[u].x, ty[u].y, ty[u].z, ty[u].w};
+                    float dzv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float da = __uint_as_float((j & 1) ? (w4[j >> 1] & 0xffff0000u) : (w4[j >> 1] << 16));
+                        const float yy = __uint_as_float((j & 1) ? (y4[j >> 1] & 0xffff0000u) : (y4[j >> 1] << 16));
+                        const float xh = (yy - f_mu[j]) * f_rs[j];
+                        dzv[j] = f_sc[j] * (da - f_m1[j] - xh * f_m2[j]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w4[q] = f32x2_to_bf16x2(dzv[2 * q], dzv[2 * q + 1]);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s_dyT[(c0 + j) * RS + px] = (uint16_t)(w4[j >> 1] >> (16 * (j & 1)));
             }
@@ -470,6 +527,7 @@ __global__ __launch_bounds__(64) void stem_wgrad_u8_kernel(const DykStemDesc d, 
     const int seg0 = blockIdx.x * segs_per_wg;
     const int seg1 = min(nsegs, seg0 + segs_per_wg);
     if (seg0 < seg1) fetch(seg0);
+    if (fused) fold();
     for (int sg = seg0; sg < seg1; ++sg) {
         const int row = sg / segs_per_row, x_begin = (sg - row * segs_per_row) * STEM_SEG;
         const int npx = min(STEM_SEG, d.Wo - x_begin);
@@ -598,10 +656,25 @@ extern "C" int dyk_stem_wgrad_planes(const DykStemDesc* d) {
     return (int)((nsegs + spw - 1) / spw);
 }
 
+// the conditions of the uint8 / bf16 MFMA kernel (the only one that carries the fused BatchNorm-backward apply)
+static bool stem_wgrad_u8_ok(const DykStemDesc* d, const void* grad) {
+    static int fast = -1;
+    if (fast < 0) { const char* e = getenv("DYK_STEM_WGRAD_U8"); fast = (e && e[0] == '0') ? 0 : 1; }
+    return fast && d->in_u8 && d->dtype == DYK_BF16 && d->lddy == d->Cout && d->W % 4 == 0 && ((uintptr_t)d->img % 4) == 0 &&
+           ((uintptr_t)grad % 16) == 0 && STEM_SEG * d->stride + 2 + 6 <= 4 * 128 && (d->Cout == 32 || d->Cout == 16);
+}
+
+// 1 = dyk_stem_conv_wgrad would run `d` with bn_fused set (the caller may then skip the separate apply pass: DYK_EW_SKIP)
+extern "C" int dyk_stem_wgrad_bn_fusable(const DykStemDesc* d) {
+    if (!d || check(d) != DYK_OK || !d->bn_da || !d->bn_yraw || !d->bn_vecs || !d->bn_red) return 0;
+    return stem_wgrad_u8_ok(d, d->bn_da) && ((uintptr_t)d->bn_yraw % 16) == 0 ? 1 : 0;
+}
+
 extern "C" int dyk_stem_conv_wgrad(const DykStemDesc* d, void* stream) {
     const int rc = check(d);
     if (rc) return rc;
-    if (!d->dy || !d->dw || !d->part || d->lddy < d->Cout) return DYK_ERR_ARG;
+    if (d->bn_fused && !dyk_stem_wgrad_bn_fusable(d)) return DYK_ERR_UNSUPPORTED;
+    if ((!d->dy && !d->bn_fused) || !d->dw || !d->part || d->lddy < d->Cout) return DYK_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long npix = (long)d->B * d->Ho * d->Wo;
     const int planes = dyk_stem_wgrad_planes(d);
@@ -610,12 +683,9 @@ extern "C" int dyk_stem_conv_wgrad(const DykStemDesc* d, void* stream) {
     const int spw = (int)((nsegs + planes - 1) / planes);
     const dim3 grid((unsigned)planes);
     const size_t es = d->dtype == DYK_BF16 ? 2 : 4;
-    const size_t lds = (size_t)STEM_SEG * 32 * es + (size_t)9 * (STEM_SEG * d->stride + 2) * 4;
+    const size_t lds = (size_t)STEM_SEG * 32 * es + (size_t)9 * (STEM_SEG * d->stride + 2) * 4 + 1024;
     (void)npix;
-    static int fast = -1;
-    if (fast < 0) { const char* e = getenv("DYK_STEM_WGRAD_U8"); fast = (e && e[0] == '0') ? 0 : 1; }
-    if (fast && d->in_u8 && d->dtype == DYK_BF16 && d->lddy == d->Cout && d->W % 4 == 0 && ((uintptr_t)d->img % 4) == 0 &&
-        ((uintptr_t)d->dy % 16) == 0 && STEM_SEG * d->stride + 2 + 6 <= 4 * 128) {
+    if (stem_wgrad_u8_ok(d, d->bn_fused ? d->bn_da : d->dy)) {
         if (d->Cout == 32) hipLaunchKernelGGL((stem_wgrad_u8_kernel<32>), grid, dim3(64), lds, s, *d, spw, segs_per_row, (int)nsegs);
         else hipLaunchKernelGGL((stem_wgrad_u8_kernel<16>), grid, dim3(64), lds, s, *d, spw, segs_per_row, (int)nsegs);
     } else

@@ -3,6 +3,7 @@ native forward / backward command lists to torch autograd so that `loss.backward
 `torch.optim` in an unchanged train loop (reference train_utils/kaist_train_eval_utils.py:75-108)
 keep working.
 """
+import ctypes
 import os
 
 import torch
@@ -158,6 +159,13 @@ class Engine:
             keep.append(t)
             desc.p[0] = t.data_ptr()
         plan._dyn_keep = keep
+        if plan.stem_fuse:
+            # the stem's BatchNorm-backward apply inside its weight gradient (csrc/stem.hip): possible for THIS call's images?
+            lib = L.load()
+            for ap, wd in plan.stem_fuse:
+                ok = bool(lib.dyk_stem_wgrad_bn_fusable(ctypes.byref(wd)))
+                wd.bn_fused = 1 if ok else 0
+                ap.flags = (ap.flags | L.EW_SKIP) if ok else (ap.flags & ~L.EW_SKIP)
         plan.run("fwd", stream)
         if plan.has_bnfwd:
             self._post_bnfwd(plan)

@@ -14,6 +14,7 @@ DYK_F32, DYK_BF16, DYK_U8 = 0, 1, 2
 ACT_CODES = {"linear": 0, "leaky": 1, "mish": 2, "relu": 3, "relu6": 4, "hard-sigmoid": 5, "hard-swish": 6}
 EPI_AFFINE, EPI_RESIDUAL, EPI_STATS, EPI_ACCUM, EPI_OUT_F32, EPI_BNBWD, EPI_ADDEND, EPI_BNFWD = 1, 2, 4, 8, 16, 32, 64, 128
 EW_ACCUM = 1
+EW_SKIP = 2
 MAX_TAPS = 25
 SE_POOL_SPLITS = 16        # DYK_SE_POOL_SPLITS (include/dyk_hip.h): partial-sum planes of the pixel-split SE pool
 
@@ -124,9 +125,12 @@ class DykCommand(ctypes.Structure):
 
 class DykStemDesc(ctypes.Structure):
     _fields_ = [("img", _vp), ("wt", _vp), ("y", _vp), ("stats", _vp), ("scale", _vp), ("shift", _vp), ("dy", _vp),
-                ("dw", _vp), ("part", _vp), ("dtype", _i32), ("in_u8", _i32),
+                ("dw", _vp), ("part", _vp),
+                ("bn_da", _vp), ("bn_yraw", _vp), ("bn_vecs", _vp), ("bn_red", _vp), ("bn_dgamma", _vp), ("bn_dbeta", _vp),
+                ("dtype", _i32), ("in_u8", _i32),
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Cout", _i32), ("k", _i32), ("stride", _i32), ("pad", _i32),
-                ("Ho", _i32), ("Wo", _i32), ("ldy", _i32), ("lddy", _i32), ("act", _i32), ("stats_slots", _i32)]
+                ("Ho", _i32), ("Wo", _i32), ("ldy", _i32), ("lddy", _i32), ("act", _i32), ("stats_slots", _i32),
+                ("bn_fused", _i32), ("bn_slots", _i32)]
 
 
 class DykSchedEntry(ctypes.Structure):
@@ -234,12 +238,13 @@ SIGNATURES = {
     "dyk_stem_conv_fwd": (_i32, [_P(DykStemDesc), _vp]),
     "dyk_stem_conv_wgrad": (_i32, [_P(DykStemDesc), _vp]),
     "dyk_stem_wgrad_planes": (_i32, [_P(DykStemDesc)]),
+    "dyk_stem_wgrad_bn_fusable": (_i32, [_P(DykStemDesc)]),
     "dyk_box_convert": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "dyk_scale_coords": (_i32, [_vp, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
 }
 
 
-ABI_VERSION = 2          # = DYK_ABI_VERSION of include/dyk_hip.h: a stale .so with older descriptor layouts is refused
+ABI_VERSION = 3          # = DYK_ABI_VERSION of include/dyk_hip.h: a stale .so with older descriptor layouts is refused
 
 
 def load(path=None):

@@ -100,6 +100,7 @@ class Plan:
         self.fwd, self.bwd = [], []            # lists of (op, desc)
         self.dyn_in = []                       # (desc, 'x'|'y')  patch-gather inputs to patch per call
         self.dyn_dp = []                       # (desc, head index) head-permute-bwd inputs
+        self.stem_fuse = []                    # (BatchNorm-backward apply desc, stem weight-gradient desc): fusable per call (engine)
         self.p_out = []                        # per head: torch tensor [B,na,ny,nx,no] fp32
         self.io = None                         # eval: [B, rows, no]
         self.arenas = {}
@@ -919,6 +920,19 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 planes = (nsegs + spw - 1) // spw                            # == dyk_stem_wgrad_planes
                 part = new_ws(planes * f.Cout * 27 * 4)
                 later(lambda wd=wd, dy=dy, part=part: (setattr(wd, "dy", ptr_of(dy)), setattr(wd, "part", ws.ptr(part))))
+                bap = rec.get("_bn_apply")
+                if (bap is not None and bap[5] and code == L.DYK_BF16 and dy.ld == f.Cout and rec["y_raw"].ld == f.Cout
+                        and os.environ.get("DYK_STEM_BN_FUSE", "1") != "0"):
+                    # BatchNorm-backward apply of the stem's own BatchNorm inside this weight gradient (uint8 images: decided per
+                    # call by the engine, dyk_stem_wgrad_bn_fusable): da and the raw output are read instead of dz, the separate
+                    # pass over the largest activation of the net is skipped (DYK_EW_SKIP on its descriptor)
+                    ap, da_ref, red_, vecs_, cout_, _ = bap
+                    wd.bn_slots = STAT_SLOTS
+                    wd.bn_dgamma, wd.bn_dbeta = ap.aux, ap.aux2
+                    later(lambda wd=wd, da_ref=da_ref, yr=rec["y_raw"], red_=red_, vecs_=vecs_: (
+                        setattr(wd, "bn_da", ptr_of(da_ref)), setattr(wd, "bn_yraw", ptr_of(yr)),
+                        setattr(wd, "bn_vecs", ws.ptr(vecs_)), setattr(wd, "bn_red", ws.ptr(red_))))
+                    plan.stem_fuse.append((ap, wd))
                 plan.dyn_in.append((wd, [k_ for (d_, k_) in plan.dyn_in if d_ is f][0]))
                 plan.bwd.append((L.OP_STEM_WGRAD, wd))
                 return
@@ -1048,6 +1062,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     setattr(ap, "p2", ws.ptr(vecs + 8 * cout)), setattr(ap, "p3", ws.ptr(vecs + 12 * cout)),
                     setattr(ap, "red", ws.ptr(red))))
                 plan.bwd.append((L.OP_BN_BWD_APPLY, ap))
+                # (the stem's weight gradient can do this pass on the fly: emit_conv_backward below, DykStemDesc.bn_fused)
+                rec["_bn_apply"] = (ap, dz, red, vecs, cout, fused_red is not None and not keep_dz and act_bwd == 0 and dyr is dz)
                 dz = dyr
             emit_conv_backward(rec, dz)
 

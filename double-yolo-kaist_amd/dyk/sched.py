@@ -193,6 +193,10 @@ def accesses(op, d, mem, plan):
     elif op == L.OP_STEM_WGRAD:
         rd(T(d.dy, d.lddy, d.Cout, _es(d.dtype)))
         wr(V(d.part)); wr(mem.interval(_v(d.dw), d.Cout * 27 * 4))
+        if d.bn_da:                        # fusable BatchNorm-backward apply (decided per call): the union of both forms' accesses
+            rd(T(d.bn_da, d.lddy, d.Cout, _es(d.dtype))); rd(T(d.bn_yraw, d.lddy, d.Cout, _es(d.dtype)))
+            rd(V(d.bn_vecs)); rd(V(d.bn_red))
+            wr(mem.interval(_v(d.bn_dgamma), d.Cout * 4)); wr(mem.interval(_v(d.bn_dbeta), d.Cout * 4))
     elif op == L.OP_BN_FINALIZE:
         wr(V(d.stats)); wr(V(d.scale)); wr(V(d.shift)); wr(V(d.save_mean)); wr(V(d.save_rstd))
     elif op == L.OP_BN_FWD_FUSED:

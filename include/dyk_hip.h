@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DYK_ABI_VERSION 2   /* 2: round-3 descriptor layouts (twin / cmd2 fields, BNFWD block, focal-loss fields) */
+#define DYK_ABI_VERSION 3   /* 3: round 4, DykStemDesc fused BatchNorm-backward apply (bn_* fields); 2: round-3 descriptor layouts */
 
 enum {
     DYK_OK = 0,
@@ -237,7 +237,8 @@ int dyk_grad_reduce(float* G, const float* part, const DykGradReduceEntry* table
  * fp64 reduction buffer.
  * ---------------------------------------------------------------------------------- */
 enum {
-    DYK_EW_ACCUM = 1      /* out += result instead of out = result */
+    DYK_EW_ACCUM = 1,     /* out += result instead of out = result */
+    DYK_EW_SKIP = 2       /* dyk_bn_act_bwd_apply: do nothing (the pass is done inside the consumer: DykStemDesc.bn_fused) */
 };
 
 typedef struct DykEwDesc {
@@ -687,13 +688,29 @@ typedef struct DykStemDesc {
     const void* dy;        /* wgrad: gradient wrt y, dtype, rows of lddy elements */
     float* dw;             /* wgrad: [Cout][27], accumulated */
     float* part;           /* wgrad workspace */
+    /* wgrad with bn_fused != 0 (uint8 images, bf16): the BatchNorm-backward APPLY pass of the stem's own BatchNorm is done on
+     * the fly instead of by a separate dyk_bn_act_bwd_apply launch -- `dy` is not read; the kernel reads da (the gradient wrt the
+     * normalised output with act' already applied, as a fused data-gradient epilogue leaves it) and the raw conv output, folds
+     * the two reduction sums from the replicas and feeds  dz = scale * (da - S1/N - xhat * S2/N),  xhat = (yraw - mean) * rstd,
+     * rounded to bf16 as the apply pass would store it, to the weight gradient; workgroup 0 adds S2 / S1 to dgamma / dbeta.
+     * Saves one pass over the largest activation of the net (512 x 640 x 32 per image): written once less, read once less. */
+    const void* bn_da;     /* [B,Ho,Wo,Cout] dtype, rows of Cout elements */
+    const void* bn_yraw;   /* raw conv output, same layout */
+    const float* bn_vecs;  /* scale | shift | mean | rstd, Cout floats each */
+    const double* bn_red;  /* [bn_slots][2][Cout]: sum(da), sum(da * xhat) replicas */
+    float* bn_dgamma;      /* += S2 (or NULL) */
+    float* bn_dbeta;       /* += S1 (or NULL) */
     int32_t dtype, in_u8;
     int32_t B, H, W, Cout, k, stride, pad, Ho, Wo;
     int32_t ldy, lddy, act, stats_slots;
+    int32_t bn_fused, bn_slots;
 } DykStemDesc;
 int dyk_stem_conv_fwd(const DykStemDesc* desc, void* stream);
 int dyk_stem_conv_wgrad(const DykStemDesc* desc, void* stream);
 int dyk_stem_wgrad_planes(const DykStemDesc* desc);
+/* 1 when dyk_stem_conv_wgrad would accept `desc` with bn_fused set (its bn_* fields and in_u8 / img filled in): the caller then
+ * sets bn_fused and DYK_EW_SKIP on the BatchNorm's own dyk_bn_act_bwd_apply descriptor; 0: run the two passes separately. */
+int dyk_stem_wgrad_bn_fusable(const DykStemDesc* desc);
 
 /* Dependency-scheduled execution on several HIP streams.  The plan compiler derives the read / write sets of every
  * command from its descriptor, builds the dependency graph and list-schedules it onto n_streams in-order streams

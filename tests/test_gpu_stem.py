@@ -94,6 +94,76 @@ def test_stem_forward_statistics_and_weight_gradient(cout, stride, dtype, u8, sh
     assert torch.equal(dw, first), "weight gradient must be bit-reproducible"
 
 
+@pytest.mark.parametrize("cout,stride,shape", [(32, 1, (2, 37, 300)), (16, 2, (3, 70, 600)), (32, 1, (4, 64, 128))])
+def test_stem_weight_gradient_with_the_batchnorm_backward_apply_inside(cout, stride, shape):
+    """DykStemDesc.bn_fused (uint8 images, bf16): the weight gradient reads da and the raw conv output, folds the reduction
+    replicas and applies  dz = scale * (da - S1/N - xhat * S2/N)  on the fly; workgroup 0 adds S2 / S1 to dgamma / dbeta.
+    Against the two separate passes (dyk_bn_act_bwd_apply, then dyk_stem_conv_wgrad on its output): the same dz, rounded to
+    bf16 the same way -- weight gradient, dgamma and dbeta agree to fp32 summation level; DYK_EW_SKIP makes the separate pass
+    a no-op; a float image batch is not fusable."""
+    from dyk import lib as L
+    lib = L.load()
+    B, H, W = shape
+    g = torch.Generator().manual_seed(7 * cout + stride)
+    img = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=g).cuda().contiguous()
+    d = _desc(img, torch.zeros(cout, 3, 3, 3), stride, torch.bfloat16)
+    Ho, Wo = d.Ho, d.Wo
+    n = B * Ho * Wo
+    da = (torch.randn(B, Ho, Wo, cout, generator=g) * 0.2).bfloat16().cuda()
+    yraw = (torch.randn(B, Ho, Wo, cout, generator=g) * 1.3 + 0.2).bfloat16().cuda()
+    mean = yraw.float().mean((0, 1, 2))
+    rstd = (yraw.float().var((0, 1, 2), unbiased=False) + 1e-5).rsqrt()
+    scale = (torch.rand(cout, generator=g) + 0.5).cuda() * rstd
+    vecs = torch.cat([scale, torch.zeros(cout, device="cuda"), mean, rstd]).contiguous()
+    xhat = (yraw.float() - mean) * rstd
+    slots = 16
+    red = torch.zeros(slots, 2, cout, dtype=torch.float64, device="cuda")
+    # the sums as a fused data-gradient epilogue leaves them: spread over the replicas
+    s1, s2 = da.double().sum((0, 1, 2)), (da.double() * xhat.double()).sum((0, 1, 2))
+    wts = torch.rand(slots, generator=g).double().cuda()
+    wts /= wts.sum()
+    red[:, 0] = wts.view(-1, 1) * s1
+    red[:, 1] = wts.view(-1, 1) * s2
+    planes = lib.dyk_stem_wgrad_planes(ctypes.byref(d))
+    part = torch.empty(planes * cout * 27, dtype=torch.float32, device="cuda")
+    # ---- two passes
+    dz = torch.empty_like(da)
+    dg0, db0 = torch.full((cout,), 0.25, device="cuda"), torch.full((cout,), -0.5, device="cuda")
+    e = L.DykEwDesc()
+    e.a, e.b, e.out = da.data_ptr(), yraw.data_ptr(), dz.data_ptr()
+    e.p0, e.p1, e.p2, e.p3 = vecs.data_ptr(), vecs.data_ptr() + 4 * cout, vecs.data_ptr() + 8 * cout, vecs.data_ptr() + 12 * cout
+    e.red, e.slots, e.aux, e.aux2 = red.data_ptr(), slots, dg0.data_ptr(), db0.data_ptr()
+    e.dtype, e.npix, e.C, e.lda, e.ldb, e.ldo, e.act = L.DYK_BF16, n, cout, cout, cout, cout, 0
+    L.check(lib.dyk_bn_act_bwd_apply(ctypes.byref(e), _stream()), "dyk_bn_act_bwd_apply")
+    dw0 = torch.zeros((cout, 27), dtype=torch.float32, device="cuda")
+    d.dy, d.lddy, d.dw, d.part = dz.data_ptr(), cout, dw0.data_ptr(), part.data_ptr()
+    L.check(lib.dyk_stem_conv_wgrad(ctypes.byref(d), _stream()), "dyk_stem_conv_wgrad")
+    # ---- one pass
+    dg1, db1 = torch.full((cout,), 0.25, device="cuda"), torch.full((cout,), -0.5, device="cuda")
+    dw1 = torch.zeros((cout, 27), dtype=torch.float32, device="cuda")
+    d.dy, d.dw = None, dw1.data_ptr()
+    d.bn_da, d.bn_yraw, d.bn_vecs, d.bn_red, d.bn_slots = da.data_ptr(), yraw.data_ptr(), vecs.data_ptr(), red.data_ptr(), slots
+    d.bn_dgamma, d.bn_dbeta = dg1.data_ptr(), db1.data_ptr()
+    assert lib.dyk_stem_wgrad_bn_fusable(ctypes.byref(d)) == 1
+    d.bn_fused = 1
+    L.check(lib.dyk_stem_conv_wgrad(ctypes.byref(d), _stream()), "dyk_stem_conv_wgrad(bn_fused)")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dw1).all()) and float(dw0.abs().max()) > 0
+    assert float((dw1 - dw0).abs().max()) <= 2e-3 * float(dw0.abs().max()), float((dw1 - dw0).abs().max()) / float(dw0.abs().max())
+    assert torch.allclose(dg1, dg0, rtol=1e-6, atol=1e-5) and torch.allclose(db1, db0, rtol=1e-6, atol=1e-5)
+    assert float((dg1 - 0.25 - s2.float()).abs().max()) <= 1e-4 * max(1.0, float(s2.abs().max()))
+    # DYK_EW_SKIP: the separate pass does nothing
+    dz.fill_(7.0)
+    e.flags = L.EW_SKIP
+    L.check(lib.dyk_bn_act_bwd_apply(ctypes.byref(e), _stream()), "dyk_bn_act_bwd_apply(skip)")
+    assert float((dz.float() - 7.0).abs().max()) == 0.0 and torch.equal(dg0, dg1)
+    # float images: not fusable, and asking for it anyway is refused
+    imgf = (img.float() / 255.0).contiguous()
+    d.img, d.in_u8 = imgf.data_ptr(), 0
+    assert lib.dyk_stem_wgrad_bn_fusable(ctypes.byref(d)) == 0
+    assert lib.dyk_stem_conv_wgrad(ctypes.byref(d), _stream()) != 0
+
+
 def test_stem_rejects_unsupported_shapes():
     from dyk import lib as L
     lib = L.load()
