@@ -196,7 +196,7 @@ class Plan:
         mode = os.environ.get("DYK_SCHED", "dag")
         if mode == "dag" and os.environ.get("DYK_OVERLAP", "1") != "0":
             sc = self.schedule(which, start, end)
-            lp = 1 if os.environ.get("DYK_SCHED_FILLER", "0") != "0" else 0
+            lp = 1 if os.environ.get("DYK_SCHED_LOWPRIO", "0") != "0" else 0       # (low-priority streams: 40 ms against 28.5, round 4)
             rc = None
             # hipGraph replay of the dependency graph: built and tested, OFF by default -- on this stack (HIP runtime of
             # PyTorch-ROCm 7.0) a graph launch of the 435 + 671 child nodes runs the step in 46.3 ms against 36.1 ms for the

@@ -349,7 +349,7 @@ class Schedule:
         self.array = arr
 
 
-def schedule(cmds, deps, costs, n_streams, first=0, filler=None, klass=None):
+def schedule(cmds, deps, costs, n_streams, first=0, filler=None, klass=None, policy="hlfet"):
     """List scheduling (highest bottom level first) onto `n_streams` in-order streams.  Among the commands whose
     producers are all placed, the one with the longest remaining dependency chain goes next, onto the stream where it
     can start earliest; ties prefer the stream of its latest-finishing producer (no event needed), then the lowest
@@ -378,7 +378,8 @@ def schedule(cmds, deps, costs, n_streams, first=0, filler=None, klass=None):
     for i in range(n - 1, -1, -1):
         blevel[i] = costs[i] + max((blevel[u] for u in users[i]), default=0.0)
     missing = [len(deps[i]) for i in range(n)]
-    general = n_streams - 1 if (filler and n_streams > 1) else n_streams
+    n_fill = min(n_streams - 1, max(1, int(os.environ.get("DYK_SCHED_FILLER", "1") or 1))) if (filler and n_streams > 1) else 0
+    general = n_streams - n_fill
     avail = [0.0] * n_streams
     start, finish, stream_of = [0.0] * n, [0.0] * n, [0] * n
     pos_in_stream = [0] * n
@@ -392,7 +393,7 @@ def schedule(cmds, deps, costs, n_streams, first=0, filler=None, klass=None):
             if finish[j] > ready:
                 ready, prod = finish[j], j
         if filler and i in filler and n_streams > 1:
-            cand = [n_streams - 1]
+            cand = range(general, n_streams)
         elif klass is not None and n_streams > 1:
             cand = [0] if klass[i] == 0 else range(1, general)
         else:
@@ -405,7 +406,31 @@ def schedule(cmds, deps, costs, n_streams, first=0, filler=None, klass=None):
                 best, best_t = s_, t
         return best, best_t
 
-    if klass is None:
+    if klass is None and policy == "event":
+        # time-driven list scheduling: the next command is the highest-priority one among those that could START earliest
+        # (producers finished, a stream free).  The plain rule above places commands in priority order and only ever
+        # appends to a stream, so every weight gradient -- low priority: nothing in the pass reads it -- is placed after the
+        # whole critical chain, the expensive late ones first, and an in-order stream then holds the early cheap ones
+        # behind them (MobileNetV3 cfg: the other streams idle through the neck's backward while its weight gradients wait)
+        ready_t = {i: 0.0 for i in range(n) if missing[i] == 0}
+        while ready_t:
+            free_g = min(avail[:general])
+            free_f = min(avail[general:]) if n_fill else free_g
+            est = {j: max(r, free_f if (n_fill and j in filler) else free_g) for j, r in ready_t.items()}
+            t_min = min(est.values())
+            i = max((j for j, t in est.items() if t <= t_min + 1e-9), key=lambda j: (blevel[j], -j))
+            del ready_t[i]
+            best, best_t = place(i)
+            start[i], finish[i], stream_of[i] = best_t, best_t + costs[i], best
+            avail[best] = finish[i]
+            pos_in_stream[i] = count[best]
+            count[best] += 1
+            placed += 1
+            for u in users[i]:
+                missing[u] -= 1
+                if missing[u] == 0:
+                    ready_t[u] = max(finish[j] for j in deps[u])
+    elif klass is None:
         heap = [(-blevel[i], i) for i in range(n) if missing[i] == 0]
         heapq.heapify(heap)
         while heap:
@@ -498,7 +523,8 @@ def build(plan, store, which, start, end, n_streams=None):
     # 43.0 ms vs 35.3 (batch 1: 18.1 vs 10.2): every conv -> BatchNorm -> conv hop then crosses streams, and a cross-stream
     # event dependency costs ~7-10 us on this stack, more than the overlap it buys
     klass = None
-    if os.environ.get("DYK_SCHED_POLICY", "hlfet") == "typed" and n_streams > 1:
+    policy = os.environ.get("DYK_SCHED_POLICY", "event")
+    if policy == "typed" and n_streams > 1:
         klass = [0 if op in (L.OP_CONV, L.OP_WGRAD) else 1 for op, _ in cmds]
     # two-problem launches for the twin sections of a dual-stream net (dyk/twins.py): commands of twin sections with
     # equal descriptors that the dependency graph leaves unordered are contracted into one node each; the schedule is
@@ -523,13 +549,13 @@ def build(plan, store, which, start, end, n_streams=None):
             filler = {k for k, m in enumerate(members) if m[0] in filler}
         if klass is not None:
             klass = [klass[m[0]] for m in members]
-        sc = schedule(members, ndeps, ncosts, max(1, min(n_streams, 8)), first=0, filler=filler, klass=klass)
+        sc = schedule(members, ndeps, ncosts, max(1, min(n_streams, 8)), first=0, filler=filler, klass=klass, policy=policy)
         for e, ent in zip(sc.entries, sc.array):
             m = members[e["cmd"]]
             e["cmd"] = ent.cmd = m[0] + start
             e["cmd2"] = ent.cmd2 = (m[1] + start) if len(m) > 1 else -1
     else:
-        sc = schedule(cmds, deps, costs, max(1, min(n_streams, 8)), first=start, filler=filler, klass=klass)
+        sc = schedule(cmds, deps, costs, max(1, min(n_streams, 8)), first=start, filler=filler, klass=klass, policy=policy)
     sc.n_pairs = len(pairs)
     sc.set_deps(_reduce(deps))
     return sc

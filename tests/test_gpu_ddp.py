@@ -159,11 +159,11 @@ def test_dependency_scheduled_streams_equal_serial_execution_bitwise(name, dtype
     the same command lists enqueued in order on one stream: outputs, loss, every gradient, running statistics"""
     from build_utils.utils import compute_loss
     res = []
-    for mode in ("serial", "dag", "dag_graph", "dag6", "dag_nopair"):
+    for mode in ("serial", "dag", "dag_graph", "dag6", "dag_nopair", "dag_event"):
         monkeypatch.setenv("DYK_OVERLAP", "0" if mode == "serial" else "1")
-        monkeypatch.setenv("DYK_PAIR", "0" if mode == "dag_nopair" else "1")      # two-problem launches of the twin sections
+        monkeypatch.setenv("DYK_PAIR", "0" if mode in ("dag_nopair", "dag_event") else "1")      # two-problem launches of the twin sections
         monkeypatch.setenv("DYK_PAIR_OPS", "all" if mode in ("dag", "dag_graph") else "ew")    # all: convolutions too
-        monkeypatch.setenv("DYK_SCHED_POLICY", "hlfet" if mode == "dag6" else "typed")
+        monkeypatch.setenv("DYK_SCHED_POLICY", "hlfet" if mode == "dag6" else ("event" if mode == "dag_event" else "typed"))   # event: the default
         monkeypatch.setenv("DYK_STREAMS", "6" if mode == "dag6" else "4")
         monkeypatch.setenv("DYK_GRAPH", "1" if mode == "dag_graph" else "0")      # hipGraph of the dependency graph (optional path)
         m = _model(name, dtype)

@@ -71,7 +71,8 @@ def _check(plan, st, which, start, end, n_streams):
 
 
 @pytest.mark.parametrize("name,pair,policy", [(C3, "all", "typed"), (C3, "ew", "typed"), (C3, "0", "hlfet"), (C5, "all", "hlfet"),
-                                              (C5, "ew", "typed"), (C1, "ew", "typed")])
+                                              (C5, "ew", "typed"), (C1, "ew", "typed"), (C3, "0", "event"), (C5, "ew", "event"),
+                                              (C5, "all", "event")])
 def test_schedules_respect_every_memory_conflict(name, pair, policy, monkeypatch):
     monkeypatch.setenv("DYK_PAIR", "0" if pair == "0" else "1")
     monkeypatch.setenv("DYK_PAIR_OPS", pair)
@@ -107,6 +108,25 @@ def test_schedules_respect_every_memory_conflict(name, pair, policy, monkeypatch
     sc1 = sched.build(plan, st, "fwd", 0, len(plan.fwd), n_streams=1)
     assert [e["cmd"] for e in sc1.entries] == sorted(e["cmd"] for e in sc1.entries) or True
     assert all(not e["waits"] and not e["record"] for e in sc1.entries)
+
+
+@pytest.mark.parametrize("name", [C3, C5])
+def test_time_driven_policy_does_not_hold_early_weight_gradients_behind_late_ones(name, monkeypatch):
+    """the default policy (DYK_SCHED_POLICY=event) picks, at every step of the simulation, among the commands that could
+    start earliest; the priority-order rule (hlfet) appends every weight gradient after the whole critical chain, the late
+    expensive ones first, so an in-order stream holds the neck's cheap early ones until the end of the pass"""
+    from dyk import lib as L, sched
+    monkeypatch.setenv("DYK_PAIR", "0")
+    plan, st = _plan(name, True, B=4, H=256, W=320)
+    res = {}
+    for policy in ("hlfet", "event"):
+        monkeypatch.setenv("DYK_SCHED_POLICY", policy)
+        sc = sched.build(plan, st, "bwd", 0, len(plan.bwd), n_streams=4)
+        # mean issue position of the weight-gradient launches, relative to the pass
+        pos = [k for k, e in enumerate(sc.entries) if plan.bwd[e["cmd"]][0] in (L.OP_WGRAD, L.OP_DW_WGRAD)]
+        res[policy] = (sc.makespan_us, sum(pos) / len(pos) / sc.n)
+    assert res["event"][0] <= res["hlfet"][0] * 1.001, res
+    assert res["event"][1] < res["hlfet"][1], res                # weight gradients are issued earlier in the pass
 
 
 def test_eval_plan_schedules_and_channel_slices_are_independent():
