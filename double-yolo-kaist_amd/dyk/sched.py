@@ -350,10 +350,12 @@ class Schedule:
 
 
 def schedule(cmds, deps, costs, n_streams, first=0, filler=None, klass=None, policy="hlfet"):
-    """List scheduling (highest bottom level first) onto `n_streams` in-order streams.  Among the commands whose
-    producers are all placed, the one with the longest remaining dependency chain goes next, onto the stream where it
-    can start earliest; ties prefer the stream of its latest-finishing producer (no event needed), then the lowest
-    index.  The critical chain therefore stays on one stream while independent branches and the weight gradients
+    """List scheduling (highest bottom level first) onto `n_streams` in-order streams.  `policy`: "event" (default,
+    round 4) advances a simulated clock -- among the commands that could start earliest (producers finished, a stream
+    free) the one with the longest remaining dependency chain goes next; "hlfet" (rounds 2-3) ignores the clock: among the
+    commands whose producers are all placed, the one with the longest remaining dependency chain goes next.  Either way
+    the command goes onto the stream where it can start earliest; ties prefer the stream of its latest-finishing producer
+    (no event needed), then the lowest index.  The critical chain therefore stays on one stream while independent branches and the weight gradients
     (which nothing in a pass reads) fill the others.  `filler`: optional set of command indices restricted to the last
     stream (a low-priority stream in the executor).  Returns a Schedule whose entries are sorted by simulated start
     time -- the host issues in that order so that no stream starves behind another one's commands.  `first` is added
