@@ -181,7 +181,7 @@ def test_dependency_scheduled_streams_equal_serial_execution_bitwise(name, dtype
             assert len({e["stream"] for e in sc.entries}) >= 3
             # the twin backbones ride in two-problem launches (serial = one command per launch: the comparison partner)
             assert sc.n == len(plan.bwd) - sc.n_pairs
-            assert {"dag_nopair": sc.n_pairs == 0, "dag6": sc.n_pairs >= 20}.get(mode, sc.n_pairs >= 100 or name != C3)
+            assert {"dag_nopair": sc.n_pairs == 0, "dag_event": sc.n_pairs == 0, "dag6": sc.n_pairs >= 20}.get(mode, sc.n_pairs >= 100 or name != C3)
             assert bool(plan._graphs) == (mode == "dag_graph"), "the forward graph is captured on the second pass with the same pointers"
         res.append((outs, m.engine.store.G.clone(), m.engine.store.R.clone()))
     for other in res[1:]:
