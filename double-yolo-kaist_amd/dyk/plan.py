@@ -1517,14 +1517,45 @@ if os.environ.get("DYK_WGRAD_RB", "1") != "0":
 # | 2 << 28 = row-block 3x3 kernel (round 4: 128-pixel block steps, 64 x 32 x 9-tap tiles)
 
 
+_TUNE_LOAD = {}
+
+
+def _background_load(kind, reps):
+    """analysis ("tune under load"): DYK_TUNE_LOAD=hbm | mfma | both keeps a side stream busy with copies of a
+    512 MB buffer and / or 4096^3 bf16 matrix products while a candidate is timed, so that candidates are ranked by what
+    they cost beside other kernels (in the step four streams share the chip) instead of alone.  Measured (round 4, in-call,
+    `profiles/r04_ab_tune_under_load.log`): 28.4 ms with candidates timed alone, 29.5 (hbm), 30.5 (mfma), 29.5 (both) -- the load's
+    own jitter decides between close candidates; OFF by default"""
+    if not _TUNE_LOAD:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        _TUNE_LOAD["stream"] = torch.cuda.Stream()
+        _TUNE_LOAD["a"] = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+        _TUNE_LOAD["b"] = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+        _TUNE_LOAD["m"] = torch.randn(4096, 4096, device=dev).bfloat16()
+        _TUNE_LOAD["o"] = torch.empty(4096, 4096, dtype=torch.bfloat16, device=dev)
+    st = _TUNE_LOAD["stream"]
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        for _ in range(2 * reps + 2):
+            if kind in ("hbm", "both"):
+                _TUNE_LOAD["b"].copy_(_TUNE_LOAD["a"])
+            if kind in ("mfma", "both"):
+                torch.mm(_TUNE_LOAD["m"], _TUNE_LOAD["m"], out=_TUNE_LOAD["o"])
+    return st
+
+
 def _time_launch(fn, desc, stream, reps=3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     L.check(fn(ctypes.byref(desc), stream), "autotune launch")          # warm-up (also loads the code object)
+    load = os.environ.get("DYK_TUNE_LOAD", "0")
+    side = _background_load(load, reps) if load != "0" else None
     e0.record()
     for _ in range(reps):
         fn(ctypes.byref(desc), stream)
     e1.record()
     e1.synchronize()
+    if side is not None:
+        side.synchronize()
     return e0.elapsed_time(e1) / reps
 
 
