@@ -1023,14 +1023,23 @@ extern "C" int dyk_se_fc_fwd(const DykSeFcDesc* d, void* stream) {
 }
 
 extern "C" int dyk_se_fc_bwd(const DykSeFcDesc* d, void* stream) {
-    if (!d || !d->pooled || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->dscale || !d->dpooled || !d->dw1 || !d->db1 ||
-        !d->dw2 || !d->db2 || !d->ws || d->B <= 0 || d->B > 256 || d->C <= 0 || d->Cs <= 0 || d->C > 8192 || d->Cs > 8192)
+    // Two halves that a caller may issue as separate calls (round 4: the parameter gradients are not on the path to dx, and
+    // one call held the backward chain for all three launches):
+    //   dpooled != NULL                the data half: dt1 -> ws, dpooled
+    //   dw1, db1, dw2, db2 != NULL     the parameter half (reads h, dt1, t2 from ws: after the data half)
+    // all five set = both, in that order; the four gradient pointers come all or none.
+    const bool data = d && d->dpooled, params = d && (d->dw1 || d->db1 || d->dw2 || d->db2);
+    if (!d || !d->pooled || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->dscale || (!data && !params) ||
+        (params && (!d->dw1 || !d->db1 || !d->dw2 || !d->db2)) || !d->ws || d->B <= 0 || d->B > 256 || d->C <= 0 || d->Cs <= 0 ||
+        d->C > 8192 || d->Cs > 8192)
         return DYK_ERR_ARG;
-    hipLaunchKernelGGL(se_cols_kernel<0>, dim3((unsigned)((d->Cs + 15) / 16), (unsigned)d->B), dim3(256), (size_t)(d->C + 256) * 4,
-                       (hipStream_t)stream, *d);
-    hipLaunchKernelGGL(se_cols_kernel<1>, dim3((unsigned)((d->C + 15) / 16), (unsigned)d->B), dim3(256), (size_t)(d->Cs + 256) * 4,
-                       (hipStream_t)stream, *d);
-    hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3((unsigned)(d->C + d->Cs)), dim3(256), 0, (hipStream_t)stream, *d);
+    if (data) {
+        hipLaunchKernelGGL(se_cols_kernel<0>, dim3((unsigned)((d->Cs + 15) / 16), (unsigned)d->B), dim3(256), (size_t)(d->C + 256) * 4,
+                           (hipStream_t)stream, *d);
+        hipLaunchKernelGGL(se_cols_kernel<1>, dim3((unsigned)((d->C + 15) / 16), (unsigned)d->B), dim3(256), (size_t)(d->Cs + 256) * 4,
+                           (hipStream_t)stream, *d);
+    }
+    if (params) hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3((unsigned)(d->C + d->Cs)), dim3(256), 0, (hipStream_t)stream, *d);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

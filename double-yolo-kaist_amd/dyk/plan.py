@@ -1198,13 +1198,26 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 plan._keep.append(fd)
                 fd.w1, fd.b1 = store.p_ptr(pre + "fc1.weight"), store.p_ptr(pre + "fc1.bias")
                 fd.w2, fd.b2 = store.p_ptr(pre + "fc2.weight"), store.p_ptr(pre + "fc2.bias")
-                fd.dw1, fd.db1 = store.g_ptr(pre + "fc1.weight"), store.g_ptr(pre + "fc1.bias")
-                fd.dw2, fd.db2 = store.g_ptr(pre + "fc2.weight"), store.g_ptr(pre + "fc2.bias")
                 fd.B, fd.C, fd.Cs = B, C, Cs
-                later(lambda fd=fd, rec=rec, dscale=dscale, dpooled=dpooled, fcws=fcws: (
-                    setattr(fd, "pooled", ws.ptr(rec["pooled"])), setattr(fd, "dscale", ws.ptr(dscale)),
-                    setattr(fd, "dpooled", ws.ptr(dpooled)), setattr(fd, "ws", ws.ptr(fcws))))
+                # the data half (dpooled) stays on the chain to dx; the parameter half is a command of its own that the
+                # dependency scheduler places like a weight gradient (one call held the chain for three launches: 24 us on
+                # each of the 19 squeeze-excitation blocks of the MobileNetV3 cfg).  DYK_SE_SPLIT=0: one command, as before
+                split = os.environ.get("DYK_SE_SPLIT", "1") != "0"
+                fg = L.DykSeFcDesc() if split else fd
+                if split:
+                    plan._keep.append(fg)
+                    fg.w1, fg.b1, fg.w2, fg.b2, fg.B, fg.C, fg.Cs = fd.w1, fd.b1, fd.w2, fd.b2, B, C, Cs
+                fg.dw1, fg.db1 = store.g_ptr(pre + "fc1.weight"), store.g_ptr(pre + "fc1.bias")
+                fg.dw2, fg.db2 = store.g_ptr(pre + "fc2.weight"), store.g_ptr(pre + "fc2.bias")
+
+                def se_ptrs(fd=fd, fg=fg, rec=rec, dscale=dscale, dpooled=dpooled, fcws=fcws):
+                    for q in {id(fd): fd, id(fg): fg}.values():
+                        q.pooled, q.dscale, q.ws = ws.ptr(rec["pooled"]), ws.ptr(dscale), ws.ptr(fcws)
+                    fd.dpooled = ws.ptr(dpooled)
+                later(se_ptrs)
                 plan.bwd.append((L.OP_SE_FC_BWD, fd))
+                if split:
+                    plan.bwd.append((L.OP_SE_FC_BWD, fg))
                 gx = gref(x_in)
                 sd = ew_desc(a=dz, out=gx, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W, alpha=1.0 / (x_in.H * x_in.W), flags=acc_flag(x_in))
                 later(lambda sd=sd, rec=rec, dpooled=dpooled: (setattr(sd, "p0", ws.ptr(rec["scale"])), setattr(sd, "p1", ws.ptr(dpooled))))

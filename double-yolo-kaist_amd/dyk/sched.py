@@ -231,10 +231,13 @@ def accesses(op, d, mem, plan):
     elif op == L.OP_SE_FC_FWD:
         rd(V(d.pooled)); wr(V(d.scale)); wr(V(d.ws))
     elif op == L.OP_SE_FC_BWD:
-        rd(V(d.pooled)); rd(V(d.dscale))
-        wr(V(d.dpooled)); wr(V(d.ws))
-        for p, n in ((d.dw1, d.Cs * d.C), (d.db1, d.Cs), (d.dw2, d.C * d.Cs), (d.db2, d.C)):
-            wr(mem.interval(_v(p), n * 4))
+        rd(V(d.dscale))
+        if _v(d.dpooled):                   # data half: dt1 -> ws, dpooled
+            wr(V(d.dpooled)); wr(V(d.ws))
+        if _v(d.dw1):                       # parameter half: reads h / dt1 / t2 (ws) and the pooled activations
+            rd(V(d.pooled)); rd(V(d.ws))
+            for p, n in ((d.dw1, d.Cs * d.C), (d.db1, d.Cs), (d.dw2, d.C * d.Cs), (d.db2, d.C)):
+                wr(mem.interval(_v(p), n * 4))
     elif op == L.OP_BN_FOLD:
         wr(V(d.p[4])); wr(V(d.p[5]))
     elif op == L.OP_WFUSE_WEIGHTS:

@@ -347,7 +347,11 @@ int dyk_maxpool_bwd(const DykEwDesc* desc, const uint8_t* argmax, void* stream);
  *                   dyk_se_fc_fwd on the same `ws` (it reads the h and t2 the forward call parked; nothing is
  *                   recomputed).  Three launches: dt1 = relu'(h) * W2^T (dscale * hardsigmoid'(t2)) -> ws,
  *                   dpooled = W1^T dt1, then one thread per weight element sums its outer products over the
- *                   batch -- no atomics on the weight gradients, every sum in a fixed order. */
+ *                   batch -- no atomics on the weight gradients, every sum in a fixed order.
+ *                   dyk_se_fc_bwd may be called in two halves: with dw1 = db1 = dw2 = db2 = NULL it computes dpooled
+ *                   (and dt1 into ws) only; with dpooled = NULL only the parameter gradients, from what the first
+ *                   half left in ws -- the parameter half is not on the path to dx (dyk/plan.py issues it as its own
+ *                   command so that the dependency scheduler can move it off the backward chain). */
 typedef struct DykSeFcDesc {
     const float* pooled;   /* [B][C] */
     const float* w1;       /* [Cs][C]  fc1.weight */
