@@ -311,6 +311,28 @@ def test_squeeze_excitation_fwd_bwd(dtype, B, C, Cs, H, W):
     dx = torch.empty_like(xd)
     ops.call("dyk_se_scale", ops.ew_desc(a=dzd, out=dx, p0=scale, p1=dpooled, alpha=1.0 / (H * W), B=B, H=H, W=W))
     _close(ops.to_nchw(dx).cpu(), xr.grad, tol, "se dx")
+    # the two halves as separate calls (how the plan issues them: dpooled on the chain to dx, the parameter gradients as a
+    # command of their own) give the same bits as the one call
+    def clone(src):
+        out = type(src)()
+        ctypes.memmove(ctypes.byref(out), ctypes.byref(src), ctypes.sizeof(src))
+        return out
+    dpooled2 = torch.zeros_like(dpooled)
+    grads2 = [torch.zeros_like(t) for t in prm]
+    half = clone(fd)
+    half.dpooled = dpooled2.data_ptr()
+    half.dw1 = half.db1 = half.dw2 = half.db2 = None
+    ops.call("dyk_se_fc_bwd", half)
+    assert torch.equal(dpooled2, dpooled) and all(float(t.abs().max()) == 0.0 for t in grads2)
+    half = clone(fd)
+    half.dpooled = None
+    half.dw1, half.db1, half.dw2, half.db2 = (t.data_ptr() for t in grads2)
+    ops.call("dyk_se_fc_bwd", half)
+    for a, b2_ in zip(grads2, grads):
+        assert torch.equal(a, b2_)
+    from dyk import lib as L
+    half.dw2 = None                                           # three of four gradient pointers: refused
+    assert L.load().dyk_se_fc_bwd(ctypes.byref(half), None) == -1          # DYK_ERR_ARG
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
