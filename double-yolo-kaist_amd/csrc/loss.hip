@@ -187,6 +187,19 @@ __global__ __launch_bounds__(256) void match_loss_kernel(DykLossDesc d, DykTarge
     const int nv = nvalid;
     if (nv == 0) return;
     const float inv_n = 1.f / (float)nv;
+    // cell of every match in LDS (when they fit): the "last match of a cell wins" scan below then compares one LDS word per
+    // candidate instead of four 8-byte global loads (400 matches on a head: 75 -> 25 us, on the path from the forward to the
+    // backward pass); -1 = out of range, never equal to a valid cell
+    constexpr int KEYS = 4096;
+    __shared__ long keys[KEYS];
+    const bool keyed = n <= KEYS;
+    if (keyed) {
+        for (int m = threadIdx.x; m < n; m += blockDim.x) {
+            const long b = ib[m], a = ib[cap + m], gj = ib[2 * cap + m], gi = ib[3 * cap + m];
+            keys[m] = (b >= 0 && b < d.B && gj >= 0 && gj < ny && gi >= 0 && gi < nx) ? ((b * na + a) * ny + gj) * nx + gi : -1;
+        }
+        __syncthreads();
+    }
     float sbox = 0.f, scls = 0.f;
     for (int m = threadIdx.x; m < n; m += blockDim.x) {
         const long b = ib[m], a = ib[cap + m], gj = ib[2 * cap + m], gi = ib[3 * cap + m];
@@ -220,8 +233,13 @@ __global__ __launch_bounds__(256) void match_loss_kernel(DykLossDesc d, DykTarge
         for (int k = 0; k < 4; ++k) atomicAdd(g + k, -d.hyp_box * inv_n * iou.d[k] * dpdt[k]);
         // objectness target: last match in (anchor-major, target) order wins for a shared cell (:271)
         bool last = true;
-        for (int q = m + 1; q < n; ++q)
-            if (ib[q] == b && ib[cap + q] == a && ib[2 * cap + q] == gj && ib[3 * cap + q] == gi) { last = false; break; }
+        if (keyed) {
+            for (int q = m + 1; q < n; ++q)
+                if (keys[q] == cell) { last = false; break; }
+        } else {
+            for (int q = m + 1; q < n; ++q)
+                if (ib[q] == b && ib[cap + q] == a && ib[2 * cap + q] == gj && ib[3 * cap + q] == gi) { last = false; break; }
+        }
         if (last) tobj[cell] = (1.f - d.gr) + d.gr * fmaxf(iou.v, 0.f);
         if (nc > 1) {                                                        // class BCE  :274-277
             const long cls = tc[m];
