@@ -313,7 +313,20 @@ def main():
     host_tl = bool(os.environ.get("DYK_HOST_TIMELINE"))
     float_input = bool(os.environ.get("DYK_BENCH_FLOAT_INPUT"))     # analysis: when does the host return from each phase
 
+    phase_ev = [] if os.environ.get("DYK_PHASE_EVENTS") else None   # analysis: GPU-side span of each phase (events, no host sync)
+
+    def mark(row):
+        if row is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            row.append(e)
+
     def step():
+        row = None
+        if phase_ev is not None:
+            row = []
+            phase_ev.append(row)
+            mark(row)
         alpha = min(it[0] / 1000.0, 1.0)
         opt.param_groups[0]["lr"] = hyp["lr0"] * (0.001 * (1 - alpha) + alpha)
         it[0] += 1
@@ -324,17 +337,21 @@ def main():
             pred = model(v8.float() / 255.0, l8.float() / 255.0)
         else:
             pred = model(v8, l8)
+        mark(row)
         if host_tl: tl.append(time.perf_counter())
         ld = compute_loss(pred, targets, model)
         loss = ld["box_loss"] + ld["obj_loss"] + ld["class_loss"]
+        mark(row)
         if host_tl: tl.append(time.perf_counter())
         if reducer is not None:
             reduce_dict(ld)                          # the harness's per-step loss exchange (kaist_train_eval_utils.py:82)
         loss.backward()
+        mark(row)
         if host_tl: tl.append(time.perf_counter())
         if reducer is not None:
             reducer.all_reduce(optimizer=opt)        # step() updates each bucket's range behind its own all-reduce (dyk/ddp.py)
         opt.step()
+        mark(row)
         if host_tl:
             tl.append(time.perf_counter())
             torch.cuda.synchronize()
@@ -361,6 +378,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.time() - t0
+    if phase_ev:
+        rows = [r for r in phase_ev[-args.steps:] if len(r) == 5]
+        spans = [sum(r[k].elapsed_time(r[k + 1]) for r in rows) / len(rows) for k in range(4)]
+        print("GPU phase spans ms (stream-ordered events, mean of %d steps): forward %.3f | loss %.3f | backward %.3f | optimizer %.3f"
+              % ((len(rows),) + tuple(spans)), file=sys.stderr)
     rccl_ranks = None
     if dist is not None:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
