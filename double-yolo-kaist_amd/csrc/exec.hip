@@ -578,7 +578,25 @@ int sched_validate(const DykSchedEntry* sched, int32_t n, int32_t n_streams) {
     return DYK_OK;
 }
 constexpr int DYK_MAX_DEVICES = 16;
+SchedRuntime& sched_runtime(int dev) {
+    static SchedRuntime rts[DYK_MAX_DEVICES];
+    return rts[dev];
+}
 }  // namespace
+
+// Library stream `idx` (1 .. 7) of the current device's schedule runtime, created on first use: host code that has work of
+// its own for a side stream (dyk/optim.py: the early part of the fused optimizer step, the rebuild of the transposed weight
+// packs) runs it on one of THESE instead of creating another stream -- the HIP runtime multiplexes all streams of a process
+// onto four hardware queues, and a fifth stream shares a queue with whichever stream the runtime picks.
+extern "C" int dyk_sched_stream(int32_t idx, void** stream_out) {
+    if (idx < 1 || idx > 7 || !stream_out) return DYK_ERR_ARG;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DYK_MAX_DEVICES) return DYK_ERR_HIP;
+    SchedRuntime& rt = sched_runtime(dev);
+    if (!rt.aux[0][idx] && hipStreamCreateWithPriority(&rt.aux[0][idx], hipStreamNonBlocking, 0) != hipSuccess) return DYK_ERR_HIP;
+    *stream_out = (void*)rt.aux[0][idx];
+    return DYK_OK;
+}
 
 extern "C" int dyk_run_schedule(const DykCommand* cmds, const DykSchedEntry* sched, int32_t n, int32_t n_streams,
                                 int32_t low_priority_last, void* stream, int32_t* failed_index) {
@@ -588,8 +606,7 @@ extern "C" int dyk_run_schedule(const DykCommand* cmds, const DykSchedEntry* sch
     // model from cuda:0 to cuda:1) gets a runtime per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DYK_MAX_DEVICES) return DYK_ERR_HIP;
-    static SchedRuntime rts[DYK_MAX_DEVICES];
-    SchedRuntime& rt = rts[dev];
+    SchedRuntime& rt = sched_runtime(dev);
     // DYK_ISSUE_THREADS=0: everything is issued by the calling thread (one launch at a time)
     static const bool threaded = !(getenv("DYK_ISSUE_THREADS") && getenv("DYK_ISSUE_THREADS")[0] == '0');
     int rc;

@@ -220,6 +220,7 @@ SIGNATURES = {
     "dyk_run_commands": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
     "dyk_run_command_pair": (_i32, [_P(DykCommand), _P(DykCommand), _vp]),
     "dyk_run_schedule_timed": (_i32, [_P(DykCommand), _P(DykSchedEntry), _i32, _vp, _P(_f32)]),
+    "dyk_sched_stream": (_i32, [_i32, _P(_vp)]),
     "dyk_run_commands_overlap": (_i32, [_P(DykCommand), _i32, _vp, _P(_i32)]),
     "dyk_run_schedule": (_i32, [_P(DykCommand), _P(DykSchedEntry), _i32, _i32, _i32, _vp, _P(_i32)]),
     "dyk_dag_graph_create": (_i32, [_P(DykCommand), _i32, _P(_i32), _P(_i32), _P(_vp), _P(_i32)]),

@@ -101,7 +101,18 @@ class _FusedBase(torch.optim.Optimizer):
             return
         n = d.n
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            # library stream 3 of the schedule runtime (dyk_sched_stream), not a fifth stream: the HIP runtime maps all streams
+            # of the process onto four hardware queues and a fifth one shares a queue with whichever stream the runtime picks
+            # (in-call, round 4: 28.39 / 28.47 ms with a stream of its own, 28.19 / 28.31 on library stream 3, 28.39 / 28.32 on 2,
+            # 28.60 / 28.47 on 1 -- stream 1 carries the second backbone).  DYK_OPT_SIDE_AUX=0: a torch stream of its own
+            import os
+            k = int(os.environ.get("DYK_OPT_SIDE_AUX", "3"))
+            if k > 0:
+                h = ctypes.c_void_p()
+                check(load().dyk_sched_stream(k, ctypes.byref(h)), "dyk_sched_stream")
+                self._side = torch.cuda.ExternalStream(h.value)
+            else:
+                self._side = torch.cuda.Stream()
         side = self._side
 
         def sub(off, cnt):

@@ -765,6 +765,10 @@ int dyk_run_commands_timed(const DykCommand* cmds, int32_t n, void* stream, floa
  * are in the step): ms_out[k] = duration of entry k. */
 int dyk_run_schedule_timed(const DykCommand* cmds, const DykSchedEntry* sched, int32_t n_entries, void* stream,
                            float* ms_out_host);
+/* Library stream idx (1..7) of the current device's schedule runtime (the streams dyk_run_schedule replays on; created on
+ * first use).  For host code with side-stream work of its own: the HIP runtime maps all streams of a process onto four
+ * hardware queues, so such work goes onto one of these rather than onto a fifth stream. */
+int dyk_sched_stream(int32_t idx, void** stream_out);
 
 #ifdef __cplusplus
 }
