@@ -1,7 +1,10 @@
-// ABI version and error strings.
+// ABI version, build digest and error strings.
 #include "dyk_common.h"
+#include "build_sha.h"
 
 extern "C" int dyk_abi_version(void) { return DYK_ABI_VERSION; }
+
+extern "C" const char* dyk_build_sha(void) { return DYK_BUILD_SHA; }
 
 extern "C" const char* dyk_error_string(int code) {
     switch (code) {

@@ -1456,14 +1456,13 @@ int launch_conv_halo(const DykConvDesc* d, hipStream_t stream) {
     }
     const size_t body = ring + hsrc > stage_c ? ring + hsrc : stage_c;
     const size_t lds = halo_table_bytes<BM, TH>() + body;
-    static bool attr_set = false;
+    static DykDeviceOnce attr_set;   // (the attribute is per DEVICE: one flag per device id)
     auto kfn = conv_halo_kernel<T, BM, TH, BKB, EPIK>;
-    if (!attr_set) {
+    if (attr_set.first()) {
         constexpr size_t sc_max = (size_t)BN * (BM * 4 + 16) > bnbwd_sliced_bytes<T, BM, WaveGrid<BM, BN>::WN>(true)
                                       ? (size_t)BN * (BM * 4 + 16) : bnbwd_sliced_bytes<T, BM, WaveGrid<BM, BN>::WN>(true);
         constexpr size_t lds_max = halo_table_bytes<BM, TH>() + (ring + hsrc > sc_max ? ring + hsrc : sc_max);
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-        attr_set = true;
     }
     const int tiles_n = d->B * (d->Hi / TH) * (d->Wi / 20);
     const int tiles_m = dyk_div_up(d->Cout, BM);
@@ -1510,14 +1509,13 @@ int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
         if (need > stage_c) stage_c = need;
     }
     const size_t lds = TABLE_BYTES + (ring > stage_c ? ring : stage_c);
-    static bool attr_set = false;
+    static DykDeviceOnce attr_set;   // (the attribute is per DEVICE: one flag per device id)
     auto kfn = conv_igemm_kernel<T, BM, BN, BKB, PIPE, KG, EPIK>;
-    if (!attr_set) {
+    if (attr_set.first()) {
         constexpr size_t sc_max = (size_t)BN * (BM * 4 + 16) > bnbwd_sliced_bytes<T, BM, WaveGrid<BM, BN>::WN>(true)
                                       ? (size_t)BN * (BM * 4 + 16) : bnbwd_sliced_bytes<T, BM, WaveGrid<BM, BN>::WN>(true);
         constexpr size_t lds_max = TABLE_BYTES + (ring > sc_max ? ring : sc_max);
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-        attr_set = true;
     }
     const long Ntot = (long)d->B * d->Hg * d->Wg;
     const int tiles_n = dyk_div_up(Ntot, BN);

@@ -345,11 +345,10 @@ int launch_conv_lt(const DykConvDesc* d, hipStream_t stream) {
     size_t lds = ring > stage_c ? ring : stage_c;
     if (park > lds) lds = park;
     if (lds > 160 * 1024) return DYK_ERR_UNSUPPORTED;
-    static bool attr_set = false;
+    static DykDeviceOnce attr_set;   // (the attribute is per DEVICE: one flag per device id)
     auto kfn = conv_lt_kernel<WMn, WNn, KG, EPIK>;
-    if (!attr_set) {
+    if (attr_set.first()) {
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     const int tiles_n = d->B * (d->Hi / g.TH) * (d->Wi / g.TW);
     const int tiles_m = dyk_div_up(d->Cout, BM);

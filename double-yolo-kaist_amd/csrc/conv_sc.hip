@@ -297,11 +297,10 @@ bool sc_eligible(const DykConvDesc* d) {
 template <int NCLS, int K, int ACTB>
 int sc_launch(const ScArgs& g, hipStream_t stream) {
     using C = ScCfg<NCLS, K>;
-    static bool attr_set = false;
+    static DykDeviceOnce attr_set;   // (the attribute is per DEVICE: one flag per device id)
     auto kfn = conv_sc_kernel<NCLS, K, ACTB>;
-    if (!attr_set) {
+    if (attr_set.first()) {
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
-        attr_set = true;
     }
     int grid = 256 * (int)((160 * 1024) / C::LDS);   // as many workgroups per CU as the LDS holds (two for stride 2), persistent over the tiles
     if (grid > g.ntiles) grid = g.ntiles;

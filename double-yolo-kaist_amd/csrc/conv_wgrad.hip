@@ -420,11 +420,10 @@ int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream, int* query) {
     constexpr size_t park = KG > 1 ? (size_t)BM * BN * 4 : 0;
     constexpr size_t lds = ring > park ? ring : park;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
+    static DykDeviceOnce attr_set;   // (the attribute is per DEVICE: one flag per device id)
     auto kfn = conv_wgrad_kernel<T, BM, BN, PIPE, KG>;
-    if (!attr_set) {
+    if (attr_set.first()) {
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     const long Ntot = (long)d->B * d->Ho * d->Wo;
     const int tiles = dyk_div_up(d->Cout, BM) * dyk_div_up(d->Cin, BN) * d->ntaps;
@@ -670,11 +669,10 @@ int launch_wgrad_mt(const DykWgradDesc* d, hipStream_t stream, int* query) {
     constexpr int NI_B = ((HROWS + RPI_B - 1) / RPI_B + 3) / 4 * 4;
     constexpr size_t lds = 2 * ((size_t)(KW / 8) * 1024 + (size_t)NI_B * 1024);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
+    static DykDeviceOnce attr_set;   // (the attribute is per DEVICE: one flag per device id)
     auto kfn = conv_wgrad_mt_kernel<BN, SI, KW>;
-    if (!attr_set) {
+    if (attr_set.first()) {
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     const int tiles = dyk_div_up(d->Cout, 64) * dyk_div_up(d->Cin, BN);
     const int nseg = d->B * d->Ho * ((d->Wo + KW - 1) / KW);

@@ -362,11 +362,10 @@ bool rb_geometry(const DykWgradDesc* d, int KP, RbGeom* out) {
 template <int KKW, int NXW>
 int rb_launch(const DykWgradDesc* d, const RbGeom& g, hipStream_t stream, int* query) {
     using C = RbCfg<KKW, NXW>;
-    static bool attr_set = false;
+    static DykDeviceOnce attr_set;   // (the attribute is per DEVICE: one flag per device id)
     auto kfn = conv_wgrad_rb_kernel<KKW, NXW>;
-    if (!attr_set) {
+    if (attr_set.first()) {
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
-        attr_set = true;
     }
     const int tiles = dyk_div_up(d->Cout, RB_BM) * dyk_div_up(d->Cin, RB_BN);
     int splits = d->splits;

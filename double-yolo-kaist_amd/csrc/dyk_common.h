@@ -222,6 +222,22 @@ __device__ inline int xcd_remap(int bid, int nblk) {
 
 static inline int dyk_div_up(long a, long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE attribute and exec.hip serves several devices in one
+// process: a function-local `static DykDeviceOnce` answers "first launch of this instantiation on the CURRENT device?"
+// (a per-process bool left the second device at the default 64 KB cap)
+struct DykDeviceOnce {
+    unsigned long long seen[4] = {0, 0, 0, 0};           // 256 device ids
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return true;
+        unsigned long long& w = seen[(dev >> 6) & 3];
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (w & bit) return false;
+        w |= bit;
+        return true;
+    }
+};
+
 // Two-problem launches of the elementwise / BatchNorm kernels (DykEwDesc.twin, DykBnFinalizeDesc.twin): the kernel takes
 // both descriptors and blockIdx.z selects the problem.  fill_* return the number of problems (1 | 2), 0 when the twin
 // differs in a non-pointer field.

@@ -347,8 +347,11 @@ extern "C" int dyk_yolo_loss(const DykLossDesc* d, const DykTargetsDesc* t, void
         return DYK_ERR_ARG;
     if (!(d->fl_gamma >= 0.f) || (d->fl_gamma > 0.f && !(d->fl_alpha >= 0.f && d->fl_alpha <= 1.f))) return DYK_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    // dp / tobj / acc start from zero.  A caller that lays them out back to back (dp[0] | dp[1] | .. | tobj[0] | .. | acc: what
-    // dyk/detect.py allocates) gets ONE fill instead of 2 * nheads + 1
+    // dp / tobj / acc / flag start from zero.  A caller that lays them out back to back gets ONE fill instead of
+    // 2 * nheads + 2: either  acc (12 doubles) | flag | 4 spare bytes | dp[0] | dp[1] | .. | tobj[0] | ..  (what dyk/detect.py
+    // allocates: acc sits at the start of the allocation and is 8-byte aligned whatever the grid sizes are -- with B, ny and
+    // nx all odd the float count in front of a trailing acc is odd), or  dp[0] | .. | tobj[..] | acc | flag  when that
+    // offset happens to be 8-byte aligned.  Any other layout takes one fill per buffer, the flag word included.
     size_t ncells[3] = {0, 0, 0};
     bool contiguous = true;
     char* expect = (char*)d->dp[0];
@@ -362,17 +365,22 @@ extern "C" int dyk_yolo_loss(const DykLossDesc* d, const DykTargetsDesc* t, void
         contiguous = contiguous && (char*)d->tobj[h] == expect;
         expect += ncells[h] * sizeof(float);
     }
-    contiguous = contiguous && (char*)d->acc == expect;
-    if (contiguous) {
-        // (a flag word placed right behind acc is cleared with them; anywhere else the caller clears it)
-        const size_t tail = 12 * sizeof(double) + ((char*)d->flag == expect + 12 * sizeof(double) ? sizeof(int32_t) : 0);
-        DYK_HIP_TRY(hipMemsetAsync(d->dp[0], 0, (size_t)(expect - (char*)d->dp[0]) + tail, s));
+    const size_t acc_bytes = 12 * sizeof(double);
+    const bool head = contiguous && (char*)d->flag == (char*)d->acc + acc_bytes && (char*)d->dp[0] == (char*)d->flag + 8;
+    const bool tail = contiguous && (char*)d->acc == expect;
+    if (head) {
+        DYK_HIP_TRY(hipMemsetAsync(d->acc, 0, (size_t)(expect - (char*)d->acc), s));
+    } else if (tail) {
+        const bool flag_behind = (char*)d->flag == expect + acc_bytes;
+        DYK_HIP_TRY(hipMemsetAsync(d->dp[0], 0, (size_t)(expect - (char*)d->dp[0]) + acc_bytes + (flag_behind ? sizeof(int32_t) : 0), s));
+        if (!flag_behind) DYK_HIP_TRY(hipMemsetAsync(d->flag, 0, sizeof(int32_t), s));
     } else {
         for (int h = 0; h < d->nheads; ++h) {
             DYK_HIP_TRY(hipMemsetAsync(d->dp[h], 0, ncells[h] * d->no * sizeof(float), s));
             DYK_HIP_TRY(hipMemsetAsync(d->tobj[h], 0, ncells[h] * sizeof(float), s));
         }
-        DYK_HIP_TRY(hipMemsetAsync(d->acc, 0, 12 * sizeof(double), s));
+        DYK_HIP_TRY(hipMemsetAsync(d->acc, 0, acc_bytes, s));
+        DYK_HIP_TRY(hipMemsetAsync(d->flag, 0, sizeof(int32_t), s));
     }
     hipLaunchKernelGGL(build_targets_kernel, dim3(t->nheads), dim3(256), 0, s, *t);
     DYK_LAUNCH_CHECK();

@@ -87,21 +87,22 @@ class _LossFunction(torch.autograd.Function):
         ps = [pi.detach().float().contiguous() for pi in p]
         t, keep = _targets_desc([tuple(pi.shape) for pi in ps], targets.to(dev), model)
         d = L.DykLossDesc()
-        # ONE buffer for everything dyk_yolo_loss wants zeroed: dp of every head | tobj of every head | acc (12 doubles) | flag,
-        # back to back -- one fill launch instead of 2 * nheads + 2 (and the backward scales all heads' gradients in one launch)
+        # ONE buffer for everything dyk_yolo_loss wants zeroed: acc (12 doubles) | flag | 4 spare bytes | dp of every head |
+        # tobj of every head, back to back -- one fill launch instead of 2 * nheads + 2 (and the backward scales all heads'
+        # gradients in one launch).  acc leads: the allocation is 8-byte aligned whatever the grids are (441 * B * ny * nx
+        # floats of dp + tobj are an odd count when B, ny and nx are all odd -- batch 1 at 416 x 416 -- ADVICE r4)
         n_dp = [pi.numel() for pi in ps]
         n_to = [pi.numel() // pi.shape[4] for pi in ps]
-        flat = torch.empty(sum(n_dp) + sum(n_to) + 24 + 2, dtype=torch.float32, device=dev)
-        dps, tobjs, off = [], [], 0
+        flat = torch.empty(24 + 2 + sum(n_dp) + sum(n_to), dtype=torch.float32, device=dev)
+        acc = flat[0:24].view(torch.float64)
+        flag = flat[24:25].view(torch.int32)
+        dps, tobjs, off = [], [], 26
         for pi, n in zip(ps, n_dp):
             dps.append(flat[off:off + n].view(pi.shape))
             off += n
         for pi, n in zip(ps, n_to):
             tobjs.append(flat[off:off + n].view(pi.shape[:4]))
             off += n
-        assert off % 2 == 0, "acc must be 8-byte aligned"
-        acc = flat[off:off + 24].view(torch.float64)
-        flag = flat[off + 24:off + 25].view(torch.int32)
         for i, pi in enumerate(ps):
             d.p[i], d.dp[i], d.tobj[i] = pi.data_ptr(), dps[i].data_ptr(), tobjs[i].data_ptr()
         d.nheads, d.B, d.no = len(ps), ps[0].shape[0], ps[0].shape[4]
@@ -117,11 +118,11 @@ class _LossFunction(torch.autograd.Function):
         out = torch.empty(3, dtype=torch.float32, device=dev)
         d.acc, d.out, d.flag = acc.data_ptr(), out.data_ptr(), flag.data_ptr()
         lib = load()
-        # the fill of `flat` covers the flag word: 8 bytes behind the 12 doubles of acc
+        # (the one fill of `flat` covers acc and the flag word)
         rc = lib.dyk_yolo_loss(ctypes.byref(d), ctypes.byref(t), _stream())
         check(rc, "dyk_yolo_loss")
         ctx.dps = dps
-        ctx.dp_flat = flat[:sum(n_dp)]
+        ctx.dp_flat = flat[26:26 + sum(n_dp)]
         ctx.no = d.no
         ctx.set_materialize_grads(False)        # an unused loss term arrives as None (no zeros tensor: a fill launch)
         # bit 0: a target fell outside the grid (the reference raises IndexError there).  Copied to pinned host memory

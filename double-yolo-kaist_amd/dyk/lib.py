@@ -176,6 +176,7 @@ _P = ctypes.POINTER
 # name -> (restype, argtypes); tests/test_abi.py checks this table against include/dyk_hip.h.
 SIGNATURES = {
     "dyk_abi_version": (_i32, []),
+    "dyk_build_sha": (ctypes.c_char_p, []),
     "dyk_error_string": (ctypes.c_char_p, [_i32]),
     "dyk_conv_igemm": (_i32, [_P(DykConvDesc), _vp]),
     "dyk_conv_bnfwd_max_grid": (_i32, []),
@@ -271,6 +272,14 @@ def load(path=None):
         fn.argtypes = args
     if lib.dyk_abi_version() != ABI_VERSION:
         raise DykLibraryError("ABI version mismatch")
+    if path is None and "DYK_LIB" not in os.environ and os.environ.get("DYK_ALLOW_STALE_LIB", "0") == "0":
+        # the in-tree library must be the build of the in-tree sources (a variant library named by DYK_LIB / `path` is the
+        # caller's business: tools/ab.sh compares builds of different sources)
+        from .buildinfo import native_sha
+        built, tree = lib.dyk_build_sha().decode(), native_sha()
+        if built != tree:
+            raise DykLibraryError("%s was built from other sources (digest %s, tree %s): rebuild it with "
+                                  "`python -c 'import __graft_entry__ as g; g.build()'`" % (p, built, tree))
     _lib = lib
     return lib
 

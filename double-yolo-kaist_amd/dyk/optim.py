@@ -32,7 +32,9 @@ class _FusedBase(torch.optim.Optimizer):
         self._buckets = None
         self._fresh = True
         import os
-        if os.environ.get("DYK_OPT_OVERLAP", "1") != "0":
+        mode = os.environ.get("DYK_OPT_OVERLAP", "1")
+        self.early_start = mode == "early"
+        if mode != "0":
             from .ddp import GradAllReduce
             model.engine.opt_overlap = GradAllReduce(model, None, attach=False)
 
@@ -143,7 +145,18 @@ class _FusedBase(torch.optim.Optimizer):
             main.wait_event(done)
             return
         ev, lo = early
-        side.wait_event(ev)
+        if self.early_start:
+            # opt-in (DYK_OPT_OVERLAP=early / optimizer.early_start = True): the side stream waits for the event recorded in the
+            # MIDDLE of the backward pass only.  Anything the caller enqueued on its own stream between backward() and step() that
+            # touches gradients -- clip_grad_norm_, manual scaling, gradient-norm logging -- is NOT ordered against it (a clip
+            # would be ignored for G[lo:], a norm could read zeros).  For loops that call step() straight after backward().
+            side.wait_event(ev)
+        else:
+            # default: behind EVERYTHING the caller has enqueued so far: the two ranges still run side by side
+            # and the transposed packs are rebuilt beside the next forward
+            now = torch.cuda.Event()
+            now.record(main)
+            side.wait_event(now)
         check(fn(ctypes.byref(sub(lo, n - lo)), ctypes.c_void_p(side.cuda_stream)), name)
         done = torch.cuda.Event()
         done.record(side)

@@ -241,6 +241,14 @@ class ParamStore:
         if st is not None and st["version"] == ver and not force:
             return st
         lib = load()
+        if self.wt_ready is not None:
+            # a rebuild of the transposed packs may still be pending on the optimizer's side stream (load_state_dict / mark_dirty /
+            # a new dtype between step() and the next backward): this rebuild, on whichever stream, comes after it
+            torch.cuda.current_stream().wait_event(self.wt_ready)
+            if side is not None:
+                side.wait_event(self.wt_ready)
+            else:
+                self.wt_ready = None
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         code = L.DYK_BF16 if dtype == torch.bfloat16 else L.DYK_F32
         if st is None:

@@ -1475,7 +1475,85 @@ def _setup_wgrad_partials(plan, store, device, force_layers=()):
 
 _TUNE_MS = {}        # problem key -> measured duration (ms) of the chosen configuration
 _TUNE_CACHE = {}     # process-wide: the same problem always runs the same tile configuration (bit-reproducible
-                     # results across plans / model instances within a process)
+                     # results across plans / model instances within a process) -- and, through the file below, across processes
+_TUNE_FILE = {"path": None, "loaded": False}
+# environment switches (analysis knobs) that change a problem's candidate set, its ranking or the kernels behind a choice
+_TUNE_KNOBS = ("DYK_CONV_", "DYK_WGRAD_", "DYK_TUNE_", "DYK_BNFWD", "DYK_BNBWD", "DYK_EPI_", "DYK_TIGHT_ROWS", "DYK_RB_",
+               "DYK_SPLITK", "DYK_PW_", "DYK_DW_")
+
+
+def _tune_file_path(device=None):
+    """Where the autotuner's choices persist (tile choices fix the summation order of the bf16 path, so two
+    processes that tune separately may differ in the last bits).  One JSON file per (library source digest, device name) under
+    $DYK_TUNE_CACHE_DIR | $XDG_CACHE_HOME/dyk | ~/.cache/dyk; DYK_TUNE_CACHE=0 turns persistence off, DYK_TUNE_CACHE=<file>
+    names the file.  A changed kernel source changes the digest: stale choices are never applied to new kernels."""
+    knob = os.environ.get("DYK_TUNE_CACHE", "1")
+    if knob == "0":
+        return None
+    if knob not in ("1", ""):
+        return knob
+    base = os.environ.get("DYK_TUNE_CACHE_DIR") or os.path.join(
+        os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "dyk")
+    try:
+        sha = L.load().dyk_build_sha().decode()
+        name = torch.cuda.get_device_name(device if device is not None else torch.cuda.current_device())
+    except Exception:
+        return None
+    name = "".join(ch if ch.isalnum() else "_" for ch in name)
+    # environment switches that change what a key's candidates are / how they are ranked belong to the file's identity
+    knobs = "".join("%s=%s;" % (k, os.environ[k]) for k in sorted(os.environ) if k.startswith(_TUNE_KNOBS) and k not in (
+        "DYK_TUNE_CACHE", "DYK_TUNE_CACHE_DIR", "DYK_TUNE_VERBOSE"))
+    import hashlib
+    tag = hashlib.sha1(knobs.encode()).hexdigest()[:8] if knobs else "default"
+    return os.path.join(base, "tune_%s_%s_%s.json" % (sha, name, tag))
+
+
+def _tune_cache_load():
+    if _TUNE_FILE["loaded"]:
+        return
+    _TUNE_FILE["loaded"] = True
+    path = _TUNE_FILE["path"] = _tune_file_path()
+    if not path or not os.path.exists(path):
+        return
+    import json
+    try:
+        with open(path) as f:
+            data = json.load(f)
+    except (OSError, ValueError):
+        return
+    import ast
+    for k, (best, ms) in data.items():
+        key = ast.literal_eval(k)
+        if key not in _TUNE_CACHE:
+            _TUNE_CACHE[key] = tuple(best) if isinstance(best, list) else best
+            if ms is not None:
+                _TUNE_MS[key] = ms
+
+
+def _tune_cache_save():
+    path = _TUNE_FILE["path"]
+    if not path:
+        return
+    import json
+    data = {}
+    if os.path.exists(path):                   # merge: another process may have tuned other problems meanwhile (its choices win
+        try:                                   # for keys both hold -- the file is the authority once written)
+            with open(path) as f:
+                data = json.load(f)
+        except (OSError, ValueError):
+            data = {}
+    for key, best in _TUNE_CACHE.items():
+        data.setdefault(repr(key), [list(best) if isinstance(best, tuple) else best, _TUNE_MS.get(key)])
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "w") as f:
+            json.dump(data, f)
+        os.replace(tmp, path)
+    except OSError:
+        pass
+
+
 def _conv_candidates(d):
     """tile configurations of dyk_conv_igemm for one problem: K-step bytes | ring stages << 8 | pixel tile << 12
     (0 = 128, 1 = 80, 2 = 160 pixels, 3 / 4 = halo kernel 4x20 / 8x20; bf16 only) | channel tile << 24 (0 = by Cout, 2 = 64, 1 = 32)
@@ -1607,6 +1685,13 @@ def autotune(plan, cache=None):
     lib = L.load()
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     cache = cache if cache is not None else {}
+    if cache is _TUNE_CACHE:
+        _tune_cache_load()
+    n_known = len(cache)
+    store = getattr(plan, "store", None)
+    if store is not None and store.wt_ready is not None:
+        # data-gradient trials read the transposed packs: a rebuild pending on the optimizer's side stream comes first
+        torch.cuda.current_stream().wait_event(store.wt_ready)
     groups = {}
     scratch = [None]                      # partial planes of the weight-gradient trials
     for (op, d) in plan.fwd + plan.bwd:
@@ -1622,104 +1707,108 @@ def autotune(plan, cache=None):
         best = cache.get(key)
         if best is None:
             d = descs[0]
-            if key[0] == "c":
-                cands = _conv_candidates(d)
-                fn = lib.dyk_conv_igemm
-                bn_saved = None
-                if d.flags & L.EPI_BNFWD:
-                    # The trial launches run the REAL descriptor: every one of them would EMA-update the layer's running statistics
-                    # (from replica sums that keep accumulating across trials: k x the mean, variance clamped to 0) and rewrite its
-                    # saved mean / rstd.  Trials run without those outputs and on freshly zeroed replicas.
-                    bn_saved = (d.bn_running_mean, d.bn_running_var, d.bn_save_mean, d.bn_save_rstd)
-                    d.bn_running_mean = d.bn_running_var = d.bn_save_mean = d.bn_save_rstd = None
-                    # one-launch conv + BatchNorm: generic tiles whose launch fits the residency contract (the front end refuses the others)
-                    keep = []
-                    for c in cands:
-                        if (c >> 28) & 7 or ((c >> 12) & 0xf) in (3, 4):
-                            continue
-                        d.tune = c
-                        if lib.dyk_conv_grid(ctypes.byref(d)) <= BNFWD_MAX_GRID and fn(ctypes.byref(d), stream) == 0:
-                            keep.append(c)
-                    cands = keep
-                    assert cands, "no tile configuration fits the one-launch BatchNorm contract: %s" % (key,)
-                    plan.arenas["stats"].tensor.zero_()          # (the filter launches above left sums in the replicas)
-            else:
-                cands, fn = _WGRAD_CANDIDATES, lib.dyk_conv_wgrad
-                if os.environ.get("DYK_WGRAD_CANDS"):
-                    cands = [int(c, 0) for c in os.environ["DYK_WGRAD_CANDS"].split(",")]
-            planes_on = (key[0] == "w" and plan.training and os.environ.get("DYK_WGRAD_PARTIALS", "1") != "0"
-                         and not os.environ.get("DYK_WGRAD_TUNE_ATOMIC"))    # (analysis: the round-1 way)
-            if planes_on:
-                # Weight gradients are timed the way the step runs them: every K split stores its own partial plane
-                # (_setup_wgrad_partials below; the atomic form penalises exactly the many-split shapes the plane form is
-                # good at) plus the cost of folding that many planes (dyk_grad_reduce, ~2.7 TB/s).  The NUMBER of K splits
-                # is a tuning dimension too: the kernel's own count fills ~3 workgroups per CU, which on the deep layers
-                # (16x20 maps: 5 120 pixels) writes and re-reads several times the operand bytes as planes (512->512 3x3:
-                # 6 planes of 9.4 MB against 10.5 MB of operands) -- half / a quarter of the splits trade idle CUs for
-                # that traffic; one split means no plane at all (single writer, plain accumulation).
-                plane = d.ntaps * d.Cout * (d.lddw if d.lddw > 0 else d.Cin)
-                dev = torch.device("cuda", torch.cuda.current_device())
-                saved_dw = d.dw
-
-                def room(n):
-                    if scratch[0] is None or scratch[0].numel() < n:
-                        scratch[0] = None
-                        scratch[0] = torch.empty(n, dtype=torch.float32, device=dev)
-                    return scratch[0].data_ptr()
-
-                # Weight of the fold term.  2, not 1: the trial times the weight-gradient launch ALONE, in the step it shares the
-                # chip with three other streams and every plane byte is paid for at the shared rate -- in-call A/B of the whole step
-                # (round 3, C3): weight 0.5 / 1 / 1.5 / 2 / 2.5 / 3 / 4 -> 32.8 / 32.6 / 32.2 / 31.8 / 32.1 / 32.0 / 32.6 ms
-                fold_w = float(os.environ.get("DYK_WGRAD_FOLD_W", "2"))
-                def trial(c, o, reps=3):
-                    """time tile configuration c with o K splits (0 = the kernel's own count); None if c does not apply"""
-                    d.tune, d.part, d.part_stride, d.splits = c, None, 0, o
-                    n = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
-                    if n < 1:
-                        return None
-                    if n >= 2 and plane % 4 == 0:
-                        d.part, d.part_stride, d.splits = room(n * plane), plane, n
-                        t = _time_launch(fn, d, stream, reps) + fold_w * (n + 1) * plane * 4 / 2.7e9
-                    else:
-                        d.dw = room(plane)                         # (trial sums must not land in the gradient buffer)
-                        t = _time_launch(fn, d, stream, reps)
-                        d.dw = saved_dw
-                    return t
-
-                combos, times = [], []
-                for c in cands:
-                    d.tune, d.part, d.part_stride, d.splits = c, None, 0, 0
-                    auto = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
-                    if auto < 1:
-                        continue
-                    opts = {auto}
-                    if os.environ.get("DYK_WGRAD_TUNE_SPLITS", "1") != "0" and plane % 4 == 0:
-                        opts |= {max(1, auto // 2), max(1, auto // 4), max(1, auto // 8)}
-                    for o in sorted(opts, reverse=True):
-                        t = trial(c, 0 if o == auto else o)
-                        if t is not None:
-                            combos.append((c, 0 if o == auto else o))
-                            times.append(t)
-                if not combos:                     # no candidate applies to this problem: the kernel's defaults
-                    combos, times = [(0, 0)], [float("inf")]
+            bn_saved = None
+            try:
+                if key[0] == "c":
+                    cands = _conv_candidates(d)
+                    fn = lib.dyk_conv_igemm
+                    if d.flags & L.EPI_BNFWD:
+                        # The trial launches run the REAL descriptor: every one of them would EMA-update the layer's running statistics
+                        # (from replica sums that keep accumulating across trials: k x the mean, variance clamped to 0) and rewrite its
+                        # saved mean / rstd.  Trials run without those outputs and on freshly zeroed replicas.
+                        bn_saved = (d.bn_running_mean, d.bn_running_var, d.bn_save_mean, d.bn_save_rstd)
+                        d.bn_running_mean = d.bn_running_var = d.bn_save_mean = d.bn_save_rstd = None
+                        # one-launch conv + BatchNorm: generic tiles whose launch fits the residency contract (the front end refuses the others)
+                        keep = []
+                        for c in cands:
+                            if (c >> 28) & 7 or ((c >> 12) & 0xf) in (3, 4):
+                                continue
+                            d.tune = c
+                            if lib.dyk_conv_grid(ctypes.byref(d)) <= BNFWD_MAX_GRID and fn(ctypes.byref(d), stream) == 0:
+                                keep.append(c)
+                        cands = keep
+                        assert cands, "no tile configuration fits the one-launch BatchNorm contract: %s" % (key,)
+                        plan.arenas["stats"].tensor.zero_()          # (the filter launches above left sums in the replicas)
                 else:
-                    times = _refine(combos, times, lambda cc, reps: trial(cc[0], cc[1], reps))
-                    if os.environ.get("DYK_TUNE_VERBOSE"):
-                        print("tune", key, " ".join("%#x/%d:%.1f" % (c[0], c[1], 1e3 * t) for t, c in sorted(zip(times, combos))[:10]), flush=True)
-                d.part, d.part_stride, d.splits, d.dw = None, 0, 0, saved_dw
-                best = combos[times.index(min(times))]
-            else:
-                def trial_c(c, reps=3):
-                    d.tune = c
-                    if bn_saved is not None:
-                        plan.arenas["stats"].tensor.zero_()
-                    return _time_launch(fn, d, stream, reps)
-                times = _refine(cands, [trial_c(c) for c in cands], trial_c)
-                best = cands[times.index(min(times))]
+                    cands, fn = _WGRAD_CANDIDATES, lib.dyk_conv_wgrad
+                    if os.environ.get("DYK_WGRAD_CANDS"):
+                        cands = [int(c, 0) for c in os.environ["DYK_WGRAD_CANDS"].split(",")]
+                planes_on = (key[0] == "w" and plan.training and os.environ.get("DYK_WGRAD_PARTIALS", "1") != "0"
+                             and not os.environ.get("DYK_WGRAD_TUNE_ATOMIC"))    # (analysis: the round-1 way)
+                if planes_on:
+                    # Weight gradients are timed the way the step runs them: every K split stores its own partial plane
+                    # (_setup_wgrad_partials below; the atomic form penalises exactly the many-split shapes the plane form is
+                    # good at) plus the cost of folding that many planes (dyk_grad_reduce, ~2.7 TB/s).  The NUMBER of K splits
+                    # is a tuning dimension too: the kernel's own count fills ~3 workgroups per CU, which on the deep layers
+                    # (16x20 maps: 5 120 pixels) writes and re-reads several times the operand bytes as planes (512->512 3x3:
+                    # 6 planes of 9.4 MB against 10.5 MB of operands) -- half / a quarter of the splits trade idle CUs for
+                    # that traffic; one split means no plane at all (single writer, plain accumulation).
+                    plane = d.ntaps * d.Cout * (d.lddw if d.lddw > 0 else d.Cin)
+                    dev = torch.device("cuda", torch.cuda.current_device())
+                    saved_dw = d.dw
+
+                    def room(n):
+                        if scratch[0] is None or scratch[0].numel() < n:
+                            scratch[0] = None
+                            scratch[0] = torch.empty(n, dtype=torch.float32, device=dev)
+                        return scratch[0].data_ptr()
+
+                    # Weight of the fold term.  2, not 1: the trial times the weight-gradient launch ALONE, in the step it shares the
+                    # chip with three other streams and every plane byte is paid for at the shared rate -- in-call A/B of the whole step
+                    # (round 3, C3): weight 0.5 / 1 / 1.5 / 2 / 2.5 / 3 / 4 -> 32.8 / 32.6 / 32.2 / 31.8 / 32.1 / 32.0 / 32.6 ms
+                    fold_w = float(os.environ.get("DYK_WGRAD_FOLD_W", "2"))
+                    def trial(c, o, reps=3):
+                        """time tile configuration c with o K splits (0 = the kernel's own count); None if c does not apply"""
+                        d.tune, d.part, d.part_stride, d.splits = c, None, 0, o
+                        n = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
+                        if n < 1:
+                            return None
+                        if n >= 2 and plane % 4 == 0:
+                            d.part, d.part_stride, d.splits = room(n * plane), plane, n
+                            t = _time_launch(fn, d, stream, reps) + fold_w * (n + 1) * plane * 4 / 2.7e9
+                        else:
+                            d.dw = room(plane)                         # (trial sums must not land in the gradient buffer)
+                            t = _time_launch(fn, d, stream, reps)
+                            d.dw = saved_dw
+                        return t
+
+                    combos, times = [], []
+                    for c in cands:
+                        d.tune, d.part, d.part_stride, d.splits = c, None, 0, 0
+                        auto = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
+                        if auto < 1:
+                            continue
+                        opts = {auto}
+                        if os.environ.get("DYK_WGRAD_TUNE_SPLITS", "1") != "0" and plane % 4 == 0:
+                            opts |= {max(1, auto // 2), max(1, auto // 4), max(1, auto // 8)}
+                        for o in sorted(opts, reverse=True):
+                            t = trial(c, 0 if o == auto else o)
+                            if t is not None:
+                                combos.append((c, 0 if o == auto else o))
+                                times.append(t)
+                    if not combos:                     # no candidate applies to this problem: the kernel's defaults
+                        combos, times = [(0, 0)], [float("inf")]
+                    else:
+                        times = _refine(combos, times, lambda cc, reps: trial(cc[0], cc[1], reps))
+                        if os.environ.get("DYK_TUNE_VERBOSE"):
+                            print("tune", key, " ".join("%#x/%d:%.1f" % (c[0], c[1], 1e3 * t) for t, c in sorted(zip(times, combos))[:10]), flush=True)
+                    d.part, d.part_stride, d.splits, d.dw = None, 0, 0, saved_dw
+                    best = combos[times.index(min(times))]
+                else:
+                    def trial_c(c, reps=3):
+                        d.tune = c
+                        if bn_saved is not None:
+                            plan.arenas["stats"].tensor.zero_()
+                        return _time_launch(fn, d, stream, reps)
+                    times = _refine(cands, [trial_c(c) for c in cands], trial_c)
+                    best = cands[times.index(min(times))]
+                    if os.environ.get("DYK_TUNE_VERBOSE"):   # analysis: every candidate's time, fastest first
+                        print("tune", key, " ".join("%#x:%.1f" % (c, 1e3 * t) for t, c in sorted(zip(times, cands))[:12]), flush=True)
+            finally:
+                # (also when a trial raises: a live descriptor without its running-statistics outputs would silently stop
+                # updating the BatchNorm running statistics -- ADVICE r4)
                 if bn_saved is not None:
                     d.bn_running_mean, d.bn_running_var, d.bn_save_mean, d.bn_save_rstd = bn_saved
-                if os.environ.get("DYK_TUNE_VERBOSE"):   # analysis: every candidate's time, fastest first
-                    print("tune", key, " ".join("%#x:%.1f" % (c, 1e3 * t) for t, c in sorted(zip(times, cands))[:12]), flush=True)
             cache[key] = best
             if min(times) != float("inf"):
                 _TUNE_MS[key] = min(times)
@@ -1733,6 +1822,8 @@ def autotune(plan, cache=None):
             if key in _TUNE_MS:
                 plan._cmd_us[ctypes.addressof(d)] = 1e3 * _TUNE_MS[key]      # measured duration: cost of the scheduler
     plan.tuned = dict(cache)
+    if cache is _TUNE_CACHE and len(cache) != n_known:
+        _tune_cache_save()
     # the trial launches polluted the statistics accumulators / scratch: reset
     plan.arenas["ws"].tensor.zero_()
     plan.arenas["grad"].tensor.zero_()

@@ -54,6 +54,9 @@ enum {
 };
 
 int dyk_abi_version(void);
+/* digest (16 hex digits) of the kernel sources, this header and the Makefile the library was built from
+ * (double-yolo-kaist_amd/dyk/buildinfo.py); the Python loader refuses a library whose digest differs from the tree's */
+const char* dyk_build_sha(void);
 const char* dyk_error_string(int code);
 
 /* ------------------------------------------------------------------------------------
@@ -602,9 +605,10 @@ typedef struct DykLossDesc {
     float fl_alpha;        /* FocalLoss alpha (utils.py:176 default 0.25; read only when fl_gamma > 0) */
     double* acc;           /* [12] scratch */
     float* out;            /* [3] */
-    int32_t* flag;         /* bit 0 is SET when a target falls outside the grid; the caller clears it -- except in the
-                              back-to-back layout dp[0] | dp[1] | .. | tobj[0] | .. | acc | flag, which dyk_yolo_loss recognises
-                              and zeroes with one fill (otherwise: one fill per dp / tobj buffer and one for acc) */
+    int32_t* flag;         /* bit 0 is SET when a target falls outside the grid; dyk_yolo_loss clears it first, like dp / tobj /
+                              acc.  Two back-to-back layouts get ONE fill for everything: acc | flag | 4 spare bytes | dp[0] |
+                              dp[1] | .. | tobj[0] | ..  (acc leads: 8-byte aligned for any grid) and dp[0] | .. | tobj[..] | acc
+                              | flag; any other layout takes one fill per buffer */
 } DykLossDesc;
 
 int dyk_build_targets(const DykTargetsDesc* desc, void* stream);
