@@ -43,6 +43,13 @@ static int conv_validate(const DykConvDesc* d) {
             ((uintptr_t)d->res % 16))
             return DYK_ERR_ARG;
     }
+    if (d->splitk > 1) {
+        // split-K across workgroups: private scratch + zeroed counters; one problem, one parity class, no in-launch BatchNorm
+        if (d->splitk > 16 || !d->sk_ws || !d->sk_cnt || ((uintptr_t)d->sk_ws % 16) || ((uintptr_t)d->sk_cnt % 4) || d->sk_cnt_n <= 0 ||
+            d->sk_ws_bytes <= 0)
+            return DYK_ERR_ARG;
+        if (d->twin || d->ncls > 1 || (d->flags & DYK_EPI_BNFWD)) return DYK_ERR_ARG;
+    }
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
     if (d->dtype != DYK_BF16 && d->dtype != DYK_F32) return DYK_ERR_ARG;
     if (d->ldx % epv || ((uintptr_t)d->x % 16) || ((uintptr_t)d->w % 16)) return DYK_ERR_ARG;
@@ -75,7 +82,7 @@ extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
         return dyk_conv_launch_n160(d, s);
     }
     if (tile == 6) {                       // resident-weight 3x3 data gradient into 32-channel tensors (conv_sc.hip)
-        const int rc = dyk_conv_launch_sc(d, s);
+        const int rc = d->splitk > 1 ? DYK_ERR_UNSUPPORTED : dyk_conv_launch_sc(d, s);
         if (rc != DYK_ERR_UNSUPPORTED || ((d->tune >> 23) & 1)) return rc;       // (bit 23, analysis: no fallback)
         return dyk_conv_launch_n128(d, s);
     }
@@ -106,4 +113,41 @@ extern "C" int dyk_conv_grid(const DykConvDesc* d) {
     if (bn == 80 && bm == 32) bm = 64;
     const long n = (long)d->B * d->Hg * d->Wg;
     return (int)((n + bn - 1) / bn) * ((d->Cout + bm - 1) / bm) * (d->ncls > 1 ? d->ncls : 1);
+}
+
+// split-K scratch: bytes of sk_ws and words of sk_cnt that hold for every kernel the tune word of `d` can select (the chosen
+// kernel AND the generic tile it falls back to): S * 4 bytes * (Cout rounded up to the channel tile) * (positions rounded up
+// to the pixel tile), tiles = their product counted in tiles
+extern "C" int64_t dyk_conv_splitk_ws_bytes(const DykConvDesc* d, int32_t* tiles) {
+    if (tiles) *tiles = 0;
+    if (!d || d->B <= 0 || d->Hg <= 0 || d->Wg <= 0 || d->Cout <= 0) return DYK_ERR_ARG;
+    if (d->splitk <= 1) return 0;
+    const long n = (long)d->B * d->Hg * d->Wg;
+    const int tile = d->dtype == DYK_BF16 ? (d->tune >> 12) & 0xf : 0;
+    int64_t bytes = 0;
+    int32_t nt = 0;
+    auto cover = [&](int bm, int bn) {
+        const int64_t tm = (d->Cout + bm - 1) / bm, tn = (n + bn - 1) / bn;
+        const int64_t b = tm * tn * (int64_t)d->splitk * bm * bn * 4;
+        if (b > bytes) bytes = b;
+        if (tm * tn > nt) nt = (int32_t)(tm * tn);
+    };
+    // generic tile (also the fallback of the large-tile / halo / resident-weight codes)
+    {
+        const int bn = (tile == 1 || tile == 3) ? 80 : ((tile == 2 || tile == 4 || tile == 5) ? 160 : 128);
+        int bm = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
+        const int bm_code = (d->tune >> 24) & 0xf;
+        if (tile != 5 && bm_code >= 1 && bm_code <= 3) bm = 16 << bm_code;
+        if (bn == 80 && bm == 32) bm = 64;
+        if (((d->tune >> 28) & 7) == 1 && bm < 64) bm = 64;
+        cover(bm, bn);
+    }
+    if (tile == 5) {
+        const int shape = (d->tune >> 8) & 0xf;
+        if (shape == 1) cover(128, 320);
+        else if (shape == 2) cover(256, 160);
+        else cover(128, 160);
+    }
+    if (tiles) *tiles = nt;
+    return bytes;
 }

@@ -868,6 +868,65 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& desc, f32x4_t (
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-K across workgroups (DykConvDesc.splitk): the hand-off between the S workgroups of one output tile.
+// Protocol = the counter form of cdna_hip_programming.md Guideline 16 R1 / section 5 "in-launch split-K reduction":
+//   every slice stores its accumulators into its slab WRITE-THROUGH (global_store ... sc1: no release fence, no L2 write-back),
+//   16 bytes per lane in accumulator order (a wave instruction writes 1 KiB contiguous) -> every wave drains vmcnt(0) ->
+//   workgroup barrier -> ONE lane takes a relaxed agent-scope ticket on the tile's counter -> the workgroup that draws S - 1
+//   is the reducer: it re-arms the counter (all S have arrived; the next launch is stream-ordered behind this one), ONE
+//   agent-scope acquire (drops this CU's stale L1 lines), barrier, then plain 16-byte loads of all S slabs IN SLICE ORDER --
+//   its own included, so the fp32 sum is the same whichever slice arrives last (bit-reproducible).  The others exit.
+// No workgroup waits for another one: correct for any dispatch order, residency and workgroup -> XCD placement.
+// Returns true in the reducer (acc = folded tile), false in the workgroups that are done.  NWV = waves holding accumulators
+// (all threads with tid < 64 * NWV call it; other waves of the workgroup must have exited), s_flag = one free LDS word.
+__device__ inline void st_wt16(void* p, const f32x4_t& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+template <int NWV, int MI, int NI>
+__device__ __forceinline__ bool splitk_exchange(f32x4_t (&acc)[MI][NI], const DykConvDesc& a, int tile, int slice, int S, int tid, int* s_flag) {
+    constexpr int PER = MI * NI * NWV * 64;                // 16-byte cells per slab (= BM * BN * 4 bytes)
+    const int lane = tid & 63, wid = tid >> 6;
+    f32x4_t* slab = (f32x4_t*)sgpr_ptr((char*)a.sk_ws) + (size_t)tile * S * PER;
+    f32x4_t* mine = slab + (size_t)slice * PER + wid * 64 + lane;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) st_wt16(mine + (mi * NI + ni) * NWV * 64, acc[mi][ni]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave (the asm stores are invisible to hipcc's counters)
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t* cnt = (uint32_t*)sgpr_ptr((char*)a.sk_cnt) + tile;
+        const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == (unsigned)(S - 1) ? 1 : 0;
+        if (last) {
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        *s_flag = last;
+    }
+    __syncthreads();
+    const int last = *s_flag;
+    __syncthreads();                                       // (the flag word goes back to the epilogue's scratch)
+    if (!last) return false;
+    const f32x4_t* src = slab + wid * 64 + lane;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < S; ++sl) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            f32x4_t v[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) v[ni] = src[(size_t)sl * PER + (mi * NI + ni) * NWV * 64];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += v[ni];
+        }
+    }
+    return true;
+}
+
 // PIPE: LDS-DMA ring stages (2 | 3 | 4 | 6)
 // KG:   K-groups per workgroup (1 | 2).  The deep layers (16x20 / 32x40 maps) have ~256 tiles of a long K loop: one
 //       4-wave workgroup per CU, every step's barrier / LDS / DMA latency exposed.  With KG = 2 a 512-thread workgroup
@@ -935,6 +994,11 @@ void conv_igemm_kernel(const ConvArgs args) {
     const int Ntot = a.B * HWg;
     const int tiles_n = (Ntot + BN - 1) / BN;
     int bid = xcd_remap(blk, nblk);
+    // split-K across workgroups: the S slices of an output tile have consecutive remapped ids (one XCD, dispatched together)
+    const int SK = a.splitk > 1 ? __builtin_amdgcn_readfirstlane(a.splitk) : 1;
+    int slice = 0;
+    if (SK > 1) { slice = bid % SK; bid /= SK; }
+    const int tile_id = bid;
     if (bid >= tiles_n * ((a.Cout + BM - 1) / BM) * (a.ncls > 1 ? a.ncls : 1)) return;    // padding blocks of a two-problem launch
     // output-parity classes of a strided data gradient in one launch: class fastest, so the classes of a pixel tile
     // run side by side on one XCD (shared gradient tile, interleaved output lines merge in its L2)
@@ -993,9 +1057,12 @@ void conv_igemm_kernel(const ConvArgs args) {
     const bool abl_nostore = (a.tune >> 16) & 1, abl_noloop = (a.tune >> 17) & 1;
     const bool abl_nobar = (a.tune >> 22) & 1;      // analysis: K loop without its workgroup barrier (WRONG results: timing only)
     // K-groups split the input-channel chunks; the step count of group 0 (the larger half) drives the common barriers
-    const int nchunks = a.Cin / BK;
-    const int c_begin = (KG > 1 && grp) ? (nchunks + 1) / 2 : 0;
-    const int c_end = (KG > 1 && !grp) ? (nchunks + 1) / 2 : nchunks;
+    const int nchunks_all = a.Cin / BK;
+    // this workgroup's share of the input-channel chunks (split-K slice), then the K-groups' halves of it
+    const int k_lo = SK > 1 ? (slice * nchunks_all) / SK : 0;
+    const int nchunks = SK > 1 ? ((slice + 1) * nchunks_all) / SK - k_lo : nchunks_all;
+    const int c_begin = k_lo + ((KG > 1 && grp) ? (nchunks + 1) / 2 : 0);
+    const int c_end = k_lo + ((KG > 1 && !grp) ? (nchunks + 1) / 2 : nchunks);
     const int S = abl_noloop ? 0 : (c_end - c_begin) * ntaps;
     const int Smax = abl_noloop ? 0 : (KG > 1 ? ((nchunks + 1) / 2) * ntaps : S);
     const int frow = lane & 15, fslot = lane >> 4;
@@ -1187,8 +1254,15 @@ void conv_igemm_kernel(const ConvArgs args) {
         __syncthreads();                                   // the epilogue's staging tile overlays the park area
     }
 
+    if constexpr (EPIK != 3) {
+        if (SK > 1) {
+            if (KG == 1) __syncthreads();                  // every wave is done with the operand ring (s_stat's first word is the flag)
+            if (!splitk_exchange<4, MI, NI>(acc, a, tile_id, slice, SK, tid, (int*)s_stat)) return;
+        }
+    }
     // ------------------------------------------------------------------ epilogue
-    conv_epilogue<T, BM, BN, EPIK>(a, acc, sC, s_stat, t_out, t_res, m0, blk, n0 == 0, (unsigned)nblk);
+    // (split-K: the statistics replica is chosen by the TILE, not by whichever slice's workgroup happened to arrive last)
+    conv_epilogue<T, BM, BN, EPIK>(a, acc, sC, s_stat, t_out, t_res, m0, SK > 1 ? tile_id : blk, n0 == 0, (unsigned)nblk);
 }
 
 // ======================================================================================
@@ -1423,6 +1497,8 @@ inline unsigned conv_fill_args(ConvArgs& args, const DykConvDesc* d, int tiles, 
     }
     return grid;
 }
+// split count of a launch (validated by the front end: no twin, one parity class, scratch present)
+inline int conv_splitk_of(const DykConvDesc* d) { return d->splitk > 1 ? d->splitk : 1; }
 // can the staged epilogue store 16-byte vectors for this problem?
 inline bool conv_vec_ok(const DykConvDesc* d, int eso, size_t elem) {
     bool vec = ((size_t)d->ldy * eso) % 16 == 0 && ((uintptr_t)d->y % 16) == 0;
@@ -1431,7 +1507,7 @@ inline bool conv_vec_ok(const DykConvDesc* d, int eso, size_t elem) {
 }
 
 inline bool conv_halo_eligible(const DykConvDesc* d, int TH) {
-    if (d->dtype != DYK_BF16 || d->ntaps != 9) return false;
+    if (d->dtype != DYK_BF16 || d->ntaps != 9 || d->splitk > 1) return false;      // (split-K: generic / large-tile kernels only)
     if (d->isy != 1 || d->isx != 1 || d->osy != 1 || d->osx != 1 || d->ooy != 0 || d->oox != 0) return false;
     if (d->Hg != d->Hi || d->Wg != d->Wi || d->Ho != d->Hi || d->Wo != d->Wi) return false;
     if (d->Wi % 20 || d->Hi % TH) return false;
@@ -1527,7 +1603,12 @@ int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     static int force_scatter = -1;
     if (force_scatter < 0) { const char* e = getenv("DYK_CONV_EPI"); force_scatter = (e && e[0] == 's') ? 1 : 0; }
     if (force_scatter) vec = false;
-    const unsigned grid = conv_fill_args(args, d, tiles_n * tiles_m * (d->ncls > 1 ? d->ncls : 1), vec);
+    const int sk = conv_splitk_of(d);
+    if (sk > 1) {
+        if constexpr (EPIK == 3) return DYK_ERR_UNSUPPORTED;
+        if (tiles_n * tiles_m > d->sk_cnt_n || (int64_t)tiles_n * tiles_m * sk * BM * BN * 4 > d->sk_ws_bytes) return DYK_ERR_ARG;
+    }
+    const unsigned grid = conv_fill_args(args, d, tiles_n * tiles_m * (d->ncls > 1 ? d->ncls : 1) * sk, vec);
     if constexpr (EPIK == 3) {
         // every workgroup must be resident while the launch waits on its arrival counter: bounded grid, vector epilogue, one problem
         if (grid > (unsigned)DYK_BNFWD_MAX_GRID || !vec || d->twin || d->ncls > 1 || lds > 80 * 1024) return DYK_ERR_UNSUPPORTED;

@@ -16,6 +16,6 @@ static int launch_kg(const DykConvDesc* d, hipStream_t s) {
 }
 
 int dyk_conv_launch_kg(const DykConvDesc* d, hipStream_t s) {
-    if (d->dtype != DYK_BF16 || (d->Cin * 2) % 128 || d->Cin / 64 < 2) return DYK_ERR_UNSUPPORTED;
+    if (d->dtype != DYK_BF16 || (d->Cin * 2) % 128 || d->Cin / 64 < 2 * conv_splitk_of(d)) return DYK_ERR_UNSUPPORTED;
     return (d->flags & DYK_EPI_BNBWD) ? launch_kg<1>(d, s) : launch_kg<0>(d, s);
 }

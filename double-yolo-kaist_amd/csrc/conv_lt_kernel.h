@@ -91,7 +91,12 @@ void conv_lt_kernel(const ConvArgs args, const int TH, const int TW) {
     const int tiles_x = Wi / TW, tiles_y = Hi / TH;
     const int tiles_n = a.B * tiles_y * tiles_x;
     const int blk = blockIdx.x;
-    const int bid = xcd_remap(blk, gridDim.x);
+    int bid = xcd_remap(blk, gridDim.x);
+    // split-K across workgroups (DykConvDesc.splitk): the S slices of a tile have consecutive remapped ids
+    const int SK = a.splitk > 1 ? __builtin_amdgcn_readfirstlane(a.splitk) : 1;
+    int slice = 0;
+    if (SK > 1) { slice = bid % SK; bid /= SK; }
+    const int tile_id = bid;
     const int m0 = (bid / tiles_n) * BM;
     int nt = bid % tiles_n;
     const int bimg = nt / (tiles_y * tiles_x);
@@ -141,10 +146,12 @@ void conv_lt_kernel(const ConvArgs args, const int TH, const int TW) {
     const T* __restrict__ wg = sgpr_ptr((const T*)a.w);
     const T* zero = (const T*)dyk_zero_page;
     // K-groups split the 32-channel chunks; the chunk count of group 0 (the largest share) drives the common barriers
-    const int nchunks = Cin >> 5;
+    const int nchunks_all = Cin >> 5;
+    const int k_lo = SK > 1 ? (slice * nchunks_all) / SK : 0;                 // this workgroup's share of the 32-channel chunks
+    const int nchunks = SK > 1 ? ((slice + 1) * nchunks_all) / SK - k_lo : nchunks_all;
     const int per = (nchunks + KG - 1) / KG;
-    const int c_begin = grp * per < nchunks ? grp * per : nchunks;
-    const int c_end = c_begin + per < nchunks ? c_begin + per : nchunks;
+    const int c_begin = k_lo + (grp * per < nchunks ? grp * per : nchunks);
+    const int c_end = c_begin + per < k_lo + nchunks ? c_begin + per : k_lo + nchunks;
     const int nch = ((a.tune >> 17) & 1) ? 0 : c_end - c_begin;      // chunks of this group (tune bit 17, analysis: no K loop)
     const int frow = lane & 15, fslot = lane >> 4;
 
@@ -297,7 +304,10 @@ void conv_lt_kernel(const ConvArgs args, const int TH, const int TW) {
         }
         if (grp != 0) return;                              // (ended waves no longer count at the barriers of the epilogue)
     }
-    conv_epilogue<T, BM, BN, EPIK, GT, WMn, WNn>(a, acc, sC, s_stat, t_out, t_res, m0, blk);
+    if (SK > 1) {
+        if (!splitk_exchange<GW, MI, NI>(acc, a, tile_id, slice, SK, tid, (int*)s_stat)) return;
+    }
+    conv_epilogue<T, BM, BN, EPIK, GT, WMn, WNn>(a, acc, sC, s_stat, t_out, t_res, m0, SK > 1 ? tile_id : blk);
 }
 
 // patch of BN pixels for an H x W map: TW | W, TH = BN / TW | H, halo loadable in LT_HSMAX steps by GW waves; `code` > 0 forces
@@ -332,7 +342,8 @@ int launch_conv_lt(const DykConvDesc* d, hipStream_t stream) {
     constexpr int BM = 64 * WMn, BN = 80 * WNn, GW = WMn * WNn;
     if (!conv_lt_eligible(d)) return DYK_ERR_UNSUPPORTED;
     if (!conv_vec_ok(d, 2, 2)) return DYK_ERR_UNSUPPORTED;           // staged 16-byte epilogue only
-    if (KG > 1 && (d->Cin / 32) < KG) return DYK_ERR_UNSUPPORTED;
+    const int sk = conv_splitk_of(d);
+    if ((d->Cin / 32) < KG * sk) return DYK_ERR_UNSUPPORTED;
     LtGeom g;
     if (!lt_pick_patch(d->Hi, d->Wi, BN, GW, (d->tune >> 24) & 0xf, g)) return DYK_ERR_UNSUPPORTED;
     const size_t ring = (size_t)lt_rings_off<BM, BN>() + (size_t)KG * (LT_NA * (size_t)BM * LT_ROWB + 2 * (size_t)g.NB * 1024);
@@ -353,7 +364,8 @@ int launch_conv_lt(const DykConvDesc* d, hipStream_t stream) {
     const int tiles_n = d->B * (d->Hi / g.TH) * (d->Wi / g.TW);
     const int tiles_m = dyk_div_up(d->Cout, BM);
     ConvArgs args;
-    const unsigned grid = conv_fill_args(args, d, tiles_n * tiles_m, true);
+    if (sk > 1 && (tiles_n * tiles_m > d->sk_cnt_n || (int64_t)tiles_n * tiles_m * sk * BM * BN * 4 > d->sk_ws_bytes)) return DYK_ERR_ARG;
+    const unsigned grid = conv_fill_args(args, d, tiles_n * tiles_m * sk, true);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, stream, args, g.TH, g.TW);
     DYK_LAUNCH_CHECK();
     return DYK_OK;

@@ -103,7 +103,7 @@ class Engine:
             budget = 0.5 * torch.cuda.get_device_properties(device).total_memory if device.type == "cuda" else float("inf")
 
         def nbytes(p):
-            return sum(a.size for a in p.arenas.values()) + (getattr(p, "part_bytes", 0) or 0)
+            return sum(a.size for a in p.arenas.values()) + (getattr(p, "part_bytes", 0) or 0) + (getattr(p, "sk_bytes", 0) or 0)
         keys = list(self.plans)
         total = sum(nbytes(self.plans[k]) for k in keys)
         while total > budget and len(keys) > 1:

@@ -54,6 +54,7 @@ class DykConvDesc(ctypes.Structure):
         ("act", _i32), ("flags", _i32), ("stats_slots", _i32),
         ("ldy2", _i32), ("bn_count", _i32), ("bn_momentum", _f32), ("bn_eps", _f32), ("tune", _i32),
         ("twin", _vp),
+        ("sk_ws", _vp), ("sk_cnt", _vp), ("sk_ws_bytes", _i64), ("sk_cnt_n", _i32), ("splitk", _i32),
     ]
 
 
@@ -181,6 +182,7 @@ SIGNATURES = {
     "dyk_conv_igemm": (_i32, [_P(DykConvDesc), _vp]),
     "dyk_conv_bnfwd_max_grid": (_i32, []),
     "dyk_conv_grid": (_i32, [_P(DykConvDesc)]),
+    "dyk_conv_splitk_ws_bytes": (_i64, [_P(DykConvDesc), _P(_i32)]),
     "dyk_conv_wgrad": (_i32, [_P(DykWgradDesc), _vp]),
     "dyk_conv_wgrad_splits": (_i32, [_P(DykWgradDesc)]),
     "dyk_conv_wgrad_variant": (_i32, [_P(DykWgradDesc)]),
@@ -246,7 +248,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 3          # = DYK_ABI_VERSION of include/dyk_hip.h: a stale .so with older descriptor layouts is refused
+ABI_VERSION = 4          # = DYK_ABI_VERSION of include/dyk_hip.h: a stale .so with older descriptor layouts is refused
 
 
 def load(path=None):

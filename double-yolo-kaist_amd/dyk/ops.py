@@ -160,9 +160,25 @@ def make_conv_desc(x, w, y, *, Hi, Wi, Cin, Cout, Hg, Wg, Ho, Wo, taps, isy=1, i
     return d
 
 
+def attach_splitk(d, S, device):
+    """split-K across workgroups for one launch of `d` (DykConvDesc.splitk, include/dyk_hip.h): slab scratch + zeroed tile
+    counters sized by dyk_conv_splitk_ws_bytes for d's tune word.  Returns the two tensors (keep them alive over the launch)."""
+    d.splitk = int(S)
+    nt = ctypes.c_int32(0)
+    need = int(load().dyk_conv_splitk_ws_bytes(ctypes.byref(d), ctypes.byref(nt)))
+    if need <= 0:
+        d.splitk = 0
+        return None
+    ws = torch.empty(need, dtype=torch.uint8, device=device)
+    cnt = torch.zeros(max(nt.value, 1), dtype=torch.int32, device=device)
+    d.sk_ws, d.sk_ws_bytes, d.sk_cnt, d.sk_cnt_n = ws.data_ptr(), need, cnt.data_ptr(), nt.value
+    return ws, cnt
+
+
 def conv2d_fwd(x, wp, k, stride, pad, Cout, *, act="linear", scale=None, shift=None, res=None, stats=None,
-               out=None, out_f32=False, tune=0, stats_slots=0):
-    """y = epilogue(conv(x, w)); x [B,Hi,Wi,Cin] channels-last, wp = pack_weight(w)."""
+               out=None, out_f32=False, tune=0, stats_slots=0, splitk=0, keep=None):
+    """y = epilogue(conv(x, w)); x [B,Hi,Wi,Cin] channels-last, wp = pack_weight(w).  splitk > 1: S workgroups per output
+    tile (`keep`: a list that receives the scratch tensors, for callers that look at the tile counters afterwards)."""
     _require_cuda(x, wp)
     B, Hi, Wi, Cin = x.shape
     Ho, Wo = conv_out_size(Hi, k, stride, pad), conv_out_size(Wi, k, stride, pad)
@@ -172,6 +188,9 @@ def conv2d_fwd(x, wp, k, stride, pad, Cout, *, act="linear", scale=None, shift=N
                        taps=fwd_taps(k, pad), isy=stride, isx=stride, act=act, scale=scale, shift=shift,
                        res=res, stats=stats, out_f32=out_f32)
     d.tune, d.stats_slots = tune, stats_slots
+    scratch = attach_splitk(d, splitk, x.device) if splitk > 1 else None
+    if keep is not None:
+        keep.append(scratch)
     check(load().dyk_conv_igemm(ctypes.byref(d), _stream()), "dyk_conv_igemm")
     return out
 

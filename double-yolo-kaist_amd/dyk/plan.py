@@ -1265,6 +1265,10 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         _fuse_late_reduces(plan, store)
     if not dry and os.environ.get("DYK_AUTOTUNE", "1") != "0":
         autotune(plan, _TUNE_CACHE)
+    plan.sk_ws = plan.sk_cnt = None
+    plan.sk_bytes = 0
+    if not dry:
+        _setup_splitk(plan, device)
     plan.part = None
     plan.bwd_cut_ok = None
     if training and not dry and os.environ.get("DYK_WGRAD_PARTIALS", "1") != "0":
@@ -1389,6 +1393,33 @@ def _fuse_late_reduces(plan, store):
     import bisect
     plan.bwd_marks = [(cnt - bisect.bisect_left(removed, cnt), layer) for cnt, layer in plan.bwd_marks]
     plan.late_fused = len(removed)
+
+
+def _setup_splitk(plan, device):
+    """scratch of the convolutions the tuner runs with split-K across workgroups (DykConvDesc.splitk > 1): one slab set and
+    one run of tile counters PER COMMAND (commands on different streams must not share them; the scheduler need not know these
+    blocks: nobody else touches them), carved from one allocation; counters start at zero and re-arm themselves"""
+    lib = L.load()
+    todo, nbytes, nwords = [], 0, 0
+    for op, d in plan.fwd + plan.bwd:
+        if op != L.OP_CONV or d.splitk <= 1:
+            continue
+        nt = ctypes.c_int32(0)
+        need = int(lib.dyk_conv_splitk_ws_bytes(ctypes.byref(d), ctypes.byref(nt)))
+        if need <= 0:
+            d.splitk = 0
+            continue
+        todo.append((d, nbytes, need, nwords, nt.value))
+        nbytes += _ru(need, 256)
+        nwords += _ru(nt.value, 64)
+    if not todo:
+        return
+    plan.sk_ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    plan.sk_cnt = torch.zeros(nwords, dtype=torch.int32, device=device)
+    plan.sk_bytes = nbytes + 4 * nwords
+    for d, off, need, woff, nt in todo:
+        d.sk_ws, d.sk_ws_bytes = plan.sk_ws.data_ptr() + off, need
+        d.sk_cnt, d.sk_cnt_n = plan.sk_cnt.data_ptr() + 4 * woff, nt
 
 
 def _setup_wgrad_partials(plan, store, device, force_layers=()):
@@ -1599,6 +1630,54 @@ def _conv_candidates(d):
     return out
 
 
+def _conv_split_candidates(d):
+    """(tile configuration, S) pairs of dyk_conv_igemm with split-K across workgroups (DykConvDesc.splitk, round 5): for the
+    problems whose output has too few tiles to fill 256 CUs with tiles large enough to feed the matrix cores -- the 32x40 /
+    16x20 stages (reference models.py:34-62 at strides 16 / 32).  The S slices of a tile fold through private fp32 slabs in
+    slice order (bit-reproducible).  Generic 128 / 64-row tiles of 160 / 128 / 80 pixels (2- and 3-stage rings, K-grouped form)
+    and, for 3x3 stride-1 problems, the 8-wave large-tile kernels."""
+    if os.environ.get("DYK_CONV_SPLITK", "1") == "0":
+        return []
+    if d.twin or d.ncls > 1 or d.flags & L.EPI_BNFWD:
+        return []
+    es = 2 if d.dtype == L.DYK_BF16 else 4
+    npix = d.B * d.Hg * d.Wg
+    max_s = int(os.environ.get("DYK_CONV_SPLITK_MAX", "8"))
+    out = []
+
+    def splits(tiles, kchunks):
+        # S so that tiles * S is about one to two workgroups per CU, every slice keeping >= 2 K chunks
+        return [s for s in (2, 3, 4, 6, 8) if s <= max_s and tiles * s <= 640 and tiles * (s - 1) < 512 and kchunks // s >= 2]
+    if (d.Cin * es) % 64:
+        return []
+    bkbs = [128] if (d.Cin * es) % 128 == 0 else [64]
+    tiles_px = [(2, 160), (0, 128), (1, 80)] if d.dtype == L.DYK_BF16 else [(0, 128)]
+    bms = [(0, 128 if d.Cout > 64 else (64 if d.Cout > 32 else 32))] + ([(2, 64)] if d.Cout > 64 else [])
+    for bkb in bkbs:
+        kch = (d.Cin * es) // bkb
+        for t, bn in tiles_px:
+            for bmc, bm in bms:
+                if t == 1 and bm < 64:
+                    continue
+                tiles = -(-npix // bn) * -(-d.Cout // bm)
+                for s in splits(tiles, kch):
+                    for pipe in (2, 3):
+                        out.append((bkb | (pipe << 8) | (t << 12) | (bmc << 24), s))
+                    if d.dtype == L.DYK_BF16 and bkb == 128 and t in (1, 2) and bm >= 64 and kch // s >= 4 and os.environ.get("DYK_CONV_KG", "1") != "0":
+                        out.append((128 | (2 << 8) | (t << 12) | (bmc << 24) | (1 << 28), s))
+    if (d.dtype == L.DYK_BF16 and d.ntaps == 9 and d.isy == 1 and d.osy == 1 and d.Hg == d.Hi and d.Wg == d.Wi
+            and d.Cin % 32 == 0 and d.Wi % 20 == 0 and not (d.flags & L.EPI_OUT_F32) and os.environ.get("DYK_CONV_LT", "1") != "0"):
+        for shape, (bm, bn, kg) in ((1, (128, 320, 1)), (2, (256, 160, 1)), (3, (128, 160, 2))):
+            if shape == 2 and d.Cout < 256:
+                continue
+            if npix % bn:
+                continue
+            tiles = (npix // bn) * -(-d.Cout // bm)
+            for s in splits(tiles, (d.Cin // 32) // kg):
+                out.append(((5 << 12) | (shape << 8), s))
+    return out
+
+
 WGRAD_EXCLUSIVE = 1 << 20      # the plan's weight gradients have one writer each (store.g_ptr per weight, commands ordered by
                                 # their write sets): a single-split row-block launch may read-add-write instead of atomics
 _WGRAD_CANDIDATES = [2, 3, 2 | (2 << 8), 2 | (1 << 24), 3 | (1 << 24), 2 | (2 << 8) | (1 << 24), 2 | (1 << 28)]
@@ -1694,6 +1773,7 @@ def autotune(plan, cache=None):
         torch.cuda.current_stream().wait_event(store.wt_ready)
     groups = {}
     scratch = [None]                      # partial planes of the weight-gradient trials
+    sk_scratch = [None, None]             # split-K slabs / tile counters of the convolution trials
     for (op, d) in plan.fwd + plan.bwd:
         if op == L.OP_CONV:
             key = ("c", d.dtype, d.B, d.Cin, d.Cout, d.Hg, d.Wg, d.ntaps, d.isy, d.osy,
@@ -1795,15 +1875,40 @@ def autotune(plan, cache=None):
                     d.part, d.part_stride, d.splits, d.dw = None, 0, 0, saved_dw
                     best = combos[times.index(min(times))]
                 else:
+                    sk_saved = (d.sk_ws, d.sk_cnt, d.sk_ws_bytes, d.sk_cnt_n, d.splitk)
+
                     def trial_c(c, reps=3):
-                        d.tune = c
+                        if isinstance(c, tuple):
+                            # split-K candidate: private scratch for the trial (slabs + zeroed tile counters)
+                            d.tune, d.splitk = c
+                            nt = ctypes.c_int32(0)
+                            need = int(lib.dyk_conv_splitk_ws_bytes(ctypes.byref(d), ctypes.byref(nt)))
+                            if need <= 0:
+                                return float("inf")
+                            dev = torch.device("cuda", torch.cuda.current_device())
+                            if sk_scratch[0] is None or sk_scratch[0].numel() < need:
+                                sk_scratch[0] = None
+                                sk_scratch[0] = torch.empty(need, dtype=torch.uint8, device=dev)
+                            if sk_scratch[1] is None or sk_scratch[1].numel() < nt.value:
+                                sk_scratch[1] = torch.zeros(max(nt.value, 4096), dtype=torch.int32, device=dev)
+                            d.sk_ws, d.sk_ws_bytes = sk_scratch[0].data_ptr(), need
+                            d.sk_cnt, d.sk_cnt_n = sk_scratch[1].data_ptr(), nt.value
+                            if fn(ctypes.byref(d), stream) != 0:       # (a shape the chosen kernel cannot split: not a candidate)
+                                return float("inf")
+                        else:
+                            d.tune, d.splitk = c, 0
                         if bn_saved is not None:
                             plan.arenas["stats"].tensor.zero_()
                         return _time_launch(fn, d, stream, reps)
-                    times = _refine(cands, [trial_c(c) for c in cands], trial_c)
+                    cands = list(cands) + _conv_split_candidates(d)
+                    try:
+                        times = _refine(cands, [trial_c(c) for c in cands], trial_c)
+                    finally:
+                        d.sk_ws, d.sk_cnt, d.sk_ws_bytes, d.sk_cnt_n, d.splitk = sk_saved
                     best = cands[times.index(min(times))]
                     if os.environ.get("DYK_TUNE_VERBOSE"):   # analysis: every candidate's time, fastest first
-                        print("tune", key, " ".join("%#x:%.1f" % (c, 1e3 * t) for t, c in sorted(zip(times, cands))[:12]), flush=True)
+                        print("tune", key, " ".join(("%#x/%d:%.1f" % (c[0], c[1], 1e3 * t)) if isinstance(c, tuple) else ("%#x:%.1f" % (c, 1e3 * t))
+                                                    for t, c in sorted(zip(times, cands), key=lambda tc: tc[0])[:12]), flush=True)
             finally:
                 # (also when a trial raises: a live descriptor without its running-statistics outputs would silently stop
                 # updating the BatchNorm running statistics -- ADVICE r4)
@@ -1813,7 +1918,9 @@ def autotune(plan, cache=None):
             if min(times) != float("inf"):
                 _TUNE_MS[key] = min(times)
         for d in descs:
-            if isinstance(best, tuple):
+            if isinstance(best, tuple) and key[0] == "c":
+                d.tune, d.splitk = best             # (tile configuration, split-K slices; scratch: _setup_splitk)
+            elif isinstance(best, tuple):
                 d.tune, d.splits = best             # (tile configuration, K splits: 0 = the kernel's own count)
             else:
                 d.tune = best

@@ -102,6 +102,8 @@ def pair_signature(op, d, plan):
     if op == L.OP_CONV:
         if d.flags & L.EPI_BNFWD:
             return None                     # a one-launch conv + BatchNorm waits on its own workgroups: single problem only
+        if d.splitk > 1:
+            return None                     # split-K across workgroups (private slabs and tile counters): single problem only
         if ((d.tune >> 12) & 0xf) == 6:
             return None                     # resident-weight data gradient (csrc/conv_sc.hip): single problem only -- as one half of a
                                             # two-problem launch it would fall back to the generic kernel, whose epilogue rounds differently

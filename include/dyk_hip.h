@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DYK_ABI_VERSION 3   /* 3: round 4, DykStemDesc fused BatchNorm-backward apply (bn_* fields); 2: round-3 descriptor layouts */
+#define DYK_ABI_VERSION 4   /* 4: round 5, DykConvDesc split-K fields (sk_ws .. splitk), dyk_build_sha; 3: round 4, DykStemDesc fused BatchNorm-backward apply (bn_* fields); 2: round-3 descriptor layouts */
 
 enum {
     DYK_OK = 0,
@@ -167,12 +167,31 @@ typedef struct DykConvDesc {
                                        the second problem follow those of the first.  For the shape-identical RGB / LWIR twin
                                        backbones of a dual-stream net (models.py:288,299-303): half the launches, twice the
                                        workgroups per launch on the deep stages.  The twin's own `twin` field is ignored. */
+    /* Split-K ACROSS workgroups (ABI 4).  The deep stages of the network (32x40 / 16x20 maps: 20 480 / 5 120 pixels at batch
+     * 16) have 64..256 output tiles of a K loop 1 000..18 000 long: tiles large enough to feed the matrix cores leave most
+     * CUs idle.  splitk = S >= 2 launches S workgroups per output tile, slice s walking the s-th share of the input-channel
+     * chunks; every slice parks its fp32 accumulators in its slab of `sk_ws` (write-through stores), takes a ticket on
+     * sk_cnt[tile], and the workgroup that draws the LAST ticket adds the S slabs in slice order -- the sum does not depend on
+     * which slice arrives last: bit-reproducible -- and runs the epilogue of `flags` on the folded tile (statistics,
+     * BatchNorm-backward reduce, ... unchanged).  No spinning: nothing depends on residency or dispatch order.
+     * sk_ws: 16-byte aligned scratch private to this descriptor, sk_ws_bytes >= dyk_conv_splitk_ws_bytes(desc);
+     * sk_cnt: sk_cnt_n >= number of output tiles 32-bit words, ZERO before the first launch (the last arriver re-arms its
+     * word).  splitk <= 1: off.  Not combinable with twin, ncls > 1 or DYK_EPI_BNFWD; generic tiles (incl. K-grouped) and
+     * the large-tile kernels carry it, the halo / resident-weight kernels fall back to their generic tile. */
+    void* sk_ws;
+    uint32_t* sk_cnt;
+    int64_t sk_ws_bytes;
+    int32_t sk_cnt_n;
+    int32_t splitk;
 } DykConvDesc;
 
 int dyk_conv_igemm(const DykConvDesc* desc, void* stream);
 /* largest launch (workgroups) DYK_EPI_BNFWD accepts, and the workgroups the launch of `desc` (with its tune word) would take */
 int dyk_conv_bnfwd_max_grid(void);
 int dyk_conv_grid(const DykConvDesc* desc);
+/* split-K scratch of `desc` (its tune word and splitk): bytes of sk_ws, and (via *tiles, may be NULL) the words of sk_cnt;
+ * upper bounds that hold for every kernel the tune word can select.  0 when splitk <= 1; negative error code on bad input */
+int64_t dyk_conv_splitk_ws_bytes(const DykConvDesc* desc, int32_t* tiles);
 
 /* ------------------------------------------------------------------------------------
  * Convolution weight gradient (split-K MFMA GEMM over output pixels, fp32 atomics):

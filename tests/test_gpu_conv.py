@@ -863,3 +863,166 @@ def test_large_tile_conv_kernels(case):
                 assert torch.allclose(st[0], r1, rtol=2e-3, atol=5e-2 * n ** 0.5), (hex(tune), flags)
                 assert torch.allclose(st[1], r2, rtol=2e-3, atol=5e-2 * n ** 0.5), (hex(tune), flags)
     assert ran_f >= 2 and ran_b >= 4, (ran_f, ran_b)
+
+
+SPLITK_CASES = [  # (B, Cin, Cout, H, W, k, dtype)
+    (2, 256, 128, 16, 20, 3, torch.bfloat16), (1, 512, 96, 8, 20, 1, torch.bfloat16), (2, 192, 256, 8, 20, 3, torch.bfloat16),
+    (1, 256, 64, 16, 40, 3, torch.bfloat16), (2, 128, 64, 8, 12, 1, torch.float32), (2, 256, 512, 8, 20, 1, torch.bfloat16),
+    (1, 128, 256, 8, 12, 3, torch.float32),
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=lambda c: "b%d_c%d_%d_%dx%d_k%d_%s" % (c[:6] + (str(c[6]).split(".")[-1],)))
+def test_conv_split_k_across_workgroups(case):
+    """DykConvDesc.splitk (round 5; deep stages of reference models.py:34-62): S workgroups per output tile, slices folded through
+    private fp32 slabs in slice order by whichever workgroup arrives last.  Every (tile configuration, S) the autotuner may
+    pick -- generic tiles, K-grouped tiles, the 8-wave large-tile kernels -- against torch CPU fp32 on the same rounded
+    operands: forward with statistics, forward with affine + activation + residual, data gradient with the fused
+    BatchNorm-backward epilogue (plain and residual chain); results bit-identical from launch to launch while another stream
+    keeps the chip busy (the sum must not depend on arrival order), tile counters back at zero."""
+    import ctypes
+    from dyk import lib as L
+    from dyk import ops
+    from dyk.plan import _conv_split_candidates
+    B, Cin, Cout, H, W, k, dtype = case
+    pad = k // 2
+    g = torch.Generator().manual_seed(11)
+
+    def rnd(*shape):
+        t = torch.randn(*shape, generator=g)
+        return t.bfloat16().float() if dtype == torch.bfloat16 else t
+    x = rnd(B, Cin, H, W)
+    w = rnd(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    w = w.bfloat16().float() if dtype == torch.bfloat16 else w
+    r = rnd(B, Cout, H, W)
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    y_ref = F.conv2d(x, w, padding=pad)
+    z_ref = F.leaky_relu(y_ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0.1) + r
+    xd, rd = ops.to_nhwc(x.cuda(), dtype), ops.to_nhwc(r.cuda(), dtype)
+    wp = ops.pack_weight(w.cuda(), dtype)
+    probe = ops.make_conv_desc(xd, wp, xd, Hi=H, Wi=W, Cin=Cin, Cout=Cout, Hg=H, Wg=W, Ho=H, Wo=W, taps=ops.fwd_taps(k, pad))
+    cands = _conv_split_candidates(probe)
+    assert len(cands) >= 2, cands
+    tol = 1.2e-2 if dtype == torch.bfloat16 else 2e-4
+    n = B * H * W
+    # a busy neighbour: copies on a second stream while the split launches run (uneven arrival order of the slices)
+    side = torch.cuda.Stream()
+    junk_a, junk_b = torch.empty(64 << 20, dtype=torch.uint8, device="cuda"), torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    ran = 0
+    for tune, S in cands:
+        with torch.cuda.stream(side):
+            for _ in range(8):
+                junk_b.copy_(junk_a)
+        first = None
+        for rep in range(3):
+            stats = torch.zeros(4, 2, Cout, dtype=torch.float64, device="cuda")
+            keep = []
+            try:
+                y = ops.conv2d_fwd(xd, wp, k, 1, pad, Cout, stats=stats, stats_slots=4, tune=tune | (1 << 23), splitk=S, keep=keep)
+            except L.DykError:
+                y = None                                  # (large-tile shape that does not fit this map / K too short for S slices)
+                break
+            assert int(keep[0][1].abs().max()) == 0, "tile counters not re-armed"
+            if first is None:
+                first = (y.clone(), stats.clone())
+            else:
+                assert torch.equal(y, first[0]) and torch.equal(stats, first[1]), (hex(tune), S, "not reproducible")
+        if y is None:
+            continue
+        ran += 1
+        err = (ops.to_nchw(y).cpu().float() - y_ref).abs().max().item()
+        assert err <= tol * max(1.0, y_ref.abs().max().item()), (hex(tune), S, err)
+        st = stats.sum(0).cpu()
+        assert torch.allclose(st[0], y_ref.double().sum((0, 2, 3)), rtol=1e-3, atol=2e-2 * n ** 0.5), (hex(tune), S)
+        assert torch.allclose(st[1], (y_ref.double() ** 2).sum((0, 2, 3)), rtol=2e-3, atol=1e-2), (hex(tune), S)
+        z = ops.conv2d_fwd(xd, wp, k, 1, pad, Cout, act="leaky", scale=scale.cuda(), shift=shift.cuda(), res=rd, tune=tune, splitk=S)
+        err = (ops.to_nchw(z).cpu().float() - z_ref).abs().max().item()
+        assert err <= 1.3 * tol * max(1.0, z_ref.abs().max().item()), (hex(tune), S, err)
+    assert ran >= max(2, len(cands) // 3), (ran, len(cands))
+    torch.cuda.synchronize()
+    # ---- data gradient of the same conv into a BatchNorm + Mish block (fused reduce), split the same ways
+    dy = rnd(B, Cout, H, W)
+    u = rnd(B, Cin, H, W)
+    gadd = rnd(B, Cin, H, W)
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    mean, var = u.mean((0, 2, 3)), u.var((0, 2, 3), unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    sc2, sh2 = gamma * rstd, beta - mean * gamma * rstd
+    xhat = (u - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1)
+    dz = torch.nn.grad.conv2d_input((B, Cin, H, W), w, dy, padding=pad)
+
+    def cast(t):
+        return t.bfloat16().float() if dtype == torch.bfloat16 else t
+
+    def bn_ref(dzv):
+        t = (u * sc2.view(1, -1, 1, 1) + sh2.view(1, -1, 1, 1)).requires_grad_(True)
+        F.mish(t).backward(dzv)
+        return t.grad, t.grad.double().sum((0, 2, 3)), (t.grad.double() * xhat.double()).sum((0, 2, 3))
+    da_ref, s1_ref, s2_ref = bn_ref(cast(dz))
+    dzc = cast(dz + gadd)
+    _, s1c, s2c = bn_ref(dzc)
+    dyd, ud, addd = (ops.to_nhwc(t.cuda(), dtype) for t in (dy, u, gadd))
+    wpt = ops.pack_weight(w.cuda(), dtype, transposed=True)
+    out = torch.empty((B, H, W, Cin), dtype=dtype, device="cuda")
+    red = torch.zeros(4, 2, Cin, dtype=torch.float64, device="cuda")
+    vec = [t.cuda().contiguous() for t in (sc2, sh2, mean, rstd)]
+    (py, px, Hg, Wg, taps), = ops.dgrad_classes(k, pad, 1, H, W)
+    d = ops.make_conv_desc(dyd, wpt, out, Hi=H, Wi=W, Cin=Cout, Cout=Cin, Hg=Hg, Wg=Wg, Ho=H, Wo=W, taps=taps, act="mish")
+    d.res, d.ldr = ud.data_ptr(), Cin
+    d.scale, d.shift, d.aux0, d.aux1 = (t.data_ptr() for t in vec)
+    d.stats, d.stats_slots, d.add = red.data_ptr(), 4, addd.data_ptr()
+    ran_b = 0
+    bcands = _conv_split_candidates(d)
+    for tune, S in bcands:
+        for flags, ref, r1, r2 in ((L.EPI_BNBWD, da_ref, s1_ref, s2_ref), (L.EPI_BNBWD | L.EPI_ADDEND, dzc, s1c, s2c)):
+            d.flags, d.tune = flags, tune | (1 << 23)
+            scratch = ops.attach_splitk(d, S, out.device)
+            red.zero_()
+            out.zero_()
+            rc = L.load().dyk_conv_igemm(ctypes.byref(d), None)
+            if rc == -3:
+                continue
+            assert rc == 0, (hex(tune), S, rc)
+            ran_b += 1
+            err = (ops.to_nchw(out).cpu().float() - ref).abs().max().item()
+            assert err <= 1.5 * tol * max(1.0, ref.abs().max().item()), (hex(tune), S, flags, err)
+            st = red.sum(0).cpu()
+            assert torch.allclose(st[0], r1, rtol=2e-3, atol=5e-2 * n ** 0.5), (hex(tune), S, flags)
+            assert torch.allclose(st[1], r2, rtol=2e-3, atol=5e-2 * n ** 0.5), (hex(tune), S, flags)
+            assert int(scratch[1].abs().max()) == 0
+    assert ran_b >= (8 if Cout >= 256 else min(2, len(bcands))), (ran_b, len(bcands))      # (K = Cout of the forward: short K, few ways to split)
+
+
+@pytest.mark.parametrize("case", [(16, 512, 512, 16, 20, 3), (16, 1024, 512, 16, 20, 1), (16, 256, 256, 32, 40, 3)])
+def test_split_k_conv_at_baseline_size(case):
+    """the deep-stage layers of the target cfg at BASELINE size (batch 16): every split-K candidate the tuner would time,
+    correct against torch CPU fp32 and bit-identical between two launches"""
+    from dyk import lib as L
+    from dyk import ops
+    from dyk.plan import _conv_split_candidates
+    B, Cin, Cout, H, W, k = case
+    pad = k // 2
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    y_ref = F.conv2d(x, w, padding=pad)
+    xd = ops.to_nhwc(x.cuda(), torch.bfloat16)
+    wp = ops.pack_weight(w.cuda(), torch.bfloat16)
+    probe = ops.make_conv_desc(xd, wp, xd, Hi=H, Wi=W, Cin=Cin, Cout=Cout, Hg=H, Wg=W, Ho=H, Wo=W, taps=ops.fwd_taps(k, pad))
+    cands = _conv_split_candidates(probe)
+    assert cands
+    ran = 0
+    for tune, S in cands:
+        stats = torch.zeros(4, 2, Cout, dtype=torch.float64, device="cuda")
+        try:
+            y = ops.conv2d_fwd(xd, wp, k, 1, pad, Cout, stats=stats, stats_slots=4, tune=tune | (1 << 23), splitk=S)
+        except L.DykError:
+            continue
+        ran += 1
+        stats2 = torch.zeros_like(stats)
+        y2 = ops.conv2d_fwd(xd, wp, k, 1, pad, Cout, stats=stats2, stats_slots=4, tune=tune | (1 << 23), splitk=S)
+        assert torch.equal(y, y2) and torch.equal(stats, stats2), (hex(tune), S)
+        err = (ops.to_nchw(y).cpu() - y_ref).abs().max().item()
+        assert err <= 1.2e-2 * max(1.0, y_ref.abs().max().item()), (hex(tune), S, err)
+    assert ran >= 4, ran
