@@ -11,6 +11,7 @@ int dyk_conv_launch_halo(const DykConvDesc* d, hipStream_t s, int th);
 int dyk_conv_launch_kg(const DykConvDesc* d, hipStream_t s);
 int dyk_conv_launch_lt(const DykConvDesc* d, hipStream_t s);
 int dyk_conv_launch_sc(const DykConvDesc* d, hipStream_t s);
+int dyk_conv_launch_pw(const DykConvDesc* d, hipStream_t s);
 
 static int conv_validate(const DykConvDesc* d) {
     if (!d || !d->x || !d->w || !d->y) return DYK_ERR_ARG;
@@ -83,6 +84,11 @@ extern "C" int dyk_conv_igemm(const DykConvDesc* d, void* stream) {
     }
     if (tile == 6) {                       // resident-weight 3x3 data gradient into 32-channel tensors (conv_sc.hip)
         const int rc = d->splitk > 1 ? DYK_ERR_UNSUPPORTED : dyk_conv_launch_sc(d, s);
+        if (rc != DYK_ERR_UNSUPPORTED || ((d->tune >> 23) & 1)) return rc;       // (bit 23, analysis: no fallback)
+        return dyk_conv_launch_n128(d, s);
+    }
+    if (tile == 7) {                       // persistent resident-weight pointwise kernels (conv_pw_kernel.h)
+        const int rc = dyk_conv_launch_pw(d, s);
         if (rc != DYK_ERR_UNSUPPORTED || ((d->tune >> 23) & 1)) return rc;       // (bit 23, analysis: no fallback)
         return dyk_conv_launch_n128(d, s);
     }

@@ -1585,6 +1585,20 @@ def _tune_cache_save():
         pass
 
 
+def pw_eligible(d):
+    """mirror of conv_pw_eligible (csrc/conv_pw_kernel.h): 1x1 / stride 1 / dense grid, bf16, K <= 256, plain | statistics |
+    BatchNorm-backward (| chain) epilogues, weights of one 128-row channel tile <= 64 KB"""
+    if d.dtype != L.DYK_BF16 or d.ntaps != 1 or d.tdy[0] or d.tdx[0] or d.ncls > 1 or d.twin or d.splitk > 1:
+        return False
+    if (d.isy, d.isx, d.osy, d.osx, d.ooy, d.oox) != (1, 1, 1, 1, 0, 0):
+        return False
+    if not (d.Hg == d.Hi == d.Ho and d.Wg == d.Wi == d.Wo):
+        return False
+    if d.flags not in (0, L.EPI_STATS, L.EPI_BNBWD, L.EPI_BNBWD | L.EPI_ADDEND):
+        return False
+    return d.Cin % 32 == 0 and d.Cin <= 256 and d.Cout % 8 == 0 and d.ldx % 8 == 0 and d.ldy % 8 == 0
+
+
 def _conv_candidates(d):
     """tile configurations of dyk_conv_igemm for one problem: K-step bytes | ring stages << 8 | pixel tile << 12
     (0 = 128, 1 = 80, 2 = 160 pixels, 3 / 4 = halo kernel 4x20 / 8x20; bf16 only) | channel tile << 24 (0 = by Cout, 2 = 64, 1 = 32)
@@ -1621,6 +1635,15 @@ def _conv_candidates(d):
         # resident-weight 3x3 data gradient into 32-channel tensors (csrc/conv_sc.hip): one patch per tile for every tap and
         # parity class, epilogue from the accumulators; the front end falls back to the generic tile where it does not apply
         out.append(6 << 12)
+    if pw_eligible(d) and os.environ.get("DYK_CONV_PW", "1") != "0":
+        # persistent resident-weight pointwise kernels (csrc/conv_pw_kernel.h): ring stages 2 | 3 | 4, 64- or (channel tiles <= 64
+        # rows) 128-pixel tiles; the front end falls back to the generic 128-pixel tile where a shape does not fit
+        for nxs in (2, 3, 4):
+            out.append((7 << 12) | (nxs << 8))
+            if d.Cout <= 64:
+                out.append((7 << 12) | (nxs << 8) | (1 << 24))
+            else:
+                out.append((7 << 12) | (nxs << 8) | (1 << 25))
     if d.dtype == L.DYK_BF16 and (d.Cin * es) % 128 == 0 and d.Cin >= 128 and os.environ.get("DYK_CONV_KG", "1") != "0":
         # K-grouped workgroups (two 4-wave groups over the two halves of Cin): for tiles that leave a CU one workgroup
         for t in (1, 2):

@@ -104,6 +104,8 @@ def pair_signature(op, d, plan):
             return None                     # a one-launch conv + BatchNorm waits on its own workgroups: single problem only
         if d.splitk > 1:
             return None                     # split-K across workgroups (private slabs and tile counters): single problem only
+        if ((d.tune >> 12) & 0xf) == 7:
+            return None                     # persistent pointwise kernels (csrc/conv_pw_kernel.h): single problem only
         if ((d.tune >> 12) & 0xf) == 6:
             return None                     # resident-weight data gradient (csrc/conv_sc.hip): single problem only -- as one half of a
                                             # two-problem launch it would fall back to the generic kernel, whose epilogue rounds differently

@@ -1026,3 +1026,114 @@ def test_split_k_conv_at_baseline_size(case):
         err = (ops.to_nchw(y).cpu() - y_ref).abs().max().item()
         assert err <= 1.2e-2 * max(1.0, y_ref.abs().max().item()), (hex(tune), S, err)
     assert ran >= 4, ran
+
+
+PW_CASES = [  # (B, Cin, Cout, H, W): 1x1 conv Cin -> Cout; channel counts of the target and the MobileNet cfgs, ragged pixel counts
+    (2, 128, 128, 16, 20), (1, 256, 256, 13, 17), (3, 64, 32, 9, 25), (2, 72, 24, 12, 20), (1, 16, 64, 31, 33),
+    (2, 256, 128, 8, 10), (1, 120, 40, 16, 20), (2, 64, 64, 16, 24), (1, 256, 512, 8, 20), (2, 96, 16, 10, 12),
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=lambda c: "b%d_c%d_%d_%dx%d" % c)
+def test_pointwise_conv_kernels(case):
+    """csrc/conv_pw_kernel.h (round 5): the persistent resident-weight 1x1 kernels, every ring depth and pixel tile, against
+    torch CPU fp32 on the same bf16-rounded operands -- forward with BatchNorm statistics, plain data gradient, data gradient
+    with the fused BatchNorm-backward reduce (plain and residual chain, Mish / leaky / hard-swish) -- and BIT-identical raw
+    outputs to the generic implicit-GEMM tile (same K walk, same MFMA).  Tune bit 23: no fallback, so every configuration
+    counted really ran the pointwise kernel.  Channel counts that are not multiples of 32 run as the plan runs them: tight
+    activation rows, K padded in the weight pack only (the K tail of a pixel meets zero weights)."""
+    import ctypes
+    from dyk import lib as L
+    from dyk import ops
+    B, Cin, Cout, H, W = case
+    Kp = -(-Cin // 32) * 32
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).bfloat16().float()
+    y_ref = F.conv2d(x, w)
+    n = B * H * W
+
+    def nhwc_tight(t, C):
+        """channels-last rows of exactly C (multiple of 8) elements + spare zeros behind the tensor (the arena's K tail pad)"""
+        flat = torch.zeros(n * C + 256, dtype=torch.bfloat16, device="cuda")
+        v = flat[:n * C].view(t.shape[0], t.shape[2], t.shape[3], C)
+        ops.to_nhwc(t.cuda(), torch.bfloat16, out=v)
+        return flat, v
+    xflat, xd = nhwc_tight(x, Cin)
+    wp = ops.pack_weight(w.cuda(), torch.bfloat16, cin_pad=Kp)
+    cands = [(7 << 12) | (nxs << 8) | (bn << 24) for nxs in (2, 3, 4) for bn in ((0, 1) if Cout <= 64 else (0, 2))]
+    ran = 0
+    y_gen = None
+    for tune in [0] + cands:
+        stats = torch.zeros(4, 2, Cout, dtype=torch.float64, device="cuda")
+        y = torch.full((B, H, W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+        d = ops.make_conv_desc(xd, wp, y, Hi=H, Wi=W, Cin=Kp, Cout=Cout, Hg=H, Wg=W, Ho=H, Wo=W, taps=ops.fwd_taps(1, 0), stats=stats,
+                               ldx=Cin)
+        d.tune, d.stats_slots = (tune | (1 << 23)) if tune else 0, 4
+        rc = L.load().dyk_conv_igemm(ctypes.byref(d), None)
+        if rc == -3:
+            continue
+        assert rc == 0, (hex(tune), rc)
+        if tune == 0:
+            y_gen = y.clone()
+        else:
+            ran += 1
+            assert torch.equal(y, y_gen), (hex(tune), "raw output differs from the generic tile")
+        err = (ops.to_nchw(y).cpu() - y_ref).abs().max().item()
+        assert err <= 1.2e-2 * max(1.0, y_ref.abs().max().item()), (hex(tune), err)
+        st = stats.sum(0).cpu()
+        assert torch.allclose(st[0], y_ref.double().sum((0, 2, 3)), rtol=1e-3, atol=2e-2 * n ** 0.5), hex(tune)
+        assert torch.allclose(st[1], (y_ref.double() ** 2).sum((0, 2, 3)), rtol=2e-3, atol=1e-2), hex(tune)
+    assert ran >= 3, ran
+    # ---- data gradient of the conv Cout -> Cin' where the roles swap: dx[n][ci] = sum_co dy[n][co] w[co][ci]
+    Kb = -(-Cout // 32) * 32
+    if Kb > 256 or Cin % 8:
+        return
+    dy = torch.randn(B, Cout, H, W, generator=g).bfloat16().float()
+    u = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    gadd = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    mean, var = u.mean((0, 2, 3)), u.var((0, 2, 3), unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    sc2, sh2 = gamma * rstd, beta - mean * gamma * rstd
+    xhat = (u - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1)
+    dz = torch.nn.grad.conv2d_input((B, Cin, H, W), w, dy)
+    dyflat, dyd = nhwc_tight(dy, Cout)
+    uflat, ud = nhwc_tight(u, Cin)
+    aflat, addd = nhwc_tight(gadd, Cin)
+    wpt = ops.pack_weight(w.cuda(), torch.bfloat16, transposed=True, cout_pad=Kb)
+    vec = [t.cuda().contiguous() for t in (sc2, sh2, mean, rstd)]
+    (py, px, Hg, Wg, taps), = ops.dgrad_classes(1, 0, 1, H, W)
+    ran_b = 0
+    for actname, actfn in (("mish", F.mish), ("leaky", lambda t: F.leaky_relu(t, 0.1)), ("hard-swish", F.hardswish)):
+        def bn_ref(dzv):
+            t = (u * sc2.view(1, -1, 1, 1) + sh2.view(1, -1, 1, 1)).requires_grad_(True)
+            actfn(t).backward(dzv)
+            return t.grad, t.grad.double().sum((0, 2, 3)), (t.grad.double() * xhat.double()).sum((0, 2, 3))
+        da_ref, s1_ref, s2_ref = bn_ref(dz)
+        dzc = (dz + gadd).bfloat16().float()
+        _, s1c, s2c = bn_ref(dzc)
+        for tune in [(7 << 12) | (nxs << 8) | (bn << 24) for nxs in (2, 3) for bn in (0, 1, 2)]:
+            for flags, ref, r1, r2 in ((0, dz, None, None), (L.EPI_BNBWD, da_ref, s1_ref, s2_ref), (L.EPI_BNBWD | L.EPI_ADDEND, dzc, s1c, s2c)):
+                if flags == 0 and actname != "mish":
+                    continue
+                out = torch.full((B, H, W, Cin), float("nan"), dtype=torch.bfloat16, device="cuda")
+                red = torch.zeros(4, 2, Cin, dtype=torch.float64, device="cuda")
+                d = ops.make_conv_desc(dyd, wpt, out, Hi=H, Wi=W, Cin=Kb, Cout=Cin, Hg=Hg, Wg=Wg, Ho=H, Wo=W, taps=taps, act=actname, ldx=Cout)
+                if flags:
+                    d.res, d.ldr = ud.data_ptr(), Cin
+                    d.scale, d.shift, d.aux0, d.aux1 = (t.data_ptr() for t in vec)
+                    d.stats, d.stats_slots, d.add = red.data_ptr(), 4, addd.data_ptr()
+                d.flags, d.tune = flags, tune | (1 << 23)
+                rc = L.load().dyk_conv_igemm(ctypes.byref(d), None)
+                if rc == -3:
+                    continue
+                assert rc == 0, (hex(tune), flags, rc)
+                ran_b += 1
+                err = (ops.to_nchw(out).cpu() - ref).abs().max().item()
+                assert err <= 1.5e-2 * max(1.0, ref.abs().max().item()), (hex(tune), flags, actname, err)
+                if flags:
+                    st = red.sum(0).cpu()
+                    assert torch.allclose(st[0], r1, rtol=2e-3, atol=5e-2 * n ** 0.5), (hex(tune), flags, actname)
+                    assert torch.allclose(st[1], r2, rtol=2e-3, atol=5e-2 * n ** 0.5), (hex(tune), flags, actname)
+    assert ran_b >= 9, ran_b
