@@ -41,6 +41,36 @@ __global__ void cast_pad_rows_kernel(const float* __restrict__ src, T* __restric
     }
 }
 
+// dyk_cast_pad_table: one block = 2048 consecutive elements of one entry's destination (binary search over blk_begin).
+// Plain entries: dst[r][c] = (T) src[r][c] for c < cols, 0 for cols <= c < cpad.  transpose_f32 entries: dst is fp32
+// [cols][rows], dst[c][r] = src[r][c] (the [27][Cout] transpose the direct stem kernel streams through scalar loads).
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad_table_kernel(const DykPadEntry* __restrict__ tab, int n_entries) {
+    const int bidx = blockIdx.x;
+    int lo = 0, hi = n_entries - 1;           // last entry with blk_begin <= bidx
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].blk_begin <= bidx) lo = mid; else hi = mid - 1;
+    }
+    const DykPadEntry e = tab[lo];
+    const long total = e.transpose_f32 ? (long)e.rows * e.cols : (long)e.rows * e.cpad;
+    const long i0 = (long)(bidx - e.blk_begin) * 2048;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long i = i0 + u * 256 + threadIdx.x;
+        if (i >= total) break;
+        if (e.transpose_f32) {
+            const int r = (int)(i % e.rows);
+            const long c = i / e.rows;
+            ((float*)e.dst)[i] = e.src[(long)r * e.cols + c];
+        } else {
+            const int c = (int)(i % e.cpad);
+            const long r = i / e.cpad;
+            ((T*)e.dst)[i] = ElemTraits<T>::from_f32(c < e.cols ? e.src[r * e.cols + c] : 0.f);
+        }
+    }
+}
+
 // one block = one 32x32 tile of one (entry, tap); dst[t][col][row] = src[t][row][col]
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_taps_kernel(const float* __restrict__ src, T* __restrict__ dst,
@@ -133,6 +163,18 @@ extern "C" int dyk_cast_pad_rows(const float* src, void* dst, int32_t R, int32_t
         hipLaunchKernelGGL(cast_pad_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, R, C, Cpad);
     else if (dtype == DYK_F32)
         hipLaunchKernelGGL(cast_pad_rows_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, R, C, Cpad);
+    else
+        return DYK_ERR_ARG;
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
+extern "C" int dyk_cast_pad_table(const DykPadEntry* tab, int32_t n_entries, int32_t total_blocks, int32_t dtype, void* stream) {
+    if (!tab || n_entries <= 0 || total_blocks <= 0) return DYK_ERR_ARG;
+    if (dtype == DYK_BF16)
+        hipLaunchKernelGGL(cast_pad_table_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, tab, n_entries);
+    else if (dtype == DYK_F32)
+        hipLaunchKernelGGL(cast_pad_table_kernel<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, tab, n_entries);
     else
         return DYK_ERR_ARG;
     DYK_LAUNCH_CHECK();

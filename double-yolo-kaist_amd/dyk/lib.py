@@ -103,6 +103,11 @@ class DykTransposeEntry(ctypes.Structure):
                 ("tile_begin", _i32), ("dst_ld", _i32), ("_pad", _i32)]
 
 
+class DykPadEntry(ctypes.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("rows", _i32), ("cols", _i32), ("cpad", _i32), ("blk_begin", _i32),
+                ("transpose_f32", _i32), ("_pad", _i32)]
+
+
 class DykDwDesc(ctypes.Structure):
     _fields_ = [("x", _vp), ("y", _vp), ("w", _vp), ("dw", _vp), ("stats", _vp), ("part", _vp),
                 ("dtype", _i32), ("ldx", _i32), ("ldy", _i32),
@@ -215,6 +220,7 @@ SIGNATURES = {
     "dyk_nhwc_to_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dyk_cast_f32": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "dyk_cast_pad_rows": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "dyk_cast_pad_table": (_i32, [_vp, _i32, _i32, _i32, _vp]),
     "dyk_transpose_taps": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "dyk_dwconv_fwd": (_i32, [_P(DykDwDesc), _vp]),
     "dyk_dwconv_dgrad": (_i32, [_P(DykDwDesc), _vp]),

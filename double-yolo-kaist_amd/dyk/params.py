@@ -269,19 +269,33 @@ class ParamStore:
         if side is not None:
             self.wt_ready = torch.cuda.Event()
             self.wt_ready.record(side)
-        esz = 2 if dtype == torch.bfloat16 else 4
-        for name, off in st["fwd_pad_off"].items():
-            e = self.by_name[name]
-            co, ci, kh, kw = e.shape
-            check(lib.dyk_cast_pad_rows(self.P.data_ptr() + 4 * e.offset, st["Wc_pad"].data_ptr() + esz * off,
-                                        kh * kw * co, ci, _round_up(ci, 32), code, stream), "dyk_cast_pad_rows")
-        for e in self.entries:
-            if e.kind == "stem_w":
+        # every K-padded forward pack, the stems' padded packs and their fp32 [27][Cout] transposes: ONE table-driven launch
+        # (round 5: the MobileNetV3 cfg has 68 padded packs -- 68 launches of 3 us plus two torch copies, 0.5-0.8 ms of a
+        # nearly idle GPU on the caller's stream at every step boundary)
+        tab = st.get("pad_table")
+        if tab is None:
+            esz = 2 if dtype == torch.bfloat16 else 4
+            ents = []
+            for name, off in st["fwd_pad_off"].items():
+                e = self.by_name[name]
                 co, ci, kh, kw = e.shape
-                t = st["stems"][e.name]
-                check(lib.dyk_cast_pad_rows(self.P.data_ptr() + 4 * e.offset, t.data_ptr(), co, ci * kh * kw, t.shape[1],
-                                            code, stream), "dyk_cast_pad_rows")
-                with torch.no_grad():
-                    st["stems_t"][e.name].copy_(self.P[e.offset:e.offset + e.numel].view(co, ci * kh * kw).t())
+                ents.append((self.P.data_ptr() + 4 * e.offset, st["Wc_pad"].data_ptr() + esz * off, kh * kw * co, ci, _round_up(ci, 32), 0))
+            for e in self.entries:
+                if e.kind == "stem_w":
+                    co, ci, kh, kw = e.shape
+                    t = st["stems"][e.name]
+                    ents.append((self.P.data_ptr() + 4 * e.offset, t.data_ptr(), co, ci * kh * kw, t.shape[1], 0))
+                    ents.append((self.P.data_ptr() + 4 * e.offset, st["stems_t"][e.name].data_ptr(), co, ci * kh * kw, ci * kh * kw, 1))
+            arr = (L.DykPadEntry * max(len(ents), 1))()
+            blocks = 0
+            for i, (src, dst, rows, cols, cpad, tr) in enumerate(ents):
+                arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols, arr[i].cpad = src, dst, rows, cols, cpad
+                arr[i].blk_begin, arr[i].transpose_f32 = blocks, tr
+                blocks += (rows * (cols if tr else cpad) + 2047) // 2048
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            tab = st["pad_table"] = (dev, len(ents), blocks, self.P.data_ptr())
+        if tab[1]:
+            assert tab[3] == self.P.data_ptr()
+            check(lib.dyk_cast_pad_table(tab[0].data_ptr(), tab[1], tab[2], code, stream), "dyk_cast_pad_table")
         st["version"] = ver
         return st

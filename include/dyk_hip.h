@@ -487,6 +487,19 @@ typedef struct DykTransposeEntry {
     int32_t dst_ld;       /* row length of dst (>= rows, <= rows rounded up to 32; 0 = rows); the tail is zero-filled */
     int32_t _pad;
 } DykTransposeEntry;
+/* dyk_cast_pad_table: every K-padded weight pack of a model in ONE launch (the MobileNet cfgs have 68 of them: 68 launches of
+ * 3 us on the caller's stream at every step boundary, round 5).  Entry e: dst_e[r][c] = (dtype) src_e[r][c] for c < cols,
+ * 0 for cols <= c < cpad; with transpose_f32 set dst_e is fp32 [cols][rows] = the transpose of src_e (no padding).  blk_begin =
+ * exclusive prefix sum of ceil(elements_e / 2048) over the entries; total_blocks = its end. */
+typedef struct DykPadEntry {
+    const float* src;
+    void* dst;
+    int32_t rows, cols, cpad;
+    int32_t blk_begin;
+    int32_t transpose_f32;
+    int32_t _pad;
+} DykPadEntry;
+int dyk_cast_pad_table(const DykPadEntry* table_dev, int32_t n_entries, int32_t total_blocks, int32_t dtype, void* stream);
 int dyk_cast_f32(const float* src, void* dst, int64_t n, int32_t dtype, void* stream);
 int dyk_cast_pad_rows(const float* src, void* dst, int32_t R, int32_t C, int32_t Cpad, int32_t dtype, void* stream);
 int dyk_transpose_taps(const float* src, void* dst, const DykTransposeEntry* table_dev, int32_t n_entries,

@@ -42,7 +42,7 @@ def test_null_descriptors_are_rejected_without_a_gpu():
     assert h.dyk_conv_igemm(ctypes.byref(d), None) == -1          # null pointers inside
 
 
-STRUCTS = ["DykConvDesc", "DykWgradDesc", "DykEwDesc", "DykBnFinalizeDesc", "DykSeFcDesc", "DykTransposeEntry",
+STRUCTS = ["DykConvDesc", "DykWgradDesc", "DykEwDesc", "DykBnFinalizeDesc", "DykSeFcDesc", "DykTransposeEntry", "DykPadEntry",
            "DykMiscDesc", "DykCommand", "DykDwDesc", "DykGradReduceEntry", "DykDecodeDesc", "DykTargetsDesc", "DykLossDesc", "DykNmsDesc", "DykOptimDesc", "DykSchedEntry", "DykStemDesc"]
 
 
