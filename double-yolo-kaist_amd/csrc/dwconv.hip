@@ -5,6 +5,7 @@
 // L1/L2), not MFMA work.  Weights are read directly from the fp32 master copy in tap-major order [k*k][C].
 // The forward optionally accumulates the per-channel sum / sum of squares for a following train-mode
 // BatchNorm into the same replicated fp64 buffers the MFMA conv epilogue uses.
+#include <type_traits>
 #include "dyk_common.h"
 
 namespace {
@@ -272,7 +273,8 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DykDwDesc d, int CT, i
     {   // ---- stage the patch: all loads first (clamped addresses), then the LDS stores (zeros outside the image)
         const int nvec = IR * IC * CT;
         uint4 v[NLD];
-        int dst[NLD];
+        int dst[NLD], cts[NLD];
+        unsigned okm = 0;
         const T* img = x + (long)b * Hsrc * Wsrc * ld_src + (long)cv0 * EPV;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -285,7 +287,8 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DykDwDesc d, int CT, i
             const int yc = ys < 0 ? 0 : (ys >= Hsrc ? Hsrc - 1 : ys), xc = xs < 0 ? 0 : (xs >= Wsrc ? Wsrc - 1 : xs);
             const int cc = cv0 + ct < CV ? ct : 0;
             v[i] = *(const uint4*)(img + ((long)yc * Wsrc + xc) * ld_src + cc * EPV);
-            if (!ok) v[i] = make_uint4(0u, 0u, 0u, 0u);
+            okm |= ok ? (1u << i) : 0u;
+            cts[i] = cc;
             dst[i] = idx < (unsigned)nvec ? (row * IC + col) * S + ct : -1;
         }
         // weights of this channel group, tap order flipped for the data gradient
@@ -297,9 +300,48 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(DykDwDesc d, int CT, i
             if (cch < d.C) w4 = *(const float4*)(d.w + (long)tsrc * d.C + cch);
             *(float4*)(wl + (tap * CT * 2 + rem) * 4) = w4;
         }
+        if (!GRAD && d.pre != nullptr) {
+            // DykDwDesc.pre: the patch holds the RAW output of the expansion conv; z = dtype(act(scale * u + shift)) is formed
+            // here, between the loads (all in flight) and the LDS stores.  scale | shift of this workgroup's channel vectors
+            // go through LDS (behind the weights): a staged vector belongs to any of the CT vectors
+            float* pl = wl + K * K * CT * 8;
+            for (int i = tid; i < CT * 4; i += 256) {                 // i = (which, ct, half)
+                const int which = i / (CT * 2), rem = i - which * (CT * 2);
+                const int cch = cv0 * EPV + rem * 4;
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cch < d.C) q = *(const float4*)(d.pre + (long)which * d.C + cch);
+                *(float4*)(pl + i * 4) = q;
+            }
+            __syncthreads();
+            // (ONE switch around the whole pass: with the activation switch inside the unrolled loops the transform is all branches)
+            auto xform = [&](auto act_tag) {
+                constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i)
+                for (int i = 0; i < NLD; ++i) {
+                    float u[EPV];
+                    vec_unpack<T>(v[i], u);
+                    const float4 s0 = *(const float4*)(pl + cts[i] * 8), s1 = *(const float4*)(pl + cts[i] * 8 + 4);
+                    const float4 h0 = *(const float4*)(pl + CT * 8 + cts[i] * 8), h1 = *(const float4*)(pl + CT * 8 + cts[i] * 8 + 4);
+                    const float sc[EPV] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                    const float sh[EPV] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) u[j] = act_fwd_c<ACT>(u[j] * sc[j] + sh[j], d.pre_act);
+                    v[i] = vec_pack<T>(u);
+                }
+            };
+            switch (d.pre_act) {
+            case DYK_ACT_RELU: xform(std::integral_constant<int, DYK_ACT_RELU>{}); break;
+            case DYK_ACT_RELU6: xform(std::integral_constant<int, DYK_ACT_RELU6>{}); break;
+            case DYK_ACT_HSWISH: xform(std::integral_constant<int, DYK_ACT_HSWISH>{}); break;
+            case DYK_ACT_LEAKY: xform(std::integral_constant<int, DYK_ACT_LEAKY>{}); break;
+            default: xform(std::integral_constant<int, -1>{}); break;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            if (!((okm >> i) & 1u)) v[i] = make_uint4(0u, 0u, 0u, 0u);
             if (dst[i] >= 0) smem[dst[i]] = v[i];
+        }
     }
     __syncthreads();
     const unsigned sl = CT == 1 ? (unsigned)tid : __umulhi((unsigned)tid, m_ct);
@@ -439,7 +481,7 @@ int launch_dw_tile(const DykDwDesc* d, hipStream_t stream) {
     if (IR * IC * CT > NLD * 256) return DYK_ERR_UNSUPPORTED;
     const int Hout = GRAD ? d->Hi : d->Ho, Wout = GRAD ? d->Wi : d->Wo;
     const int tiles_x = (Wout + TW - 1) / TW, tiles_y = (Hout + RT - 1) / RT;
-    size_t lds = (size_t)IR * IC * S * 16 + (size_t)K * K * CT * 8 * 4;
+    size_t lds = (size_t)IR * IC * S * 16 + (size_t)K * K * CT * 8 * 4 + (size_t)CT * 16 * 4;   // patch | weights | pre scale, shift
     if (lds < 256 * 16 * 4 + 2048) lds = 256 * 16 * 4 + 2048;            // the statistics reduction reuses the patch
     const unsigned m_ct = (unsigned)(0xFFFFFFFFu / (unsigned)CT) + 1u;   // idx / CT == umulhi(idx, m_ct) for idx < 2^32 / CT
     const long nblk = (long)groups * tiles_x * tiles_y * d->B;
@@ -584,6 +626,38 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DykDwDesc d, int CVB)
     for (int t = 0; t < K; ++t)
 #pragma unroll
         for (int j = 0; j < EPV; ++j) acc[t][j] = 0.f;
+    // DykDwDesc.pre: x holds the raw output of the producing conv; z = dtype(act(scale * u + shift)) is formed on load
+    const bool pre = d.pre != nullptr;
+    float psc[EPV], psh[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) { psc[j] = 1.f; psh[j] = 0.f; }
+    if (pre && active) {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) { psc[j] = d.pre[c + j]; psh[j] = d.pre[d.C + c + j]; }
+    }
+    // branch-free for the activations the depthwise blocks use (ReLU, ReLU6, h-swish, leaky, linear):
+    //   act(t) = clamp(t, lo, hi) * (mulx ? clamp(t + 3, 0, 6) / 6 : 1)   with leaky as max(t, 0.1 t)
+    const int pact = d.pre_act;
+    const bool p_generic = pre && !(pact == DYK_ACT_LINEAR || pact == DYK_ACT_RELU || pact == DYK_ACT_RELU6 || pact == DYK_ACT_HSWISH ||
+                                    pact == DYK_ACT_LEAKY);
+    const float p_lo = (pact == DYK_ACT_RELU || pact == DYK_ACT_RELU6) ? 0.f : -__builtin_inff();
+    const float p_hi = pact == DYK_ACT_RELU6 ? 6.f : __builtin_inff();
+    const float p_leak = pact == DYK_ACT_LEAKY ? 0.1f : 1.f;
+    const bool p_hsw = pact == DYK_ACT_HSWISH;
+    auto pre_apply = [&](float (&xv)[EPV]) {
+        if (pre) {
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                const float t = xv[j] * psc[j] + psh[j];
+                float r = fminf(fmaxf(fmaxf(t, p_leak * t), p_lo), p_hi);
+                if (p_hsw) r = t * fminf(fmaxf(t + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                if (p_generic) r = act_fwd(pact, t);
+                xv[j] = r;
+            }
+            const uint4 pk = vec_pack<T>(xv);                  // rounded to the storage type: what the separate pass would have stored
+            vec_unpack<T>(pk, xv);
+        }
+    };
     if (active) {
         const int nrows = d.B * d.Ho;
         for (int row = blockIdx.y; row < nrows; row += gridDim.y) {
@@ -622,6 +696,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DykDwDesc d, int CVB)
                         const bool in = xi >= 0 && xi < d.Wi;
                         float xv[EPV];
                         vec_unpack<T>(xraw[sl], xv);
+                        pre_apply(xv);
 #pragma unroll
                         for (int j = 0; j < EPV; ++j) xv[j] = in ? xv[j] : 0.f;
 #pragma unroll
@@ -652,6 +727,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DykDwDesc d, int CVB)
                 const bool in = xi >= 0 && xi < d.Wi;
                 float xv[EPV];
                 vec_unpack<T>(xraw[t], xv);
+                pre_apply(xv);
 #pragma unroll
                 for (int j = 0; j < EPV; ++j) acc[t][j] += in ? g[j] * xv[j] : 0.f;
             }
@@ -722,6 +798,7 @@ extern "C" int dyk_dwconv_fwd(const DykDwDesc* d, void* stream) {
         const int rt = d->k == 3 ? launch_dw_tile<3, false>(d, (hipStream_t)stream) : launch_dw_tile<5, false>(d, (hipStream_t)stream);
         if (rt != DYK_ERR_UNSUPPORTED) { DYK_LAUNCH_CHECK(); return rt; }
     }
+    if (d->pre) return DYK_ERR_UNSUPPORTED;        // normalise + activation on load: the LDS-tiled kernel only (dyk_dwconv_tile_ok)
     if (d->stride == 1 && (d->k == 3 || d->k == 5) && d->dtype == DYK_BF16) {
         if (d->k == 3) hipLaunchKernelGGL((dwconv_strip_kernel<bf16_t, 3, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
         else hipLaunchKernelGGL((dwconv_strip_kernel<bf16_t, 5, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
@@ -731,6 +808,20 @@ extern "C" int dyk_dwconv_fwd(const DykDwDesc* d, void* stream) {
         hipLaunchKernelGGL((dwconv_kernel<float, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *d, CVB);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
+}
+
+extern "C" int dyk_dwconv_tile_ok(const DykDwDesc* d) {
+    const int rc = check_dw(d);
+    if (rc) return rc;
+    if (!(d->stride == 1 && (d->k == 3 || d->k == 5) && d->dtype == DYK_BF16 && dw_tile_on())) return 0;
+    const int K = d->k, TW = 16, IC = TW + K - 1, NLD = K == 5 ? 8 : 6;
+    const int CV = d->C / 8;
+    const int groups = (CV + 7) / 8, CT = (CV + groups - 1) / groups;
+    const int RT = (256 / CT) / 4, IR = RT + K - 1, S = CT | 1;
+    if (IR * IC * CT > NLD * 256) return 0;
+    const size_t lds = (size_t)IR * IC * S * 16 + (size_t)K * K * CT * 8 * 4 + (size_t)CT * 16 * 4;
+    const long nblk = (long)groups * ((d->Wo + TW - 1) / TW) * ((d->Ho + RT - 1) / RT) * d->B;
+    return (nblk < (1L << 31) && lds <= 64 * 1024) ? 1 : 0;
 }
 
 extern "C" int dyk_dwconv_dgrad(const DykDwDesc* d, void* stream) {

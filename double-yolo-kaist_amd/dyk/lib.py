@@ -113,7 +113,8 @@ class DykDwDesc(ctypes.Structure):
                 ("dtype", _i32), ("ldx", _i32), ("ldy", _i32),
                 ("B", _i32), ("Hi", _i32), ("Wi", _i32), ("Ho", _i32), ("Wo", _i32), ("C", _i32),
                 ("k", _i32), ("stride", _i32), ("pad", _i32), ("flags", _i32), ("stats_slots", _i32),
-                ("res", _vp), ("bn", _vp), ("ldr", _i32), ("act", _i32)]
+                ("res", _vp), ("bn", _vp), ("ldr", _i32), ("act", _i32),
+                ("pre", _vp), ("pre_act", _i32), ("_pad", _i32)]
 
 
 class DykGradReduceEntry(ctypes.Structure):
@@ -223,6 +224,7 @@ SIGNATURES = {
     "dyk_cast_pad_table": (_i32, [_vp, _i32, _i32, _i32, _vp]),
     "dyk_transpose_taps": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "dyk_dwconv_fwd": (_i32, [_P(DykDwDesc), _vp]),
+    "dyk_dwconv_tile_ok": (_i32, [_P(DykDwDesc)]),
     "dyk_dwconv_dgrad": (_i32, [_P(DykDwDesc), _vp]),
     "dyk_dwconv_wgrad": (_i32, [_P(DykDwDesc), _vp]),
     "dyk_dwconv_wgrad_rows": (_i32, [_P(DykDwDesc)]),

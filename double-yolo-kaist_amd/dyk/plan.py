@@ -350,6 +350,39 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     head_idx = 0
     na_no = []
 
+    def defer_to_dw(i, out_layer, out_ref, Bn, Ho, Wo, cout, is_dw, is_direct):
+        """OFF by default (DYK_DW_PRE=1 enables it): built for VERDICT r4 #3a, bit-identical (tests), measured SLOWER -- MobileNetV3
+        cfg, batch 32, in-call: 18.2-18.3 ms without, 19.1-19.3 ms with (20.8 with the activation switch inside the unrolled
+        loops): the depthwise kernels are latency-bound, every VALU op and the extra barrier on their staging path costs more than
+        the two streaming passes (at 3-5 TB/s) it removes.
+        May section i's conv + BatchNorm + activation leave normalise + activation to its consumer?  Yes when the consumer
+        is THE next section, a stride-1 3x3 / 5x5 depthwise conv over the same channels that dyk_dwconv_fwd runs on the
+        LDS-tiled kernel, nobody else reads the output (no route / shortcut, no concat placement), bf16 training plan."""
+        if (not training or is_dw or is_direct or out_ref is not None or out_layer != i or code != L.DYK_BF16
+                or os.environ.get("DYK_DW_PRE", "0") == "0" or os.environ.get("DYK_DEBUG_PLAN") or _bnfwd_on()):
+            return False
+        if i + 1 >= len(defs) or nrefs[i] != 1 or i in concat_slot or (second is not None and i + 1 == second):
+            return False
+        nx = defs[i + 1]
+        if nx["type"] == "convolutional":
+            g = nx.get("groups", 1)
+            if not (isinstance(g, int) and g > 1 and g == cout and nx["filters"] == cout and nx.get("stride", 1) == 1
+                    and nx["size"] in (3, 5) and nx["pad"] and nx["batch_normalize"]):
+                return False
+            k2, pad2 = nx["size"], nx["size"] // 2
+        elif nx["type"] == "depthwiseconvolutional":
+            if nx.get("stride", 1) != 1 or nx.get("size", 3) not in (3, 5):
+                return False
+            k2, pad2 = nx.get("size", 3), 1
+        else:
+            return False
+        q = L.DykDwDesc()
+        q.x = q.y = 1                                    # (shape query only)
+        q.dtype, q.B, q.Hi, q.Wi, q.C, q.k, q.stride, q.pad = code, Bn, Ho, Wo, cout, k2, 1, pad2
+        q.Ho, q.Wo = conv_out_size(Ho, k2, 1, pad2), conv_out_size(Wo, k2, 1, pad2)
+        q.ldx = q.ldy = _ru(cout, 8)
+        return L.load().dyk_dwconv_tile_ok(ctypes.byref(q)) == 1
+
     def conv_forward(i, x_in, stem_src, wname, bnpre, bnm, bias_name, k, stride, pad, cout, act, groups=1, out_layer=None,
                      out_ref=None, entry=True):
         """emit forward commands of Conv2d [+ BatchNorm2d] [+ activation]; returns (out TRef, info dict).
@@ -371,6 +404,11 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             d.k, d.stride, d.pad = k, stride, pad
             d.ldx = x_in.ld
             conv_op = L.OP_DW_FWD
+            pre = getattr(x_in, "pre", None)
+            if pre is not None:
+                # x_in aliases the RAW output of the expansion conv (deferred normalise, below): z is formed on load
+                d.pre_act = pre[1]
+                later(lambda d=d, pre=pre: setattr(d, "pre", ws.ptr(pre[0])))
         elif (stem_src is not None and k == 3 and pad == 1 and stride in (1, 2) and cout in (16, 32) and bn
               and os.environ.get("DYK_STEM_DIRECT", "1") != "0"):
             # Cin=3 stem straight from the image batch (csrc/stem.hip): no float conversion pass, no im2col
@@ -432,7 +470,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         if bn:
             if training:
                 y_raw = new_act(B, Ho, Wo, cout)
-                z = out_ref if out_ref is not None else alloc_out(out_layer, B, Ho, Wo, cout)
+                z = None if defer_to_dw(i, out_layer, out_ref, B, Ho, Wo, cout, dw, direct) else (
+                    out_ref if out_ref is not None else alloc_out(out_layer, B, Ho, Wo, cout))
                 # replicas of the fp64 statistics accumulators: keep the atomics per address at a few dozen
                 tiles = (B * Ho * Wo + 127) // 128
                 # (about 32 workgroups per replica), few enough that the consumer folds them cheaply
@@ -485,6 +524,19 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     setattr(f, "stats", st_arena.ptr(stats)), setattr(f, "scale", ws.ptr(vecs)),
                     setattr(f, "shift", ws.ptr(vecs + 4 * cout)), setattr(f, "save_mean", ws.ptr(vecs + 8 * cout)),
                     setattr(f, "save_rstd", ws.ptr(vecs + 12 * cout))))
+                if defer_to_dw(i, out_layer, out_ref, B, Ho, Wo, cout, dw, direct):
+                    # Normalise + activation ON LOAD in the consumer (VERDICT r4 #3a): this block's only reader is a stride-1
+                    # depthwise conv on the LDS-tiled kernel (MobileNet expansion conv -> depthwise, reference models.py:34-62
+                    # then :41 groups=C): its forward and its weight gradient form z = dtype(act(scale * u + shift)) from the
+                    # raw output while staging (DykDwDesc.pre) -- the same values this pass would have stored -- so z is never
+                    # written or read back: two tensor passes over the LARGEST tensors of the net less, per block.  Only
+                    # the finalize launch remains.  The output TRef aliases the raw tensor and carries the vectors.
+                    plan.fwd.append((L.OP_BN_FINALIZE, f))
+                    z = TRef(y_raw.arena, y_raw.off, y_raw.B, y_raw.H, y_raw.W, y_raw.C, y_raw.ld, y_raw.esize)
+                    z.pre = (vecs, act)
+                    rec.update(y_raw=y_raw, z=z, vecs=vecs, deferred=True)
+                    producer_of[z.tid] = rec
+                    return z, rec
                 a = ew_desc(a=y_raw, out=z, act=act)
                 later(lambda a=a, vecs=vecs: (setattr(a, "p0", ws.ptr(vecs)), setattr(a, "p1", ws.ptr(vecs + 4 * cout))))
                 if slots <= 32 and os.environ.get("DYK_BN_FUSED_FWD", "1") != "0":
@@ -876,6 +928,10 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 wd.k, wd.stride, wd.pad = k, stride, pad
                 wd.ldx, wd.ldy = x_in.ld, dy.ld
                 later(lambda wd=wd, x=x_in, dy=dy: (setattr(wd, "x", ptr_of(x)), setattr(wd, "y", ptr_of(dy))))
+                pre = getattr(x_in, "pre", None)
+                if pre is not None:                       # (the input is the producer's RAW output: z is formed on load)
+                    wd.pre_act = pre[1]
+                    later(lambda wd=wd, pre=pre: setattr(wd, "pre", ws.ptr(pre[0])))
                 if wname not in frozen:
                     plan.bwd.append((L.OP_DW_WGRAD, wd))
                 if rec["i"] == first_trainable and rec["entry"]:

@@ -169,6 +169,8 @@ def accesses(op, d, mem, plan):
             wr(mem.interval(_v(d.dw), plane))
     elif op in (L.OP_DW_FWD, L.OP_DW_DGRAD, L.OP_DW_WGRAD):
         es = _es(d.dtype)
+        if d.pre and op != L.OP_DW_DGRAD:     # normalise + activation on load: scale | shift of the producer's BatchNorm
+            rd(V(d.pre))
         if op == L.OP_DW_FWD:
             rd(T(d.x, d.ldx, d.C, es)); wr(T(d.y, d.ldy, d.C, es)); wr(V(d.stats))
         elif op == L.OP_DW_DGRAD:

@@ -463,8 +463,19 @@ typedef struct DykDwDesc {
     const void* res;
     const float* bn;
     int32_t ldr, act;
+    /* dyk_dwconv_fwd / dyk_dwconv_wgrad, pre != NULL (round 5): x is the RAW output u of a train-mode Conv2d + BatchNorm2d +
+     * activation block (the 1x1 expansion conv of a MobileNet block, reference models.py:34-62 in front of :41 groups=C) whose
+     * normalise + activation pass was NOT run: the kernel forms z = dtype(act(scale * u + shift)) on load -- exactly the
+     * values that pass would have stored -- and convolves / correlates z.  pre = scale | shift, C floats each (the first half
+     * of the `bn` layout), pre_act = that block's DYK_ACT_*.  Padding taps stay zero (the affine is not applied outside the
+     * image).  Forward: the LDS-tiled stride-1 kernel only (dyk_dwconv_tile_ok), else DYK_ERR_UNSUPPORTED. */
+    const float* pre;
+    int32_t pre_act, _pad;
 } DykDwDesc;
 int dyk_dwconv_fwd(const DykDwDesc* desc, void* stream);
+/* 1 when dyk_dwconv_fwd runs `desc` on the LDS-tiled kernel (stride 1, k in {3, 5}, bf16, tile fits): the precondition of
+ * `pre` in the forward and of `res` in the data gradient; 0 otherwise; negative = error code */
+int dyk_dwconv_tile_ok(const DykDwDesc* desc);
 int dyk_dwconv_dgrad(const DykDwDesc* desc, void* stream);
 int dyk_dwconv_wgrad(const DykDwDesc* desc, void* stream);
 /* number of workgroup rows (= planes of `part`) dyk_dwconv_wgrad uses for this descriptor; negative = error code */

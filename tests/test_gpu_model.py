@@ -578,6 +578,36 @@ def test_one_launch_conv_batchnorm_plan_is_bit_identical(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_normalise_on_load_in_the_depthwise_consumer_is_bit_identical(monkeypatch):
+    """DYK_DW_PRE=1 (off by default: measured slower, dyk/plan.py defer_to_dw): the expansion conv of a MobileNet block leaves
+    normalise + activation to the depthwise conv behind it (DykDwDesc.pre: forward and weight gradient form
+    z = dtype(act(scale * u + shift)) on load).  Same values as the separate pass stores: heads, running statistics and every
+    parameter gradient of the MobileNetV3 cfg are bit-identical to the default plan."""
+    from dyk import lib as L
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DYK_DW_PRE", flag)
+        m = _model(C5, "bf16").train()
+        x, y = _inputs()
+        out = m(x.cuda(), y.cuda())
+        loss = sum((t.float() ** 2).mean() for t in out)
+        loss.backward()
+        torch.cuda.synchronize()
+        plan = next(iter(m.engine.plans.values()))
+        n_pre = sum(1 for op, d in plan.fwd if op == L.OP_DW_FWD and d.pre)
+        assert (n_pre > 20) == (flag == "1") and (n_pre == 0) == (flag == "0")
+        assert sum(1 for op, d in plan.bwd if op == L.OP_DW_WGRAD and d.pre) == n_pre
+        res.append(([t.detach().clone() for t in out], {k: v.clone() for k, v in m.state_dict().items() if "running" in k},
+                    [p.grad.clone() for p in m.parameters()]))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_plan_compilation_leaves_running_statistics_alone(monkeypatch):
     """with DYK_BNFWD=1 the autotuner's trial launches ran the real descriptor, whose one-launch BatchNorm epilogue
     EMA-updates the layer's running statistics (from replica sums that kept accumulating across trials).  Compiling a training
