@@ -29,7 +29,7 @@ import torch  # noqa: E402
 CFG = "kaist_dyolov4_fshare_global_concat_se3"
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
-PROFILE_TAG = "r04"            # profiles/<tag>_*.json written by tools/run_gpu_round.sh for this round
+PROFILE_TAG = "r05"            # profiles/<tag>_*.json written by tools/run_gpu_round.sh for this round
 
 
 def synth_batch(B, H, W, rank, device):
@@ -454,7 +454,7 @@ def main():
                 with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_step_kernels.json")) as f:
                     kj = json.load(f)
                 if kj.get("code_sha") == sha:
-                    fams = [kj["families"][k] for k in ("conv_igemm_kernel", "conv_halo_kernel", "conv_lt_kernel", "conv_sc_kernel") if k in kj["families"]]
+                    fams = [kj["families"][k] for k in ("conv_igemm_kernel", "conv_halo_kernel", "conv_lt_kernel", "conv_sc_kernel", "conv_pw_kernel") if k in kj["families"]]
                     t_us = sum(f_["total_us"] for f_ in fams)
                     in_step = {"tflops": 2.0 * f1 / (t_us * 1e-6) / 1e12, "frac": 2.0 * f1 / (t_us * 1e-6) / 1e12 / peak,
                                "launches": sum(f_["n"] for f_ in fams), "total_us": t_us,
@@ -466,7 +466,7 @@ def main():
             # in-step figure; the isolated-launch figure of this run is always reported beside it
             frac_rocprof = in_step["frac"] if in_step else None
             out["roofline"] = {
-                "bound": "mfma", "kernel": "conv_igemm_kernel + conv_lt_kernel + conv_halo_kernel + conv_sc_kernel (forward + data-gradient launches)",
+                "bound": "mfma", "kernel": "conv_igemm_kernel + conv_lt_kernel + conv_halo_kernel + conv_sc_kernel + conv_pw_kernel (forward + data-gradient launches)",
                 "achieved": (in_step["tflops"] if in_step else ach), "peak": peak, "unit": "TFLOP/s",
                 "frac": (frac_rocprof if frac_rocprof is not None else ach / peak), "traffic": traffic,
                 "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % src if src else None,
