@@ -7,6 +7,7 @@ python -m pytest tests -m gpu -q 2>&1 | grep -vE "RCCL version|HIP version|ROCm 
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 python bench.py --steps 20 --warmup 5 --dump-cmds gpurun_out/cmds_c3.json > gpurun_out/bench.json 2> gpurun_out/bench.err
 python tools/cmd_roofline.py gpurun_out/cmds_c3.json > gpurun_out/cmd_roofline_c3.txt 2>&1
+DYK_ROOFLINE_TOP=1000 python tools/cmd_roofline.py gpurun_out/cmds_c3.json > gpurun_out/cmd_roofline_c3_full.txt 2>&1
 tail -c 3000 gpurun_out/bench.json
 # the other BASELINE configs (parity-test cases; kept beside the bench line for reference)
 python bench.py --mode eval --cfg kaist_dyolov3_add_sl --dtype fp32 --steps 10 --warmup 3 > gpurun_out/bench_eval_c2.json 2>/dev/null
