@@ -386,7 +386,11 @@ int launch_conv_pw(const DykConvDesc* d, hipStream_t stream) {
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     // persistent: as many workgroups per CU as the LDS holds (at most two), a multiple of the channel tiles
-    const int per_cu = (160 * 1024) / (int)lds >= 2 ? 2 : 1;
+    static int cap = 0;
+    if (!cap) { const char* e = getenv("DYK_PW_WGS"); cap = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 2; }
+    int per_cu = (160 * 1024) / (int)lds;
+    if (per_cu > cap) per_cu = cap;
+    if (per_cu < 1) per_cu = 1;
     long grid = 256L * per_cu;
     if (grid > (long)ntiles * mt) grid = (long)ntiles * mt;
     grid -= grid % mt;
