@@ -222,3 +222,33 @@ def test_target_on_the_image_edge_raises_index_error():
     torch.cuda.synchronize()
     with pytest.raises(IndexError):
         opt.step()
+
+
+def test_gradient_edits_between_backward_and_step_reach_the_whole_fused_update():
+    """with the fused optimizers the update of the deep layers runs on a side stream.  Whatever the harness
+    enqueues on ITS stream between backward() and step() -- clip_grad_norm_ (reference users add it), manual scaling, a norm for
+    logging -- must be ordered against that launch.  Here: the gradients are zeroed on the caller's stream behind a long-running
+    kernel; Adam without weight decay must then leave EVERY parameter bit-unchanged (a side stream that only waited for the
+    event in the middle of the backward pass would still see the old gradients of 95 % of the parameters), and a norm taken
+    between the two calls sees the gradients, not the zeros the step leaves behind."""
+    from dyk.optim import FusedAdam
+    m = _model(C3, "bf16")
+    opt = FusedAdam(m, lr=1e-2, weight_decay=0.0)
+    assert not opt.early_start
+    _backward(m, _batch(3))
+    opt.step()                                        # first step: creates the moment buffers (runs without the overlap)
+    _backward(m, _batch(4))
+    p_before = m.engine.store.P.clone()
+    busy = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    for _ in range(6):
+        busy.fill_(1)                                 # a few ms of work on the caller's stream in front of the edit
+    gn = torch.nn.utils.clip_grad_norm_(list(m.parameters()), 1e30)       # (a norm over all gradients, no clipping)
+    for p in m.parameters():
+        p.grad.zero_()
+    # moments of step 1 are not zero: neutralise them so that a zero gradient means a zero update
+    opt._m.zero_()
+    opt._v.zero_()
+    opt.step()
+    torch.cuda.synchronize()
+    assert float(gn) > 0 and np.isfinite(float(gn))
+    assert torch.equal(m.engine.store.P, p_before), "the fused step saw gradients the caller had already overwritten"

@@ -158,3 +158,29 @@ def test_compat_blocks_resblock_and_seinception_fusion():
     assert [c.out_channels for c in MixConv2d(32, 64, method="equal_ch").m] == [22, 21, 21]
     with pytest.raises(NotImplementedError):
         MixConv2d(32, 64)(x)
+
+
+def test_cast_pad_table_matches_per_pack_casts():
+    """dyk_cast_pad_table (round 5): every K-padded weight pack and the stems' transposes in one launch -- against
+    dyk_cast_pad_rows / torch on the same data, ragged element counts included."""
+    import ctypes
+    from dyk import lib as L
+    g = torch.Generator().manual_seed(3)
+    shapes = [(27, 16, 32, 0), (9 * 40, 24, 32, 0), (72, 120, 128, 0), (16, 27, 27, 1), (5, 2049, 2080, 0), (333, 7, 7, 1)]
+    srcs = [torch.randn(r, c, generator=g).cuda() for r, c, _, _ in shapes]
+    dsts = [torch.full((c, r), 7.0, device="cuda") if tr else torch.full((r, cp), 7.0, device="cuda").bfloat16() for r, c, cp, tr in shapes]
+    arr = (L.DykPadEntry * len(shapes))()
+    blocks = 0
+    for i, ((r, c, cp, tr), s, d) in enumerate(zip(shapes, srcs, dsts)):
+        arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols, arr[i].cpad, arr[i].blk_begin, arr[i].transpose_f32 = s.data_ptr(), d.data_ptr(), r, c, cp, blocks, tr
+        blocks += (r * (c if tr else cp) + 2047) // 2048
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    L.check(L.load().dyk_cast_pad_table(tab.data_ptr(), len(shapes), blocks, L.DYK_BF16, None), "dyk_cast_pad_table")
+    torch.cuda.synchronize()
+    for (r, c, cp, tr), s, d in zip(shapes, srcs, dsts):
+        if tr:
+            assert torch.equal(d, s.t().contiguous())
+        else:
+            ref = torch.zeros(r, cp, device="cuda")
+            ref[:, :c] = s
+            assert torch.equal(d, ref.bfloat16())
