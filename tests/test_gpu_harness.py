@@ -233,7 +233,7 @@ def test_gradient_edits_between_backward_and_step_reach_the_whole_fused_update()
     between the two calls sees the gradients, not the zeros the step leaves behind."""
     from dyk.optim import FusedAdam
     m = _model(C3, "bf16")
-    opt = FusedAdam(m, lr=1e-2, weight_decay=0.0)
+    opt = FusedAdam(m, lr=1e-6, weight_decay=0.0)        # (a small first step: the random-weight net must stay finite for the second backward)
     assert not opt.early_start
     _backward(m, _batch(3))
     opt.step()                                        # first step: creates the moment buffers (runs without the overlap)
