@@ -208,11 +208,24 @@ def test_bf16_training_backward_section_by_section_against_oracle(monkeypatch):
             sc, sh, mu, rs = vec4(rec)
             yraw = tref_to_nchw(plan, rec["y_raw"])
             v = lambda a: a.view(1, -1, 1, 1)                  # noqa: E731
-            dact = _act_grad(Lc["act"], yraw * v(sc) + v(sh))
+            # the pre-activation as the kernels form it: ONE rounding (fma); torch's mul + add rounds twice.  Where the two terms
+            # cancel to within a few fp32 ulps the SIGN of the pre-activation -- i.e. which branch of leaky / ReLU applies -- is
+            # not defined by the data (it flipped with the tile choice of one box in round 5: 0.0145 of scale at one element of
+            # section 276): those elements are left out of the comparison
+            pre_act = (yraw.double() * v(sc).double() + v(sh).double()).float()
+            dact = _act_grad(Lc["act"], pre_act)
             stored_da = rec.get("red_fused") is not None and not rec.get("keep_dz")
             exp_t1 = exp_dz * dact if stored_da else exp_dz
             scale = max(float(exp_t1.abs().max()), 1e-12)
-            rel = float((t1 - exp_t1).abs().max()) / scale
+            diff = (t1 - exp_t1).abs()
+            if stored_da and Lc["act"] in ("leaky", "relu"):
+                ambiguous = pre_act.abs() <= 1e-6 * ((yraw * v(sc)).abs() + v(sh).abs())
+                assert int(ambiguous.sum()) <= max(4, ambiguous.numel() // 1000)
+                if int(ambiguous.sum()):
+                    print("section %d: %d sign-ambiguous pre-activation(s) left out; largest deviation there %.3g of scale, elsewhere %.3g"
+                          % (c, int(ambiguous.sum()), float(diff[ambiguous].max()) / scale, float(diff[~ambiguous].max()) / scale))
+                diff = torch.where(ambiguous, torch.zeros_like(diff), diff)
+            rel = float(diff.max()) / scale
             worst["dz"] = max(worst["dz"], rel)
             assert rel <= (1 + nround) * ULP, "section %d: gradient arriving at the layer off by %.3g of scale (%s)" % (
                 c, rel, "da" if stored_da else "dz")
