@@ -763,6 +763,268 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DykDwDesc d, int CVB)
     }
 }
 
+// LDS-tiled, PERSISTENT stride-1 depthwise weight gradient (bf16, k = 3 | 5; round 5).  The kernel above makes K passes over dy
+// and x (grid.z = kernel row) with 12 sixteen-byte loads in flight per thread and three waves per SIMD: ~0.6 MB in flight over the
+// chip, 0.5-2 TB/s, waiting 0.64-0.74 of its cycles (tools/dw_pmc.sh).  Here a workgroup walks output tiles of TH x 16 pixels for
+// CT <= 8 channel vectors (the geometry of dwconv_tile_kernel): the x patch and the dy tile of the NEXT tile are requested into
+// registers (12 loads per thread, every one issued before anything waits) and stay in flight while the current tile is computed
+// from LDS -- one pass over both tensors, halo re-reads only.  Thread = (channel vector, kernel row kh, pixel lane): K * 8
+// accumulators, a strip of 4 pixels costs 4 + (4 + K - 1) ds_read_b128 for 4 * K * 8 multiply-adds.  Out-of-image patch pixels,
+// pixels beyond the output extent and ragged tiles are zeros in LDS, so no tap needs a bounds test.  Workgroup wg of its channel
+// group owns plane wg (DykDwDesc.part: plain stores, folded in plane order by dyk_grad_reduce -- same sums from run to run);
+// without planes, one fp32 atomic per (tap, channel) and workgroup.
+typedef __bf16 dw_bf16x2_t __attribute__((ext_vector_type(2)));
+template <int K, bool PRE, bool DOT2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dwconv_wgrad_tile_kernel(DykDwDesc d, int CT, int groups, unsigned m_ct, int tiles_x,
+                                                                int tiles_y, int P) {
+    using T = bf16_t;
+    constexpr int EPV = 8, TW = 16, XT = 4, SPR = TW / XT, NS = XT + K - 1, IC = TW + K - 1;
+    constexpr int NLX = K == 5 ? 8 : 6, NLG = 4, NLD = NLX + NLG;
+    extern __shared__ uint4 smem[];
+    const int S = CT | 1;
+    const int TH = (256 / CT) / SPR, IR = TH + K - 1;
+    uint4* patch = smem;                                       // [IR][IC][S]  x
+    uint4* gtile = smem + IR * IC * S;                         // [TH][TW][S]  dy
+    const int tid = threadIdx.x;
+    const int grp = blockIdx.x % groups, wg = blockIdx.x / groups;
+    const int cv0 = grp * CT, CV = d.C / EPV;
+    const T* __restrict__ x = (const T*)d.x;
+    const T* __restrict__ dy = (const T*)d.y;
+    const int ntiles = d.B * tiles_y * tiles_x;
+    // ---- staging roles (the same for every tile): load i of this thread = vector (row, col, ct) of the patch / of the dy tile
+    int role[NLD];                                             // row | col << 8 | ct << 16, -1 = none
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const bool isx = i < NLX;
+        const unsigned idx = tid + (isx ? i : i - NLX) * 256;
+        const unsigned q = CT == 1 ? idx : __umulhi(idx, m_ct);
+        const int ct = (int)(idx - q * CT);
+        const int w = isx ? IC : TW;
+        const int row = (int)(q / w), col = (int)(q - (unsigned)row * w);
+        const bool valid = idx < (unsigned)((isx ? IR * IC : TH * TW) * CT) && cv0 + ct < CV;
+        role[i] = valid ? (row | (col << 8) | (ct << 16)) : -1;
+    }
+    uint4 v[NLD];
+    unsigned okm = 0;
+    auto request = [&](int t) __attribute__((always_inline)) {
+        const int txi = t % tiles_x, r1 = t / tiles_x;
+        const int tyi = r1 % tiles_y, b = r1 / tiles_y;
+        const int y0 = tyi * TH, x0 = txi * TW;
+        const T* ximg = x + (long)b * d.Hi * d.Wi * d.ldx + (long)cv0 * EPV;
+        const T* gimg = dy + (long)b * d.Ho * d.Wo * d.ldy + (long)cv0 * EPV;
+        okm = 0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int ro = role[i] < 0 ? 0 : role[i];
+            const int row = ro & 0xff, col = (ro >> 8) & 0xff, ct = ro >> 16;
+            if (i < NLX) {
+                const int ys = y0 + row - d.pad, xs = x0 + col - d.pad;
+                const bool ok = role[i] >= 0 && ys >= 0 && ys < d.Hi && xs >= 0 && xs < d.Wi;
+                const int yc = ys < 0 ? 0 : (ys >= d.Hi ? d.Hi - 1 : ys), xc = xs < 0 ? 0 : (xs >= d.Wi ? d.Wi - 1 : xs);
+                v[i] = *(const uint4*)(ximg + ((long)yc * d.Wi + xc) * d.ldx + ct * EPV);
+                okm |= ok ? (1u << i) : 0u;
+            } else {
+                const int ys = y0 + row, xs = x0 + col;
+                const bool ok = role[i] >= 0 && ys < d.Ho && xs < d.Wo;
+                const int yc = ys >= d.Ho ? d.Ho - 1 : ys, xc = xs >= d.Wo ? d.Wo - 1 : xs;
+                v[i] = *(const uint4*)(gimg + ((long)yc * d.Wo + xc) * d.ldy + ct * EPV);
+                okm |= ok ? (1u << i) : 0u;
+            }
+        }
+    };
+    // ---- compute role
+    const int cct = tid % CT, rest = tid / CT;
+    const int kh = rest % K, lane = rest / K;
+    const int NL = (256 / CT) / K;
+    const bool active = lane < NL && cv0 + cct < CV;
+    float acc[K][EPV];
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) acc[t][j] = 0.f;
+
+    // DykDwDesc.pre (PRE): x holds the RAW output of the producing conv; z = dtype(act(scale * u + shift)) is formed between the
+    // loads and the LDS stores -- the patch then holds exactly what the separate normalise pass would have stored.  Branch-free
+    // for ReLU / ReLU6 / h-swish / leaky / linear: act(t) = clamp(max(t, leak * t), lo, hi), h-swish t * clamp(t + 3, 0, 6) / 6
+    float* pl = (float*)(smem + (IR * IC + TH * TW) * S);      // [2][CT * 8] scale | shift of this channel group
+    const int pact = d.pre_act;
+    const bool p_generic = !(pact == DYK_ACT_LINEAR || pact == DYK_ACT_RELU || pact == DYK_ACT_RELU6 || pact == DYK_ACT_HSWISH ||
+                             pact == DYK_ACT_LEAKY);
+    const float p_lo = (pact == DYK_ACT_RELU || pact == DYK_ACT_RELU6) ? 0.f : -__builtin_inff();
+    const float p_hi = pact == DYK_ACT_RELU6 ? 6.f : __builtin_inff();
+    const float p_leak = pact == DYK_ACT_LEAKY ? 0.1f : 1.f;
+    const bool p_hsw = pact == DYK_ACT_HSWISH;
+    if constexpr (PRE) {
+        for (int i = tid; i < 2 * CT * 8; i += 256) {
+            const int which = i / (CT * 8), rem = i - which * (CT * 8);
+            const int cch = cv0 * EPV + rem;
+            pl[i] = cch < d.C ? d.pre[(long)which * d.C + cch] : 0.f;
+        }
+    }
+
+    int t = wg;
+    if (t < ntiles) request(t);
+    for (; t < ntiles; t += P) {
+        __syncthreads();                                       // the previous tile's LDS reads are done (and, first trip, pl is there)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            if (role[i] < 0) continue;
+            const int row = role[i] & 0xff, col = (role[i] >> 8) & 0xff, ct = role[i] >> 16;
+            if constexpr (PRE) {
+                if (i < NLX) {
+                    float u[EPV];
+                    vec_unpack<T>(v[i], u);
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) {
+                        const float tt = u[j] * pl[ct * 8 + j] + pl[CT * 8 + ct * 8 + j];
+                        float r = fminf(fmaxf(fmaxf(tt, p_leak * tt), p_lo), p_hi);
+                        if (p_hsw) r = tt * fminf(fmaxf(tt + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                        if (p_generic) r = act_fwd(pact, tt);
+                        u[j] = r;
+                    }
+                    v[i] = vec_pack<T>(u);
+                }
+            }
+            const uint4 z = ((okm >> i) & 1u) ? v[i] : make_uint4(0u, 0u, 0u, 0u);
+            if (i < NLX) patch[(row * IC + col) * S + ct] = z;
+            else gtile[(row * TW + col) * S + ct] = z;
+        }
+        __syncthreads();
+        if (t + P < ntiles) request(t + P);                    // in flight while this tile is computed
+        if (active) {
+#pragma unroll 1
+            for (int s = lane; s < TH * SPR; s += NL) {
+                const int r = s / SPR, strip = s - r * SPR;
+                const uint4* grow = gtile + (r * TW + strip * XT) * S + cct;
+                const uint4* prow = patch + ((r + kh) * IC + strip * XT) * S + cct;
+                if constexpr (DOT2) {
+                    // v_dot2c_f32_bf16: acc += x.lo * g.lo + x.hi * g.hi on the PACKED pairs -- with one half of g masked to zero
+                    // it is the fp32 multiply-add of one channel (a bf16 x bf16 product is exact in fp32: one rounding, as the
+                    // fma), and the x vectors need no unpacking: 8 VALU ops fewer per input vector
+                    unsigned gm[XT][EPV];
+#pragma unroll
+                    for (int o = 0; o < XT; ++o) {
+                        const uint4 gr = grow[o * S];
+                        const unsigned gw[4] = {gr.x, gr.y, gr.z, gr.w};
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) { gm[o][2 * m] = gw[m] & 0xffffu; gm[o][2 * m + 1] = gw[m] & 0xffff0000u; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        const uint4 xr = prow[q * S];
+                        const unsigned xw[4] = {xr.x, xr.y, xr.z, xr.w};
+#pragma unroll
+                        for (int o = 0; o < XT; ++o) {
+                            const int tp = q - o;
+                            if (tp < 0 || tp >= K) continue;
+#pragma unroll
+                            for (int j = 0; j < EPV; ++j)
+                                acc[tp][j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dw_bf16x2_t, xw[j >> 1]),
+                                                                             __builtin_bit_cast(dw_bf16x2_t, gm[o][j]), acc[tp][j], false);
+                        }
+                    }
+                } else {
+                    float g[XT][EPV];
+#pragma unroll
+                    for (int o = 0; o < XT; ++o) vec_unpack<T>(grow[o * S], g[o]);
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        float xv[EPV];
+                        vec_unpack<T>(prow[q * S], xv);
+#pragma unroll
+                        for (int o = 0; o < XT; ++o) {
+                            const int tp = q - o;                      // tap within the kernel row (compile-time after unrolling)
+                            if (tp < 0 || tp >= K) continue;
+#pragma unroll
+                            for (int j = 0; j < EPV; ++j) acc[tp][j] += g[o][j] * xv[j];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- fold the pixel lanes through LDS in lane order, one tap at a time
+    __syncthreads();
+    float* red = (float*)smem;
+#pragma unroll
+    for (int tp = 0; tp < K; ++tp) {
+        float* mine = red + tid * 8;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) mine[j] = acc[tp][j];
+        __syncthreads();
+        if (active && lane == 0) {
+            float sum[EPV];
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) sum[j] = acc[tp][j];
+            for (int q = 1; q < NL; ++q) {
+                const float* o = red + ((q * K + kh) * CT + cct) * 8;
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) sum[j] += o[j];
+            }
+            const int c = (cv0 + cct) * EPV;
+            if (d.part) {
+                float* pp = d.part + ((long)wg * K * K + (kh * K + tp)) * d.C + c;
+                if (((size_t)pp & 15) == 0) {
+                    *(float4*)pp = make_float4(sum[0], sum[1], sum[2], sum[3]);
+                    *(float4*)(pp + 4) = make_float4(sum[4], sum[5], sum[6], sum[7]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) pp[j] = sum[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) unsafeAtomicAdd(d.dw + (long)(kh * K + tp) * d.C + c + j, sum[j]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct DwWgTile { int CT, groups, tiles_x, tiles_y, P; unsigned m_ct; size_t lds; };
+inline int dw_wgrad_tile_target() {
+    static int n = -1;
+    if (n < 0) { const char* e = getenv("DYK_DW_WGRAD_TILE"); n = e ? atoi(e) : 512; }     // workgroups per launch (two resident per CU); 0 = the row kernel
+    return n;
+}
+// geometry of the tiled weight gradient for this problem; false = not eligible (the row kernel runs)
+inline bool dw_wgrad_tile_cfg(const DykDwDesc* d, DwWgTile* c) {
+    const int K = d->k;
+    if (d->dtype != DYK_BF16 || d->stride != 1 || (K != 3 && K != 5) || dw_wgrad_tile_target() <= 0) return false;
+    const int CV = d->C / 8, NLX = K == 5 ? 8 : 6;
+    c->groups = (CV + 7) / 8;
+    c->CT = (CV + c->groups - 1) / c->groups;
+    const int TH = (256 / c->CT) / 4, IR = TH + K - 1, IC = 16 + K - 1, S = c->CT | 1;
+    if (IR * IC * c->CT > NLX * 256 || (256 / c->CT) / K < 1 || IR > 255) return false;
+    c->tiles_x = (d->Wo + 15) / 16;
+    c->tiles_y = (d->Ho + TH - 1) / TH;
+    const long ntiles = (long)d->B * c->tiles_x * c->tiles_y;
+    if (ntiles >= (1L << 30)) return false;
+    long p0 = dw_wgrad_tile_target() / c->groups;
+    if (p0 < 1) p0 = 1;
+    if (p0 > ntiles) p0 = ntiles;
+    const long rounds = (ntiles + p0 - 1) / p0;
+    c->P = (int)((ntiles + rounds - 1) / rounds);
+    c->m_ct = (unsigned)(0xFFFFFFFFu / (unsigned)c->CT) + 1u;
+    c->lds = (size_t)(IR * IC + TH * 16) * S * 16 + (size_t)2 * c->CT * 8 * 4;             // patch | dy tile | pre scale, shift
+    if (c->lds < 256 * 8 * 4) c->lds = 256 * 8 * 4;
+    return c->lds <= 64 * 1024;
+}
+inline int launch_dw_wgrad_tile(const DykDwDesc* d, const DwWgTile& c, hipStream_t s) {
+    const dim3 grid((unsigned)(c.groups * c.P));
+    static int dot2 = -1;
+    if (dot2 < 0) { const char* e = getenv("DYK_DW_WGRAD_DOT2"); dot2 = (e && e[0] == '0') ? 0 : 1; }
+#define DYK_DWW(KK, PP)                                                                                                                  \
+    do {                                                                                                                                  \
+        if (dot2) hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<KK, PP, true>), grid, dim3(256), c.lds, s, *d, c.CT, c.groups, c.m_ct, c.tiles_x, c.tiles_y, c.P); \
+        else hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<KK, PP, false>), grid, dim3(256), c.lds, s, *d, c.CT, c.groups, c.m_ct, c.tiles_x, c.tiles_y, c.P);    \
+    } while (0)
+    if (d->k == 3) { if (d->pre) DYK_DWW(3, true); else DYK_DWW(3, false); }
+    else { if (d->pre) DYK_DWW(5, true); else DYK_DWW(5, false); }
+#undef DYK_DWW
+    DYK_LAUNCH_CHECK();
+    return DYK_OK;
+}
+
 int check_dw(const DykDwDesc* d) {
     if (!d || !d->x || !d->y || d->B <= 0 || d->C <= 0 || d->k <= 0 || d->k > 7 || d->stride <= 0) return DYK_ERR_ARG;
     if (d->dtype != DYK_BF16 && d->dtype != DYK_F32) return DYK_ERR_ARG;
@@ -874,6 +1136,8 @@ extern "C" int dyk_dwconv_wgrad_rows(const DykDwDesc* d) {
     const int rc = check_dw(d);
     if (rc) return rc;
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
+    DwWgTile c;
+    if (dw_wgrad_tile_cfg(d, &c)) return c.P;
     int gx, gy;
     grid2d(d->C / epv, (long)d->B * d->Ho, &gx, &gy, 768 / d->k);
     return gy;
@@ -884,6 +1148,8 @@ extern "C" int dyk_dwconv_wgrad(const DykDwDesc* d, void* stream) {
     if (rc) return rc;
     if (!d->dw) return DYK_ERR_ARG;
     const int epv = d->dtype == DYK_BF16 ? 8 : 4;
+    DwWgTile c;
+    if (dw_wgrad_tile_cfg(d, &c)) return launch_dw_wgrad_tile(d, c, (hipStream_t)stream);
     int gx, gy;
     // few, long-running workgroups: every workgroup ends with one atomic per (tap, channel) on only k*k*C addresses
     const int CVB = grid2d(d->C / epv, (long)d->B * d->Ho, &gx, &gy, 768 / d->k);

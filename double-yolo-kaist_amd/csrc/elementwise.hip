@@ -678,14 +678,22 @@ __global__ __launch_bounds__(256) void se_fc_wgrad_kernel(DykSeFcDesc d) {
 // out[b,p,c] = a[b,p,c]*p0[b*C+c] (+ p1[b*C+c]*alpha)      (SE scale; backward apply with p1 = dpooled, alpha = 1/HW)
 // block = (CVB channel vectors) x (PY pixel lanes), grid (channel groups, pixel groups, B): the per-(image, channel)
 // factors sit in registers, no integer division per element, four pixels in flight per thread (clamped addresses).
-template <typename T>
+// ACT >= -1 (round 5): `out` is the gradient w.r.t. the activated output of a conv + BatchNorm layer whose raw output is `b` and
+// whose scale | shift | mean | rstd vectors are p2[4][C]: the BatchNorm-backward reduce of that layer rides along -- sum(da),
+// sum(da * xhat) with da = out * act'(scale * b + shift), out rounded to the storage type first (what a separate
+// dyk_bn_act_bwd_reduce pass over `out` would read), into the fp64 replicas `red`; `out` itself stays the gradient (the apply
+// pass forms act' again: the keep-dz form of DykConvDesc's DYK_EPI_BNBWD | DYK_EPI_ADDEND).  ACT = -2: no reduce.
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void se_scale_kernel(DykEwDesc d, int CVB) {
     constexpr int EPV = ElemTraits<T>::EPV;
+    constexpr bool RED = ACT >= -1;
+    __shared__ float red[RED ? 256 * 2 * 8 : 8];
     const int PY = 256 / CVB;
     const int tx = threadIdx.x % CVB, ty = threadIdx.x / CVB;
     const int cv = blockIdx.x * CVB + tx;
-    if (cv * EPV >= d.C) return;
-    const int c = cv * EPV;
+    const bool active = cv * EPV < d.C;
+    if (!RED && !active) return;
+    const int c = active ? cv * EPV : 0;
     const int b = blockIdx.z;
     const int HW = d.H * d.W;
     float f0[EPV], f1[EPV];
@@ -700,35 +708,80 @@ __global__ __launch_bounds__(256) void se_scale_kernel(DykEwDesc d, int CVB) {
             f1[j] = f1[j + 1] = f1[j + 2] = f1[j + 3] = 0.f;
         }
     }
+    float sc[EPV], sh[EPV], mu[EPV], rs[EPV], s1[EPV], s2[EPV];
+    if constexpr (RED) {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            sc[j] = d.p2[c + j]; sh[j] = d.p2[d.C + c + j]; mu[j] = d.p2[2 * d.C + c + j]; rs[j] = d.p2[3 * d.C + c + j];
+            s1[j] = s2[j] = 0.f;
+        }
+    }
     const T* __restrict__ a = (const T*)d.a + (long)b * HW * d.lda + c;
+    const T* __restrict__ yr = (const T*)d.b + (long)b * HW * d.ldb + c;
     T* __restrict__ o = (T*)d.out + (long)b * HW * d.ldo + c;
     const bool accum = d.flags & DYK_EW_ACCUM;
     constexpr int U = 4;
     const int pstep = (int)gridDim.y * PY;
-    for (int p0 = (int)blockIdx.y * PY + ty; p0 < HW; p0 += pstep * U) {
-        uint4 va[U], vo[U];
+    if (active) {
+        for (int p0 = (int)blockIdx.y * PY + ty; p0 < HW; p0 += pstep * U) {
+            uint4 va[U], vo[U], vy[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int p = p0 + u * pstep;
-            const long pp = p < HW ? p : p0;
-            va[u] = *(const uint4*)(a + pp * d.lda);
-            if (accum) vo[u] = *(const uint4*)(o + pp * d.ldo);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int p = p0 + u * pstep;
-            if (p >= HW) break;
-            float x[EPV];
-            vec_unpack<T>(va[u], x);
-#pragma unroll
-            for (int j = 0; j < EPV; ++j) x[j] = x[j] * f0[j] + f1[j];
-            if (accum) {
-                float y[EPV];
-                vec_unpack<T>(vo[u], y);
-#pragma unroll
-                for (int j = 0; j < EPV; ++j) x[j] += y[j];
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * pstep;
+                const long pp = p < HW ? p : p0;
+                va[u] = *(const uint4*)(a + pp * d.lda);
+                if (accum) vo[u] = *(const uint4*)(o + pp * d.ldo);
+                if constexpr (RED) vy[u] = *(const uint4*)(yr + pp * d.ldb);
             }
-            *(uint4*)(o + (long)p * d.ldo) = vec_pack<T>(x);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * pstep;
+                if (p >= HW) break;
+                float x[EPV];
+                vec_unpack<T>(va[u], x);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) x[j] = x[j] * f0[j] + f1[j];
+                if (accum) {
+                    float y[EPV];
+                    vec_unpack<T>(vo[u], y);
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) x[j] += y[j];
+                }
+                const uint4 pk = vec_pack<T>(x);
+                *(uint4*)(o + (long)p * d.ldo) = pk;
+                if constexpr (RED) {
+                    float g[EPV], yy[EPV];
+                    vec_unpack<T>(pk, g);
+                    vec_unpack<T>(vy[u], yy);
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) {
+                        const float da = g[j] * act_bwd_c<ACT>(yy[j] * sc[j] + sh[j], d.act);
+                        s1[j] += da;
+                        s2[j] += da * ((yy[j] - mu[j]) * rs[j]);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (RED) {
+        // pixel lanes through LDS in lane order, then one fp64 atomic per channel and sum into this workgroup's replica
+        float* mine = red + threadIdx.x * 2 * 8;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) { mine[j] = s1[j]; mine[8 + j] = s2[j]; }
+        __syncthreads();
+        if (ty == 0 && active) {
+            for (int q = 1; q < PY; ++q) {
+                const float* oo = red + (q * CVB + tx) * 2 * 8;
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) { s1[j] += oo[j]; s2[j] += oo[8 + j]; }
+            }
+            const unsigned wgi = blockIdx.z * gridDim.y + blockIdx.y;
+            double* rd = d.red + (size_t)(wgi % (unsigned)(d.slots > 0 ? d.slots : 1)) * 2 * d.C;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                atomicAdd(rd + c + j, (double)s1[j]);
+                atomicAdd(rd + d.C + c + j, (double)s2[j]);
+            }
         }
     }
 }
@@ -1057,7 +1110,28 @@ extern "C" int dyk_se_scale(const DykEwDesc* d, void* stream) {
     const long cap = 4096 / ((long)gx * d->B) > 0 ? 4096 / ((long)gx * d->B) : 1;
     if (gy > cap) gy = cap;
     if (gy < 1) gy = 1;
-    DISPATCH_T(se_scale_kernel, dim3(gx, (int)gy, d->B), dim3(256), 0, (hipStream_t)stream, *d, CVB);
+    const dim3 grid(gx, (int)gy, d->B);
+    if (d->red) {          // with the BatchNorm-backward reduce of the producer of `out`'s tensor (see the kernel)
+        if (!d->b || !d->p2 || d->ldb % epv_of(d->dtype)) return DYK_ERR_ARG;
+#define DYK_SE_RED(A)                                                                                                     \
+        do {                                                                                                              \
+            if (d->dtype == DYK_BF16) hipLaunchKernelGGL((se_scale_kernel<bf16_t, A>), grid, dim3(256), 0, (hipStream_t)stream, *d, CVB); \
+            else hipLaunchKernelGGL((se_scale_kernel<float, A>), grid, dim3(256), 0, (hipStream_t)stream, *d, CVB);        \
+        } while (0)
+        switch (d->act) {
+        case DYK_ACT_MISH: DYK_SE_RED(DYK_ACT_MISH); break;
+        case DYK_ACT_RELU: DYK_SE_RED(DYK_ACT_RELU); break;
+        case DYK_ACT_HSWISH: DYK_SE_RED(DYK_ACT_HSWISH); break;
+        case DYK_ACT_RELU6: DYK_SE_RED(DYK_ACT_RELU6); break;
+        default: DYK_SE_RED(-1); break;
+        }
+#undef DYK_SE_RED
+        DYK_LAUNCH_CHECK();
+        return DYK_OK;
+    }
+    if (d->dtype == DYK_BF16) hipLaunchKernelGGL((se_scale_kernel<bf16_t, -2>), grid, dim3(256), 0, (hipStream_t)stream, *d, CVB);
+    else hipLaunchKernelGGL((se_scale_kernel<float, -2>), grid, dim3(256), 0, (hipStream_t)stream, *d, CVB);
+    DYK_LAUNCH_CHECK();
     return DYK_OK;
 }
 

@@ -287,15 +287,24 @@ def dwconv_dgrad(dy, w_taps, k, stride, pad, Hi, Wi, *, out=None, accumulate=Fal
     return out
 
 
-def dwconv_wgrad(x, dy, k, stride, pad, *, dw=None, C=None):
+def dwconv_wgrad(x, dy, k, stride, pad, *, dw=None, C=None, planes=False):
+    """depthwise weight gradient [k*k][C] fp32 (accumulated into `dw`).  planes=True: the way the plan runs it -- every workgroup
+    row stores its own partial plane (dyk_dwconv_wgrad_rows of them, DykDwDesc.part); returns the planes [rows][k*k][C]"""
     _require_cuda(x, dy)
     C = C or x.shape[3]
     if dw is None:
         dw = torch.zeros((k * k, C), dtype=torch.float32, device=x.device)
     d = _dw_desc(x, dy, None, k, stride, pad, C)
     d.dw = dw.data_ptr()
+    part = None
+    if planes:
+        rows = load().dyk_dwconv_wgrad_rows(ctypes.byref(d))
+        if rows < 1:
+            raise RuntimeError("dyk_dwconv_wgrad_rows: %d" % rows)
+        part = torch.full((rows, k * k, C), float("nan"), dtype=torch.float32, device=x.device)
+        d.part = part.data_ptr()
     check(load().dyk_dwconv_wgrad(ctypes.byref(d), _stream()), "dyk_dwconv_wgrad")
-    return dw
+    return part if planes else dw
 
 
 # --------------------------------------------------------------------------- elementwise family

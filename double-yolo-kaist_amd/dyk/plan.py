@@ -1275,8 +1275,22 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 if split:
                     plan.bwd.append((L.OP_SE_FC_BWD, fg))
                 gx = gref(x_in)
-                sd = ew_desc(a=dz, out=gx, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W, alpha=1.0 / (x_in.H * x_in.W), flags=acc_flag(x_in))
+                # BatchNorm-backward reduce of the conv + BatchNorm layer that produced x_in inside this launch (dyk_se_scale
+                # with `red`): this block is the only reader of x_in and writes its gradient first (and last); the gradient
+                # stays dz (keep_dz: the apply pass forms act' itself).  22 launches of the MobileNetV3 / 3 of the target cfg
+                prod = producer_of.get(x_in.tid)
+                fuse = (x_in.tid not in ginit and prod is not None and prod.get("bn") and "vecs" in prod
+                        and tcons.get(x_in.tid, 0) == 1 and x_in.C % (16 // es) == 0 and prod["y_raw"].C == C
+                        and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
+                        and os.environ.get("DYK_SE_BNBWD", "1") != "0")
+                sd = ew_desc(a=dz, b=prod["y_raw"] if fuse else None, out=gx, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W,
+                             alpha=1.0 / (x_in.H * x_in.W), flags=acc_flag(x_in), act=prod["act"] if fuse else 0)
                 later(lambda sd=sd, rec=rec, dpooled=dpooled: (setattr(sd, "p0", ws.ptr(rec["scale"])), setattr(sd, "p1", ws.ptr(dpooled))))
+                if fuse:
+                    prod["red_fused"] = new_red(STAT_SLOTS * 2 * C * 8)
+                    prod["keep_dz"] = True
+                    sd.slots = STAT_SLOTS
+                    later(lambda sd=sd, prod=prod: (setattr(sd, "p2", ws.ptr(prod["vecs"])), setattr(sd, "red", ws.ptr(prod["red_fused"]))))
                 plan.bwd.append((L.OP_SE_SCALE, sd))
             elif t == "maxpool":
                 z = rec["z"]

@@ -216,8 +216,8 @@ def accesses(op, d, mem, plan):
             rd(T(d.b, d.ldb, d.C, es))
         for p in (d.p0, d.p1, d.p2, d.p3):
             rd(V(p))
-        if op in (L.OP_BN_BWD_REDUCE, L.OP_DOT):
-            wr(V(d.red))
+        if op in (L.OP_BN_BWD_REDUCE, L.OP_DOT) or (op == L.OP_SE_SCALE and d.red):
+            wr(V(d.red))                         # (dyk_se_scale with the fused BatchNorm-backward reduce adds to the replicas)
         else:
             rd(V(d.red))
         if op == L.OP_BN_BWD_APPLY:

@@ -365,6 +365,11 @@ int dyk_maxpool_bwd(const DykEwDesc* desc, const uint8_t* argmax, void* stream);
  *   dyk_se_fc_fwd : scale = hardsigmoid(W2 relu(W1 pooled + b1) + b2); two launches that spread the rows of W1 / W2 over
  *                   the chip.  Needs `ws` (B*(C + 2*Cs) floats): h = relu(..) and t2 = W2 h + b2 are parked there
  *   dyk_se_scale  : out[b,hw,c] = a[b,hw,c]*p0[b*C+c] (+ alpha*p1[b*C+c])
+ *                   With desc->red set (backward of a block whose input is the activated output of a conv + BatchNorm layer,
+ *                   autograd of models.py:47-56 behind layers.py:188): b = that layer's raw conv output, p2 = its
+ *                   scale | shift | mean | rstd vectors [4][C], act = its activation; sum(da), sum(da * xhat) with
+ *                   da = out * act'(scale * b + shift) go to the `slots` fp64 replicas red[slots][2][C] exactly as
+ *                   dyk_bn_act_bwd_reduce over `out` would leave them; `out` itself stays the gradient
  *   dyk_se_fc_bwd : from dscale = d(loss)/d(scale) produce dpooled and accumulate dW1,db1,dW2,db2.  MUST follow
  *                   dyk_se_fc_fwd on the same `ws` (it reads the h and t2 the forward call parked; nothing is
  *                   recomputed).  Three launches: dt1 = relu'(h) * W2^T (dscale * hardsigmoid'(t2)) -> ws,

@@ -177,6 +177,8 @@ DW_CASES = [
     (1, 24, 50, 37, 5, 1, 2),       # 3 channel vectors per workgroup (odd group width), several tiles per image
     (1, 184, 20, 19, 5, 1, 2),      # 23 channel vectors: three groups of 8, the last one partly filled
     (2, 8, 70, 18, 3, 1, 1),        # a single channel vector (64-row tiles)
+    (16, 120, 33, 50, 5, 1, 2),     # persistent tiled weight gradient: two tiles per workgroup, ragged tiles both ways
+    (4, 16, 256, 320, 3, 1, 1),     # ... three tiles per workgroup at the MobileNetV3 cfg's first depthwise layer
 ]
 
 
@@ -228,6 +230,12 @@ def test_depthwise_conv_fwd_dgrad_wgrad(case, dtype):
     dw_ref = w.grad.reshape(C, k * k).t()
     err = (dw.cpu() - dw_ref).abs().max().item()
     assert err <= 1e-4 * max(1.0, dw_ref.abs().max().item()), "wgrad max err %g" % err
+    # the way the plan runs it: one partial plane per workgroup row, every plane fully written, same planes from run to run
+    parts = ops.dwconv_wgrad(xd, dyd, k, s, pad, C=C, planes=True)
+    assert not torch.isnan(parts).any(), "a partial plane was left unwritten"
+    err = (parts.double().sum(0).float().cpu() - dw_ref).abs().max().item()
+    assert err <= 1e-4 * max(1.0, dw_ref.abs().max().item()), "wgrad planes max err %g" % err
+    assert torch.equal(parts, ops.dwconv_wgrad(xd, dyd, k, s, pad, C=C, planes=True))
 
 
 @pytest.mark.parametrize("case", [(2, 64, 128, 16, 20, 3, 1), (1, 128, 96, 17, 23, 3, 1), (3, 64, 64, 9, 13, 1, 1),

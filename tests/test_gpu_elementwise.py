@@ -420,3 +420,41 @@ def test_head_permute_patch_gather_decode():
         err = ((got - ref.view(B, -1, no)).abs() / ref.view(B, -1, no).abs().clamp(min=1.0)).max().item()
         assert err < 2e-6, err
         assert io[:, :50].abs().max().item() == 0 and io[:, 50 + na * ny * nx:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("act", ["mish", "hard-swish", "relu6", "leaky"])
+@pytest.mark.parametrize("B,C,H,W", [(3, 64, 6, 8), (2, 72, 33, 17), (4, 960, 4, 5)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_se_scale_backward_carries_the_batchnorm_backward_reduce(dtype, B, C, H, W, act):
+    """dyk_se_scale with `red` (the squeeze-excitation backward of a block fed by conv + BatchNorm, autograd of
+    layers.py:188 behind models.py:47-56): the gradient it stores is the one the plain call stores, and the replica sums equal
+    what dyk_bn_act_bwd_reduce computes from that stored gradient"""
+    from dyk import ops
+    g = torch.Generator().manual_seed(17)
+    cpad = (C + 31) // 32 * 32
+    dz = ops.to_nhwc(torch.randn(B, C, H, W, generator=g).cuda(), dtype, cpad=cpad)
+    y = ops.to_nhwc((2.0 * torch.randn(B, C, H, W, generator=g)).cuda(), dtype, cpad=cpad)       # raw output of the producer
+    old = ops.to_nhwc(torch.randn(B, C, H, W, generator=g).cuda(), dtype, cpad=cpad)
+    s = torch.rand(B, C, generator=g).cuda()
+    dpooled = torch.randn(B, C, generator=g).cuda()
+    vecs = torch.cat([1.0 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g),
+                      0.1 * torch.randn(C, generator=g), 1.0 + 0.1 * torch.rand(C, generator=g)]).cuda()   # scale | shift | mean | rstd
+    slots = 8
+    for accumulate in (False, True):
+        plain = old.clone()
+        ops.call("dyk_se_scale", ops.ew_desc(a=dz, out=plain, C=C, p0=s, p1=dpooled, alpha=1.0 / (H * W), B=B, H=H, W=W,
+                                             flags=1 if accumulate else 0))
+        fused = old.clone()
+        red = torch.zeros(slots * 2 * C, dtype=torch.float64, device="cuda")
+        d = ops.ew_desc(a=dz, b=y, out=fused, C=C, p0=s, p1=dpooled, p2=vecs, red=red, act=act, alpha=1.0 / (H * W), B=B, H=H, W=W,
+                        flags=1 if accumulate else 0)
+        d.slots = slots
+        ops.call("dyk_se_scale", d)
+        assert torch.equal(fused, plain)
+        ref = torch.zeros_like(red)
+        r = ops.ew_desc(a=plain, b=y, C=C, act=act, p0=vecs[:C], p1=vecs[C:2 * C], p2=vecs[2 * C:3 * C], p3=vecs[3 * C:], red=ref)
+        r.slots = slots
+        ops.call("dyk_bn_act_bwd_reduce", r)
+        got, want = red.view(slots, 2, C).sum(0), ref.view(slots, 2, C).sum(0)
+        scale = want.abs().max().item() + 1.0
+        assert (got - want).abs().max().item() <= 1e-5 * scale, (got - want).abs().max().item() / scale

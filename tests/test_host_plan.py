@@ -106,6 +106,7 @@ def test_plan_compiles_consistently(name, training, one_launch, monkeypatch):
         assert bops[0] == L.OP_MEMSET
         assert bops.count(L.OP_WGRAD) == n_conv - n_stem and bops.count(L.OP_STEM_WGRAD) == n_stem
         n_fused = sum(1 for op, d in plan.bwd if op == L.OP_CONV and d.flags & L.EPI_BNBWD and d.ooy == 0 and d.oox == 0)
+        n_fused += sum(1 for op, d in plan.bwd if op == L.OP_SE_SCALE and d.red)     # (squeeze-excitation backward carrying it)
         assert bops.count(L.OP_BN_BWD_APPLY) == n_bn and bops.count(L.OP_BN_BWD_REDUCE) + n_fused == n_bn and n_fused > 0
         assert bops.count(L.OP_BN_BWD_PARAMS) == 0
         # every data-gradient launch either stores or accumulates; the first write into each buffer stores
@@ -386,8 +387,9 @@ num=3
 
 @pytest.mark.parametrize("name", [C3, C5, C1])
 def test_every_batchnorm_backward_apply_has_exactly_one_reduce(name):
-    """The BN-backward reduce of a layer runs in one of four places: its own pass, the epilogue of the data gradient that
-    produces dz (DYK_EPI_BNBWD), the depthwise data gradient (DykDwDesc.res), or -- dz with several contributors -- the
+    """The BN-backward reduce of a layer runs in one of five places: its own pass, the epilogue of the data gradient that
+    produces dz (DYK_EPI_BNBWD), the depthwise data gradient (DykDwDesc.res), the squeeze-excitation backward that produces dz
+    (dyk_se_scale with `red`), or -- dz with several contributors -- the
     LAST accumulating data gradient in chain mode (add == its own output, plan._fuse_late_reduces).  Whatever the form:
     the replicas an apply pass folds are written by exactly one earlier command, and a chain-mode launch is the last
     writer of its gradient tensor before that apply pass."""
@@ -407,6 +409,8 @@ def test_every_batchnorm_backward_apply_has_exactly_one_reduce(name):
             writers.setdefault(d.stats, []).append((q, "chain" if d.flags & L.EPI_ADDEND and d.add == d.y else "epilogue"))
         elif op == L.OP_DW_DGRAD and d.res:
             writers.setdefault(d.stats, []).append((q, "depthwise"))
+        elif op == L.OP_SE_SCALE and d.red:
+            writers.setdefault(d.red, []).append((q, "squeeze-excitation"))
     kinds = []
     n_apply = 0
     for q, (op, d) in enumerate(plan.bwd):

@@ -21,7 +21,17 @@ for (C, H, W, k, s) in [(16, 256, 320, 3, 1), (64, 256, 320, 3, 2), (72, 128, 16
     ms_f = t(lambda: ops.dwconv_fwd(x, w, k, s, pad, C=C))
     ms_alloc = t(lambda: torch.zeros_like(y))
     ms_d = t(lambda: ops.dwconv_dgrad(y, w, k, s, pad, H, W, C=C))
-    ms_w = t(lambda: ops.dwconv_wgrad(x, y, k, s, pad, C=C))
+    # the weight gradient the way the plan launches it: descriptor built once, partial planes, no allocation in the loop
+    import ctypes
+    from dyk import lib as L
+    lib = L.load()
+    dwd = ops._dw_desc(x, y, None, k, s, pad, C)
+    dw = torch.zeros(k * k, C, device="cuda")
+    rows = lib.dyk_dwconv_wgrad_rows(ctypes.byref(dwd))
+    part = torch.zeros(rows, k * k, C, device="cuda")
+    dwd.dw, dwd.part = dw.data_ptr(), part.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    ms_w = t(lambda: lib.dyk_dwconv_wgrad(ctypes.byref(dwd), st), n=20)
     by = (x.numel() + y.numel()) * 2
-    print("C %4d %3dx%-3d k%d s%d: fwd %.1f us (%.0f GB/s; zeros %.1f us) dgrad %.1f us wgrad %.1f us  [bytes %.0f MB]" % (
-        C, H, W, k, s, ms_f * 1e3, by / ms_f / 1e6, ms_alloc * 1e3, ms_d * 1e3, ms_w * 1e3, by / 1e6))
+    print("C %4d %3dx%-3d k%d s%d: fwd %.1f us (%.0f GB/s; zeros %.1f us) dgrad %.1f us wgrad %.1f us (%d planes)  [bytes %.0f MB]" % (
+        C, H, W, k, s, ms_f * 1e3, by / ms_f / 1e6, ms_alloc * 1e3, ms_d * 1e3, ms_w * 1e3, rows, by / 1e6))
