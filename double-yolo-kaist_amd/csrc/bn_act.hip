@@ -311,7 +311,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwPair pr, int
         const int c_base = blockIdx.x * CVB * EPV;
         const int nch = min(CVB * EPV, d.C - c_base);
         const int slots = d.slots > 0 ? d.slots : 1;
-        const size_t rs = (size_t)2 * d.C;
+        // replicas [slots][2][C] of this layer's own reduction -- or columns of a wider one (the joint reduction over the
+        // sections a [route] concatenates, DYK_EPI_BNBWD of the route's reader): H = replica stride, W = offset of the second sum
+        const size_t rs = d.H > 0 ? (size_t)d.H : (size_t)2 * d.C;
+        const size_t so = d.W > 0 ? (size_t)d.W : (size_t)d.C;
         for (int cl = threadIdx.x; cl < nch; cl += 256) {
             const double* p = d.red + c_base + cl;
             // both sums of a channel, 16 replicas each, requested back to back: ONE L2 round trip in front of the pixel loop for the
@@ -322,15 +325,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(DykEwPair pr, int
             for (; r + 16 <= slots; r += 16) {
                 double v[2][16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) { v[0][u] = p[(size_t)(r + u) * rs]; v[1][u] = p[(size_t)(r + u) * rs + d.C]; }
+                for (int u = 0; u < 16; ++u) { v[0][u] = p[(size_t)(r + u) * rs]; v[1][u] = p[(size_t)(r + u) * rs + so]; }
 #pragma unroll
                 for (int u = 0; u < 16; ++u) { a8[0][u & 7] += v[0][u]; a8[1][u & 7] += v[1][u]; }
             }
             for (; r + 8 <= slots; r += 8) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { a8[0][u] += p[(size_t)(r + u) * rs]; a8[1][u] += p[(size_t)(r + u) * rs + d.C]; }
+                for (int u = 0; u < 8; ++u) { a8[0][u] += p[(size_t)(r + u) * rs]; a8[1][u] += p[(size_t)(r + u) * rs + so]; }
             }
-            for (; r < slots; ++r) { a8[0][0] += p[(size_t)r * rs]; a8[1][0] += p[(size_t)r * rs + d.C]; }
+            for (; r < slots; ++r) { a8[0][0] += p[(size_t)r * rs]; a8[1][0] += p[(size_t)r * rs + so]; }
 #pragma unroll
             for (int which = 0; which < 2; ++which) {
                 const double acc = ((a8[which][0] + a8[which][1]) + (a8[which][2] + a8[which][3])) + ((a8[which][4] + a8[which][5]) + (a8[which][6] + a8[which][7]));

@@ -291,6 +291,26 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         if md["type"] != "route" and j > 0:
             nrefs[j - 1] += 1
 
+    # ---- joint BatchNorm backward over a concatenation (round 5).  A multi-source [route] whose sources are all plain conv +
+    # BatchNorm + (one common) activation sections that write their slice of the concat buffer in place and are read by
+    # nobody else: the data gradient of the route's only reader produces the gradient of ALL of them in one launch, so it can
+    # carry their BatchNorm-backward reduces in its epilogue (DYK_EPI_BNBWD over the concatenated channels) -- if their raw
+    # outputs are channel slices of ONE buffer and their scale / shift / mean / rstd vectors sit side by side.  Decided here
+    # (layout), confirmed at the route (every source took its slot) and in the backward (sole reader, first writer).
+    joint_slot, joint_raw, joint_vecs, joint_of = {}, {}, {}, {}
+    if (training and os.environ.get("DYK_JOINT_BNBWD", "1") != "0" and not os.environ.get("DYK_DEBUG_PLAN")
+            and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"):
+        for j, md in enumerate(defs):
+            if md["type"] != "route" or len(mods[j].layers) < 2:
+                continue
+            srcs_ = list(mods[j].layers)
+            ok = all(concat_slot.get(q, (None,))[0] == j and nrefs[q] == 1 and defs[q]["type"] == "convolutional"
+                     and defs[q]["batch_normalize"] and defs[q].get("groups", 1) == 1 and q != 0 and q != second
+                     and chans[q] % 8 == 0 for q in srcs_)
+            if ok and len({defs[q]["activation"] for q in srcs_}) == 1:
+                for q in srcs_:
+                    joint_slot[q] = concat_slot[q]
+
     def alloc_out(layer, Bn, Hn, Wn, C):
         """output tensor of cfg section `layer`: a slice of its concat buffer when it has one"""
         slot = concat_slot.get(layer)
@@ -469,7 +489,17 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             conv_op = L.OP_CONV
         if bn:
             if training:
-                y_raw = new_act(B, Ho, Wo, cout)
+                js = joint_slot.get(out_layer) if (not dw and not direct and stem_src is None and out_ref is None) else None
+                if js is not None:
+                    jj, jc0, jctot = js
+                    if jj not in joint_raw:
+                        joint_raw[jj] = new_act(B, Ho, Wo, jctot)
+                        joint_vecs[jj] = new_ws(4 * jctot * 4)
+                    assert (joint_raw[jj].H, joint_raw[jj].W) == (Ho, Wo)
+                    y_raw = joint_raw[jj].chan_slice(jc0, cout)
+                    rec["joint"] = jj
+                else:
+                    y_raw = new_act(B, Ho, Wo, cout)
                 z = None if defer_to_dw(i, out_layer, out_ref, B, Ho, Wo, cout, dw, direct) else (
                     out_ref if out_ref is not None else alloc_out(out_layer, B, Ho, Wo, cout))
                 # replicas of the fp64 statistics accumulators: keep the atomics per address at a few dozen
@@ -480,7 +510,11 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     slots = DW_SLOTS                 # 32 replicas: the finalize then rides on the normalise pass (measured
                                                      # -0.3 ms per MobileNetV3 step against up to 256 replicas + own launch)
                 stats = st_arena.alloc(slots * 2 * cout * 8)   # fp64 replicas; the whole arena is zeroed at the start of a pass
-                vecs = new_ws(4 * cout * 4)          # scale | shift | mean | rstd
+                if js is not None:                   # this layer's columns of the route's scale | shift | mean | rstd rows
+                    vecs, vs = joint_vecs[jj] + 4 * jc0, 4 * jctot
+                else:
+                    vecs, vs = new_ws(4 * cout * 4), 4 * cout      # scale | shift | mean | rstd, `vs` bytes apart
+                rec["vs"] = vs
                 d.ldy, d.stats_slots = y_raw.ld, slots
                 if not dw and not direct:
                     d.act, d.flags = 0, L.EPI_STATS
@@ -500,8 +534,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     d.bn_count, d.bn_momentum, d.bn_eps = B * Ho * Wo, BN_MOMENTUM, BN_EPS
                     d.ldy2 = z.ld
                     later(lambda d=d, z=z, vecs=vecs, cnt=cnt: (
-                        setattr(d, "y2", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)), setattr(d, "shift", ws.ptr(vecs + 4 * cout)),
-                        setattr(d, "bn_save_mean", ws.ptr(vecs + 8 * cout)), setattr(d, "bn_save_rstd", ws.ptr(vecs + 12 * cout)),
+                        setattr(d, "y2", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)), setattr(d, "shift", ws.ptr(vecs + vs)),
+                        setattr(d, "bn_save_mean", ws.ptr(vecs + 2 * vs)), setattr(d, "bn_save_rstd", ws.ptr(vecs + 3 * vs)),
                         setattr(d, "bn_counter", ws.ptr(cnt))))
                     plan.has_bnfwd = True
                 if direct:
@@ -520,10 +554,10 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 f.gamma, f.beta = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
                 f.running_mean, f.running_var = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
                 f.C, f.count, f.momentum, f.eps, f.slots = cout, B * Ho * Wo, BN_MOMENTUM, BN_EPS, slots
-                later(lambda f=f, stats=stats, vecs=vecs: (
+                later(lambda f=f, stats=stats, vecs=vecs, vs=vs: (
                     setattr(f, "stats", st_arena.ptr(stats)), setattr(f, "scale", ws.ptr(vecs)),
-                    setattr(f, "shift", ws.ptr(vecs + 4 * cout)), setattr(f, "save_mean", ws.ptr(vecs + 8 * cout)),
-                    setattr(f, "save_rstd", ws.ptr(vecs + 12 * cout))))
+                    setattr(f, "shift", ws.ptr(vecs + vs)), setattr(f, "save_mean", ws.ptr(vecs + 2 * vs)),
+                    setattr(f, "save_rstd", ws.ptr(vecs + 3 * vs))))
                 if defer_to_dw(i, out_layer, out_ref, B, Ho, Wo, cout, dw, direct):
                     # Normalise + activation ON LOAD in the consumer (VERDICT r4 #3a): this block's only reader is a stride-1
                     # depthwise conv on the LDS-tiled kernel (MobileNet expansion conv -> depthwise, reference models.py:34-62
@@ -538,7 +572,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     producer_of[z.tid] = rec
                     return z, rec
                 a = ew_desc(a=y_raw, out=z, act=act)
-                later(lambda a=a, vecs=vecs: (setattr(a, "p0", ws.ptr(vecs)), setattr(a, "p1", ws.ptr(vecs + 4 * cout))))
+                later(lambda a=a, vecs=vecs, vs=vs: (setattr(a, "p0", ws.ptr(vecs)), setattr(a, "p1", ws.ptr(vecs + vs))))
                 if slots <= 32 and os.environ.get("DYK_BN_FUSED_FWD", "1") != "0":
                     fm = misc()                       # finalize folded into the normalise + activation launch
                     fm.p[0], fm.p[1] = ctypes.addressof(f), ctypes.addressof(a)
@@ -695,6 +729,13 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     c0 += s.C
                 cur = cat
                 rec.update(parts=parts, out=cat)
+                if i in joint_raw and all(info[j].get("joint") == i for j in layers):
+                    c0 = 0
+                    jparts = []
+                    for j in layers:
+                        jparts.append((info[j], c0))
+                        c0 += info[j]["cout"]
+                    joint_of[cat.tid] = dict(raw=joint_raw[i], vecs=joint_vecs[i], ctot=ctot, parts=jparts, act=info[layers[0]]["act"])
         elif t == "shortcut":
             layers = mod.layers
             x_in = cur
@@ -951,7 +992,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 # writer of the gradient) -- LDS-tiled kernel only: stride 1, 3x3 / 5x5, bf16
                 prod = producer_of.get(x_in.tid)
                 if (first and prod is not None and prod is not rec and tcons.get(x_in.tid, 0) == 1
-                        and stride == 1 and k in (3, 5) and code == L.DYK_BF16 and "vecs" in prod
+                        and stride == 1 and k in (3, 5) and code == L.DYK_BF16 and "vecs" in prod and prod["vs"] == 4 * x_in.C
                         and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
                         and os.environ.get("DYK_DW_TILE", "1") != "0" and os.environ.get("DYK_DW_BNBWD", "1") != "0"):
                     prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
@@ -1033,6 +1074,19 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             if fuse:
                 prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
                 prod["keep_dz"] = addend is not None
+                bw = dict(act=prod["act"], raw=prod["y_raw"], vecs=prod["vecs"], vs=prod["vs"], red=prod["red_fused"])
+            # ... or of ALL the conv + BatchNorm sections concatenated into x_in (joint_of, decided in the forward): one launch,
+            # replicas [slots][2][ctot]; every section's apply pass folds its own columns (DykEwDesc.H / W: replica stride and
+            # offset of the second sum)
+            jr = joint_of.get(x_in.tid) if not fuse else None
+            if (jr is not None and first and tcons.get(x_in.tid, 0) == 1 and x_in.C == jr["ctot"] and x_in.C % (16 // es) == 0
+                    and all(tcons.get(pr_["z"].tid, 0) == 1 and pr_["z"].tid not in grads and pr_["z"].tid not in ginit
+                            for pr_, _ in jr["parts"])):
+                fuse = True
+                jred = new_red(STAT_SLOTS * 2 * jr["ctot"] * 8)
+                for pr_, c0_ in jr["parts"]:
+                    pr_["red_fused"], pr_["red_geom"], pr_["keep_dz"] = jred + 8 * c0_, (2 * jr["ctot"], jr["ctot"]), False
+                bw = dict(act=jr["act"], raw=jr["raw"], vecs=jr["vecs"], vs=4 * jr["ctot"], red=jred)
             classes = dgrad_classes(k, pad, stride, x_in.H, x_in.W)
             # the parity classes of a strided conv's data gradient in one launch (DykConvDesc.ncls) when they all have
             # taps, share the launch grid and fit the tap table
@@ -1067,15 +1121,14 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 d.act, d.flags = 0, (0 if first else L.EPI_ACCUM)
                 later(lambda d=d, dy=dy, gx=gx: (setattr(d, "x", ptr_of(dy)), setattr(d, "y", ptr_of(gx))))
                 if fuse:
-                    pc, pv, pr = x_in.C, prod["vecs"], prod["red_fused"]
-                    d.act, d.flags, d.stats_slots, d.ldr = prod["act"], L.EPI_BNBWD, STAT_SLOTS, prod["y_raw"].ld
+                    d.act, d.flags, d.stats_slots, d.ldr = bw["act"], L.EPI_BNBWD, STAT_SLOTS, bw["raw"].ld
                     if addend is not None:
                         d.flags |= L.EPI_ADDEND
                         later(lambda d=d, ad=addend[0]: setattr(d, "add", ptr_of(ad)))
-                    later(lambda d=d, prod=prod, pc=pc, pv=pv, pr=pr: (
-                        setattr(d, "res", ptr_of(prod["y_raw"])), setattr(d, "scale", ws.ptr(pv)),
-                        setattr(d, "shift", ws.ptr(pv + 4 * pc)), setattr(d, "aux0", ws.ptr(pv + 8 * pc)),
-                        setattr(d, "aux1", ws.ptr(pv + 12 * pc)), setattr(d, "stats", ws.ptr(pr))))
+                    later(lambda d=d, bw=bw: (
+                        setattr(d, "res", ptr_of(bw["raw"])), setattr(d, "scale", ws.ptr(bw["vecs"])),
+                        setattr(d, "shift", ws.ptr(bw["vecs"] + bw["vs"])), setattr(d, "aux0", ws.ptr(bw["vecs"] + 2 * bw["vs"])),
+                        setattr(d, "aux1", ws.ptr(bw["vecs"] + 3 * bw["vs"])), setattr(d, "stats", ws.ptr(bw["red"]))))
                 plan.bwd.append((L.OP_CONV, d))
             ginit.add(x_in.tid)
 
@@ -1096,9 +1149,9 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     red = new_red(STAT_SLOTS * 2 * cout * 8)
                     r = ew_desc(a=dz, b=rec["y_raw"], act=rec["act"])
                     r.slots = STAT_SLOTS
-                    later(lambda r=r, vecs=vecs, red=red, cout=cout: (
-                        setattr(r, "p0", ws.ptr(vecs)), setattr(r, "p1", ws.ptr(vecs + 4 * cout)),
-                        setattr(r, "p2", ws.ptr(vecs + 8 * cout)), setattr(r, "p3", ws.ptr(vecs + 12 * cout)),
+                    later(lambda r=r, vecs=vecs, red=red, vs=rec["vs"]: (
+                        setattr(r, "p0", ws.ptr(vecs)), setattr(r, "p1", ws.ptr(vecs + vs)),
+                        setattr(r, "p2", ws.ptr(vecs + 2 * vs)), setattr(r, "p3", ws.ptr(vecs + 3 * vs)),
                         setattr(r, "red", ws.ptr(red))))
                     plan.bwd.append((L.OP_BN_BWD_REDUCE, r))
                 dyr = dz
@@ -1113,9 +1166,11 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 # the apply pass folds the replicas of the reduction itself and adds them to dgamma / dbeta
                 ap.slots = STAT_SLOTS
                 ap.aux, ap.aux2 = store.g_ptr(bnpre + "weight"), store.g_ptr(bnpre + "bias")
-                later(lambda ap=ap, vecs=vecs, red=red, cout=cout: (
-                    setattr(ap, "p0", ws.ptr(vecs)), setattr(ap, "p1", ws.ptr(vecs + 4 * cout)),
-                    setattr(ap, "p2", ws.ptr(vecs + 8 * cout)), setattr(ap, "p3", ws.ptr(vecs + 12 * cout)),
+                if rec.get("red_geom"):           # the replicas are columns of a route's joint reduction (emit_conv_backward)
+                    ap.H, ap.W = rec["red_geom"]
+                later(lambda ap=ap, vecs=vecs, red=red, vs=rec["vs"]: (
+                    setattr(ap, "p0", ws.ptr(vecs)), setattr(ap, "p1", ws.ptr(vecs + vs)),
+                    setattr(ap, "p2", ws.ptr(vecs + 2 * vs)), setattr(ap, "p3", ws.ptr(vecs + 3 * vs)),
                     setattr(ap, "red", ws.ptr(red))))
                 plan.bwd.append((L.OP_BN_BWD_APPLY, ap))
                 # (the stem's weight gradient can do this pass on the fly: emit_conv_backward below, DykStemDesc.bn_fused)
@@ -1279,7 +1334,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 # with `red`): this block is the only reader of x_in and writes its gradient first (and last); the gradient
                 # stays dz (keep_dz: the apply pass forms act' itself).  22 launches of the MobileNetV3 / 3 of the target cfg
                 prod = producer_of.get(x_in.tid)
-                fuse = (x_in.tid not in ginit and prod is not None and prod.get("bn") and "vecs" in prod
+                fuse = (x_in.tid not in ginit and prod is not None and prod.get("bn") and "vecs" in prod and prod["vs"] == 4 * C
                         and tcons.get(x_in.tid, 0) == 1 and x_in.C % (16 // es) == 0 and prod["y_raw"].C == C
                         and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
                         and os.environ.get("DYK_SE_BNBWD", "1") != "0")

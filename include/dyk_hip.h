@@ -327,7 +327,10 @@ int dyk_bn_act_fwd(const DykEwDesc* desc, void* stream);
  * p2 = mean, p3 = rstd.  reduce: red[c] += sum dact, red[C+c] += sum dact*xhat with
  * dact = dz*act'(y*scale+shift), spread over `slots` replicas of red (2C doubles each);
  * params: folds the replicas into replica 0, then dbeta += red[c], dgamma += red[C+c];
- * apply: out = scale*(dact - red[c]/npix - xhat*red[C+c]/npix). */
+ * apply: out = scale*(dact - red[c]/npix - xhat*red[C+c]/npix).  The fused form (slots > 0) may read its sums as COLUMNS of
+ * a wider set of replicas -- the joint reduction a convolution's DYK_EPI_BNBWD epilogue leaves for all the conv + BatchNorm
+ * sections a [route] concatenates (reference models.py:116-124 / layers.py:40-48): desc->H = replica stride in doubles
+ * (0 = 2C), desc->W = offset of sum(dact*xhat) from sum(dact) (0 = C), `red` points at this layer's first column. */
 int dyk_bn_act_bwd_reduce(const DykEwDesc* desc, void* stream);
 int dyk_bn_bwd_params(double* red, float* dgamma, float* dbeta, int32_t C, int32_t slots, void* stream);
 int dyk_bn_act_bwd_apply(const DykEwDesc* desc, void* stream);

@@ -100,9 +100,9 @@ def test_bf16_training_backward_section_by_section_against_oracle(monkeypatch):
     ws = plan.arenas["ws"].tensor
 
     def vec4(rec):                      # scale | shift | saved mean | saved rstd of a train-mode BatchNorm
-        c = rec["cout"]
-        v = ws[rec["vecs"]:rec["vecs"] + 16 * c].view(torch.float32).cpu()
-        return v[:c], v[c:2 * c], v[2 * c:3 * c], v[3 * c:4 * c]
+        c, o, vs = rec["cout"], rec["vecs"], rec["vs"]      # (vs: bytes between the four vectors -- sections concatenated by a
+        #                                                       [route] keep theirs as columns of the route's rows)
+        return tuple(ws[o + q * vs:o + q * vs + 4 * c].view(torch.float32).cpu() for q in range(4))
 
     # ---- the HIP path's forward tensors as leaves of the oracle's section functions
     fwd = {}
@@ -134,6 +134,12 @@ def test_bf16_training_backward_section_by_section_against_oracle(monkeypatch):
     checked = {"dz": 0, "bn": 0, "dw": 0, "other": 0}
     worst = {"dz": 0.0, "dy": 0.0, "dw": 0.0, "dgb": 0.0}
     conv_up = {}                         # conv section -> gradient w.r.t. its raw output (what its dgrad / wgrad consumed)
+    # [route] sections whose sources' BatchNorm-backward reduces ride TOGETHER on the data gradient of the route's reader
+    # (plan.py: joint_of): the HIP-side gradient buffer of the concatenation then holds da = dz * act' of all its sources, never
+    # dz.  What the route hands to its sources is therefore taken from THIS side: the reader's contribution to the route
+    # (oracle data gradient of the HIP side's own upstream gradient), sliced; the sources' checks below hold the stored da to it
+    joint_routes = {c for c in range(nsec) if net.layers[c]["kind"] == "route" and len(net.layers[c]["layers"]) > 1
+                    and all(info[j].get("red_geom") for j in net.layers[c]["layers"])}
     for c in range(nsec):
         rec, Lc = info[c], net.layers[c]
         kind = Lc["kind"]
@@ -154,6 +160,8 @@ def test_bf16_training_backward_section_by_section_against_oracle(monkeypatch):
         else:
             if kind == "route" and len(Lc["layers"]) == 1:
                 continue                                       # alias: its consumers point at the source below
+            if c in joint_routes:
+                continue                                       # (second pass below)
             up = grad_of(plan.outs[c])
             if up is None:
                 continue
@@ -173,6 +181,15 @@ def test_bf16_training_backward_section_by_section_against_oracle(monkeypatch):
                     got = G(key).reshape(gw.shape)
                     assert float((got - gw).abs().max()) <= 5e-3 * max(float(gw.abs().max()), 1e-6), (key,)
 
+    for c in sorted(joint_routes):
+        if plan.outs[c] is None or plan.grads.get(plan.outs[c].tid) is None or c not in contrib:
+            continue
+        ins = [j for j in inputs_of(c)]
+        gl = torch.autograd.grad(every[c], [leaves[j] for j in ins], grad_outputs=sum(contrib[c]), retain_graph=True, allow_unused=True)
+        for j, gj in zip(ins, gl):
+            if gj is not None:
+                add(j, gj)
+
     def source(j):                       # single-source [route] sections stand for their source
         while net.layers[j]["kind"] == "route" and len(net.layers[j]["layers"]) == 1:
             j = net.layers[j]["layers"][0]
@@ -189,8 +206,9 @@ def test_bf16_training_backward_section_by_section_against_oracle(monkeypatch):
         kind = Lc["kind"]
         if kind == "yolo" or (kind == "route" and len(Lc["layers"]) == 1) or plan.outs[c] is None:
             continue
-        if info[c].get("fused"):
-            continue                                            # fused [shortcut]: shares tensor and gradient with its conv
+        if info[c].get("fused") or c in joint_routes:
+            continue                                            # fused [shortcut]: shares tensor and gradient with its conv;
+            #                                                     joint route: its buffer holds the sources' da (checked there)
         t1 = grad_of(plan.outs[c])
         if t1 is None or c not in total:
             continue
@@ -227,8 +245,9 @@ def test_bf16_training_backward_section_by_section_against_oracle(monkeypatch):
                 diff = torch.where(ambiguous, torch.zeros_like(diff), diff)
             rel = float(diff.max()) / scale
             worst["dz"] = max(worst["dz"], rel)
-            assert rel <= (1 + nround) * ULP, "section %d: gradient arriving at the layer off by %.3g of scale (%s)" % (
-                c, rel, "da" if stored_da else "dz")
+            where = tuple(int(q) for q in np.unravel_index(int(diff.argmax()), diff.shape))
+            assert rel <= (1 + nround) * ULP, "section %d: gradient arriving at the layer off by %.3g of scale (%s) at (b, c, y, x) = %s, %d elements above the bound" % (
+                c, rel, "da" if stored_da else "dz", where, int((diff > (1 + nround) * ULP * scale).sum()))
             checked["dz"] += 1
             # (ii) from the HIP side's own T1
             da = t1 if stored_da else t1 * dact

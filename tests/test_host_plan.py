@@ -105,9 +105,16 @@ def test_plan_compiles_consistently(name, training, one_launch, monkeypatch):
         bops = [op for op, _ in plan.bwd]
         assert bops[0] == L.OP_MEMSET
         assert bops.count(L.OP_WGRAD) == n_conv - n_stem and bops.count(L.OP_STEM_WGRAD) == n_stem
-        n_fused = sum(1 for op, d in plan.bwd if op == L.OP_CONV and d.flags & L.EPI_BNBWD and d.ooy == 0 and d.oox == 0)
-        n_fused += sum(1 for op, d in plan.bwd if op == L.OP_SE_SCALE and d.red)     # (squeeze-excitation backward carrying it)
+        # every BatchNorm layer's reduce is its own pass or rides on the launch that produces its gradient: a data gradient's
+        # epilogue (one layer, or all the sections a [route] concatenates: their apply passes read columns of its replicas) or
+        # the squeeze-excitation backward
+        carriers = [(d.stats, d.stats + d.stats_slots * 2 * d.Cout * 8) for op, d in plan.bwd
+                    if op == L.OP_CONV and d.flags & L.EPI_BNBWD and d.ooy == 0 and d.oox == 0]
+        carriers += [(d.red, d.red + d.slots * 2 * d.C * 8) for op, d in plan.bwd if op == L.OP_SE_SCALE and d.red]
+        n_fused = sum(1 for op, d in plan.bwd if op == L.OP_BN_BWD_APPLY and sum(1 for lo, hi in carriers if lo <= d.red < hi) == 1)
         assert bops.count(L.OP_BN_BWD_APPLY) == n_bn and bops.count(L.OP_BN_BWD_REDUCE) + n_fused == n_bn and n_fused > 0
+        if name == "kaist_dyolov4_fshare_global_concat_se3":
+            assert n_fused > len(carriers)               # (the CSP stages' two-section routes: one launch, two layers)
         assert bops.count(L.OP_BN_BWD_PARAMS) == 0
         # every data-gradient launch either stores or accumulates; the first write into each buffer stores
         seen = set()
@@ -401,23 +408,27 @@ def test_every_batchnorm_backward_apply_has_exactly_one_reduce(name):
     st.adopt(torch.device("cpu"))
     plan = compile_plan(m, st, 2, 64, 96, torch.bfloat16, True, torch.device("cpu"), dry=True)
     mem = sched.Memory(plan, st)
-    writers = {}                                   # red pointer -> [(index, kind)]
+    writers = []                                   # (first byte, end of the replicas, command index, kind)
     for q, (op, d) in enumerate(plan.bwd):
         if op == L.OP_BN_BWD_REDUCE:
-            writers.setdefault(d.red, []).append((q, "pass"))
+            writers.append((d.red, d.red + max(d.slots, 1) * 2 * d.C * 8, q, "pass"))
         elif op == L.OP_CONV and d.flags & L.EPI_BNBWD:
-            writers.setdefault(d.stats, []).append((q, "chain" if d.flags & L.EPI_ADDEND and d.add == d.y else "epilogue"))
+            writers.append((d.stats, d.stats + max(d.stats_slots, 1) * 2 * d.Cout * 8, q,
+                            "chain" if d.flags & L.EPI_ADDEND and d.add == d.y else "epilogue"))
         elif op == L.OP_DW_DGRAD and d.res:
-            writers.setdefault(d.stats, []).append((q, "depthwise"))
+            writers.append((d.stats, d.stats + max(d.stats_slots, 1) * 2 * d.C * 8, q, "depthwise"))
         elif op == L.OP_SE_SCALE and d.red:
-            writers.setdefault(d.red, []).append((q, "squeeze-excitation"))
+            writers.append((d.red, d.red + max(d.slots, 1) * 2 * d.C * 8, q, "squeeze-excitation"))
     kinds = []
     n_apply = 0
     for q, (op, d) in enumerate(plan.bwd):
         if op != L.OP_BN_BWD_APPLY:
             continue
         n_apply += 1
-        w = writers.get(d.red, [])
+        # (the replicas an apply pass folds may be columns of a wider reduction: the joint one over a [route]'s sections)
+        w = [(i, k) for lo, hi, i, k in writers if lo <= d.red < hi]
+        if d.H:
+            assert d.W and d.H >= 2 * d.W and d.W >= d.C and all(k == "epilogue" for _, k in w), (q, d.H, d.W)
         # (a strided conv's data gradient may be several parity-class launches sharing one set of replicas)
         assert w and all(i < q for i, _ in w) and len({k for _, k in w}) == 1, (q, w)
         assert len(w) == 1 or w[0][1] == "epilogue", (q, w)
