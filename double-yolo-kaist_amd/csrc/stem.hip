@@ -127,88 +127,100 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const DykStemDesc d, cons
 constexpr int STEM_SEG = 128;      // output pixels of one row per staged segment (MFMA kernels below)
 
 // Forward for the loader's uint8 batches with bf16 output and 32 filters, on the bf16 MFMA: out[p][co] = sum_tc patch[p][tc]
-// w[tc][co] with A = patch (pixel values are integers <= 255: exact in bf16), B = the fp32 weights split into THREE bf16
+// w[tc][co] with the patch as bf16 (pixel values are integers <= 255: exact) and the fp32 weights split into THREE bf16
 // terms (8 + 8 + 8 mantissa bits: hi + mid + lo == w exactly), three MFMAs per 16 patch elements -- fp32-exact products and
-// fp32 accumulation, 1/255 applied to the sums.  One wave per workgroup walks segments of 128 output pixels of a row:
-// the 3 x 3 image rows under a segment are staged in LDS as bf16 integers (aligned 32-bit loads, next segment prefetched),
-// a 32-pixel tile is 2 x 8 LDS reads + 6 MFMAs per lane, the output tile goes through LDS to 16-byte channels-last stores
-// (with the operands swapped a lane holds 16 channels of ONE pixel and could store 8-byte runs directly: measured 538 us
-// against 381 us for this form and 498 us for the scalar kernel above -- partial-line stores).
-template <int COUT>
-__global__ __launch_bounds__(64) void stem_fwd_u8_kernel(const DykStemDesc d, const float* __restrict__ wt, int segs_per_wg,
-                                                         int segs_per_row, int nsegs) {
+// fp32 accumulation, 1/255 applied to the sums.  One wave per workgroup walks segments of 128 output pixels of a row: the
+// 3 x 3 image rows under a segment are staged in LDS (aligned 32-bit loads, next segment prefetched), a 32-pixel tile is
+// 6 MFMAs, the output tile goes through LDS to 16-byte channels-last stores.
+// The round-2 form of this kernel (in the history: stem_fwd_u8_kernel) issued 269 VALU instructions per 32-pixel tile and wave
+// -- uint8 -> bf16 conversion while parking the rows, 16 address adds for the patch gather, 16 conversions + 16 two-byte LDS
+// stores + their addresses in the epilogue -- VALU active 0.28 of every wave's cycles at two to three waves per SIMD
+// (tools/stem_pmc.sh): instruction-bound at 194 us for a 336 MB output.  This form (round 5), same arithmetic: 76.8 us, 4.6 TB/s.
+//   * the fetched image words are parked RAW (nine ds_write_b32 per segment); a patch byte is read by ds_read_u8 at a
+//     per-lane base + a compile-time tile offset (the four tiles of a segment are unrolled) and converted on the way to the
+//     operand (v_cvt_f32_ubyte0 + one v_perm per pair);
+//   * operands swapped: A = weights (rows = filters), B = patch (columns = pixels).  A lane then holds 16 filters of ONE pixel
+//     as four runs of four: packed conversion, four ds_write_b64 into an 80-byte-pitch pixel row, two ds_read_b128 + two
+//     16-byte global stores per lane (whole 64-byte pixels, consecutive pixels contiguous);
+//   * BatchNorm statistics per lane and filter in registers across all tiles, folded over the pixels (lanes) once per wave.
+template <int STRIDE, bool AFF, bool STATS>
+__global__ __launch_bounds__(64) void stem_fwd_u8t_kernel(const DykStemDesc d, const float* __restrict__ wt, int segs_per_wg,
+                                                          int segs_per_row, int nsegs) {
     typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int COUT = 32;
+    constexpr int WSEG = STEM_SEG * STRIDE + 2;                   // image columns under a segment (+ halo)
+    constexpr int PW = (WSEG + 3 + 3) / 4;                        // 32-bit words per parked row (the first starts 4 bytes left of the halo: aligned)
+    constexpr int NH = (PW + 63) / 64;                            // words per lane and row
+    constexpr int OP = 80;                                        // bytes per pixel of the output tile in LDS (64 + 16: bank spread)
+    __shared__ __attribute__((aligned(16))) char s_out[32 * OP];
+    __shared__ uint32_t s_raw[9 * PW];
+    __shared__ float s_fold[2 * COUT];
     const int lane = threadIdx.x;
-    const int Wseg = STEM_SEG * d.stride + 2;
-    uint16_t* s_out = (uint16_t*)smem;                            // [32 px][COUT] bf16 output tile
-    uint16_t* s_img = (uint16_t*)(smem + 32 * COUT * 2);          // [3 ky][3 c][Wseg]
     const int i = lane & 31, g = lane >> 5;
     const long plane = (long)d.H * d.W;
-    const bool stats = d.stats != nullptr, affine = d.scale != nullptr;
-    // B fragments (constant over the launch): k = tc = 16 ks + 8 g + j, column co = i
+    // A fragments (constant over the launch): row co = i, k = tc = 16 ks + 8 g + j; fp32 weight = hi + mid + lo in bf16, exactly
     uint4 wf[2][3];
-    int offA[2][8];
+    int addrB[2][8];                                              // byte of s_raw under (pixel i of a tile, patch element k)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         uint32_t h[8], m[8], l[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int tc = ks * 16 + 8 * g + j;
-            const float w = (tc < 27 && i < COUT) ? wt[tc * COUT + i] : 0.f;
+            const float w = tc < 27 ? wt[tc * COUT + i] : 0.f;
             const uint32_t hb = __float_as_uint(w) & 0xffff0000u;
             const float r1 = w - __uint_as_float(hb);
             const uint32_t mb = __float_as_uint(r1) & 0xffff0000u;
             const float r2 = r1 - __uint_as_float(mb);
             h[j] = hb >> 16; m[j] = mb >> 16; l[j] = __float_as_uint(r2) >> 16;
-            const int tcc = tc < 27 ? tc : 0;
+            const int tcc = tc < 27 ? tc : 0;                     // (k >= 27: any valid byte, its weight is zero)
             const int c = tcc % 3, kx = (tcc / 3) % 3, ky = tcc / 9;
-            offA[ks][j] = (ky * 3 + c) * Wseg + kx;
+            addrB[ks][j] = (ky * 3 + c) * PW * 4 + 3 + kx + i * STRIDE;
         }
         wf[ks][0] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
         wf[ks][1] = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
         wf[ks][2] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
     }
-    const float sc = (affine && i < COUT) ? d.scale[i] : 1.f, sh = (affine && d.shift && i < COUT) ? d.shift[i] : 0.f;
-    const int wpr = (Wseg + 3 + 3) / 4;
-    uint32_t iw[9][2];
+    // this lane's 16 filters: register r <-> filter (r & 3) + 8 (r >> 2) + 4 g
+    float sc[AFF ? 16 : 1], sh[AFF ? 16 : 1];
+    if constexpr (AFF) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * g;
+            sc[r] = d.scale[co];
+            sh[r] = d.shift ? d.shift[co] : 0.f;
+        }
+    }
+    float s1[16], s2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s1[r] = s2[r] = 0.f;
+    uint32_t iw[9][NH];
     const uint8_t* img8 = (const uint8_t*)d.img;
-    auto fetch = [&](int sg) {
+    auto fetch = [&](int sg) __attribute__((always_inline)) {
         const int row = sg / segs_per_row, x_begin = (sg - row * segs_per_row) * STEM_SEG;
         const int b = row / d.Ho, yo = row - b * d.Ho;
-        const int a0 = x_begin * d.stride - 4;
+        const int a0 = x_begin * STRIDE - 4;
 #pragma unroll
         for (int rr = 0; rr < 9; ++rr) {
             const int kyy = rr / 3, cc = rr - kyy * 3;
-            const int yi = yo * d.stride - 1 + kyy;
+            const int yi = yo * STRIDE - 1 + kyy;
             const bool rok = (unsigned)yi < (unsigned)d.H;
             const uint8_t* rp = img8 + ((long)b * 3 + cc) * plane + (long)(rok ? yi : 0) * d.W;
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
+            for (int h2 = 0; h2 < NH; ++h2) {
                 const int w = lane + h2 * 64;
                 const int xw = a0 + 4 * w;
-                const bool ok = rok && w < wpr && xw >= 0 && xw < d.W;
+                const bool ok = rok && w < PW && xw >= 0 && xw < d.W;
                 const uint32_t v = *(const uint32_t*)(rp + (ok ? xw : 0));
                 iw[rr][h2] = ok ? v : 0u;
             }
         }
     };
-    auto park = [&]() {
-#pragma unroll
-        for (int rr = 0; rr < 9; ++rr)
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int w = lane + h2 * 64;
-                if (w >= wpr) continue;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int xp = 4 * w + j - 3;
-                    if (xp >= 0 && xp < Wseg)
-                        s_img[rr * Wseg + xp] = (uint16_t)(__float_as_uint((float)((iw[rr][h2] >> (8 * j)) & 0xffu)) >> 16);
-                }
-            }
-    };
-    float s1 = 0.f, s2 = 0.f;
+    const uint8_t* raw8 = (const uint8_t*)s_raw;
+    char* const wptr = s_out + i * OP + 8 * g;                                // this lane's pixel row of the tile, its first run of four filters
+    const char* const rptr0 = s_out + (lane >> 2) * OP + (lane & 3) * 16;     // the two 16-byte vectors this lane stores: pixels lane / 4, 16 + lane / 4
+    const char* const rptr1 = rptr0 + 16 * OP;
+    const long goff0 = (long)(lane >> 2) * d.ldy + (lane & 3) * 8, goff1 = goff0 + 16L * d.ldy;
     const int seg0 = blockIdx.x * segs_per_wg;
     const int seg1 = min(nsegs, seg0 + segs_per_wg);
     if (seg0 < seg1) fetch(seg0);
@@ -216,55 +228,89 @@ __global__ __launch_bounds__(64) void stem_fwd_u8_kernel(const DykStemDesc d, co
         const int row = sg / segs_per_row, x_begin = (sg - row * segs_per_row) * STEM_SEG;
         const int npx = min(STEM_SEG, d.Wo - x_begin);
         __syncthreads();
-        park();
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr)
+#pragma unroll
+            for (int h2 = 0; h2 < NH; ++h2)
+                if (lane + h2 * 64 < PW) s_raw[rr * PW + lane + h2 * 64] = iw[rr][h2];
         __syncthreads();
         if (sg + 1 < seg1) fetch(sg + 1);
         bf16_t* yrow = (bf16_t*)d.y + ((long)row * d.Wo + x_begin) * d.ldy;
-        for (int px0 = 0; px0 < npx; px0 += 32) {
+#pragma unroll
+        for (int tl = 0; tl < STEM_SEG / 32; ++tl) {
+            const int px0 = tl * 32;
+            if (px0 >= npx) break;
             f32x16_t acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const uint16_t* pa = s_img + (px0 + i) * d.stride;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                uint32_t aw[4];
+                uint32_t bw[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    aw[j] = (uint32_t)pa[offA[ks][2 * j]] | ((uint32_t)pa[offA[ks][2 * j + 1]] << 16);
-                const bf16x8_v av = __builtin_bit_cast(bf16x8_v, make_uint4(aw[0], aw[1], aw[2], aw[3]));
+                for (int j = 0; j < 4; ++j) {
+                    const float f0 = (float)raw8[addrB[ks][2 * j] + px0 * STRIDE];
+                    const float f1 = (float)raw8[addrB[ks][2 * j + 1] + px0 * STRIDE];
+                    bw[j] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);   // {bf16(f0), bf16(f1)}: integers <= 255 are exact
+                }
+                const bf16x8_v bv = __builtin_bit_cast(bf16x8_v, make_uint4(bw[0], bw[1], bw[2], bw[3]));
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_v, wf[ks][q]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, wf[ks][q]), bv, acc, 0, 0, 0);
             }
-            // C/D: column = lane & 31 (co), row = (r & 3) + 8 (r >> 2) + 4 g (pixel of the tile)
+            // C/D: column = lane & 31 (pixel of the tile), row = (r & 3) + 8 (r >> 2) + 4 g (filter)
+            float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pr = (r & 3) + 8 * (r >> 2) + 4 * g;
-                float v = acc[r] * (1.0f / 255.0f);
-                if (stats && px0 + pr < npx) { s1 += v; s2 += v * v; }
-                if (affine) v = act_fwd(d.act, v * sc + sh);
-                if (i < COUT) s_out[pr * COUT + i] = (uint16_t)(f32x2_to_bf16x2(v, 0.f) & 0xffffu);
+            for (int r = 0; r < 16; ++r) v[r] = acc[r] * (1.0f / 255.0f);
+            if constexpr (STATS) {
+                if (px0 + 32 <= npx) {                            // (whole tile: no lane mask)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+                } else if (px0 + i < npx) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+                }
+            }
+            if constexpr (AFF) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = act_fwd(d.act, v[r] * sc[r] + sh[r]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint2 pk;
+                pk.x = f32x2_to_bf16x2(v[4 * q], v[4 * q + 1]);
+                pk.y = f32x2_to_bf16x2(v[4 * q + 2], v[4 * q + 3]);
+                *(uint2*)(wptr + 16 * q) = pk;
             }
             __syncthreads();
-            constexpr int VPP = COUT / 8;
-#pragma unroll
-            for (int u = 0; u < 32 * VPP / 64; ++u) {
-                const int v = lane + u * 64;
-                const int px = v / VPP, part = v % VPP;
-                if (px0 + px < npx) *(uint4*)(yrow + (long)(px0 + px) * d.ldy + part * 8) = ((const uint4*)s_out)[v];
+            if (px0 + 32 <= npx) {
+                *(uint4*)(yrow + (long)px0 * d.ldy + goff0) = *(const uint4*)rptr0;
+                *(uint4*)(yrow + (long)px0 * d.ldy + goff1) = *(const uint4*)rptr1;
+            } else {
+                if (px0 + (lane >> 2) < npx) *(uint4*)(yrow + (long)px0 * d.ldy + goff0) = *(const uint4*)rptr0;
+                if (px0 + 16 + (lane >> 2) < npx) *(uint4*)(yrow + (long)px0 * d.ldy + goff1) = *(const uint4*)rptr1;
             }
             __syncthreads();
         }
     }
-    if (stats) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (lane < COUT) {
-            const int slots = d.stats_slots > 0 ? d.stats_slots : 1;
-            double* st = d.stats + (size_t)(blockIdx.x % (unsigned)slots) * 2 * COUT;
-            atomicAdd(st + lane, (double)s1);
-            atomicAdd(st + COUT + lane, (double)s2);
+    if constexpr (STATS) {
+        // fold the pixels (the 32 lanes of a half-wave), then one fp64 atomic per filter and sum
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
         }
+        if (i == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * g;
+                s_fold[co] = s1[r];
+                s_fold[COUT + co] = s2[r];
+            }
+        }
+        __syncthreads();
+        const int slots = d.stats_slots > 0 ? d.stats_slots : 1;
+        double* st = d.stats + (size_t)(blockIdx.x % (unsigned)slots) * 2 * COUT;
+        atomicAdd(st + lane, (double)s_fold[lane]);              // lanes 0..31: sum, 32..63: sum of squares ([2][COUT] contiguous)
     }
 }
 
@@ -627,16 +673,25 @@ extern "C" int dyk_stem_conv_fwd(const DykStemDesc* d, void* stream) {
     static int fast = -1;
     if (fast < 0) { const char* e = getenv("DYK_STEM_FWD_U8"); fast = (e && e[0] == '0') ? 0 : 1; }
     // (16 filters / stride 2 -- the MobileNet stem -- measured faster in the scalar kernel: half of the 32-wide tile idles)
-    if (fast && d->in_u8 && d->dtype == DYK_BF16 && d->Cout == 32 && d->W % 4 == 0 && ((uintptr_t)d->img % 4) == 0) {
+    if (fast && d->in_u8 && d->dtype == DYK_BF16 && d->Cout == 32 && d->W % 4 == 0 && ((uintptr_t)d->img % 4) == 0 && (d->stride == 1 || d->stride == 2)) {
         const int segs_per_row = (d->Wo + STEM_SEG - 1) / STEM_SEG;
         const long nsegs = (long)d->B * d->Ho * segs_per_row;
         const long want = nsegs < 3072 ? nsegs : 3072;                  // one-wave workgroups, ~12 per CU
         const int spw = (int)((nsegs + want - 1) / want);
         const dim3 grid((unsigned)((nsegs + spw - 1) / spw));
-        const size_t lds = (size_t)32 * d->Cout * 2 + (size_t)9 * (STEM_SEG * d->stride + 2) * 2;
-        hipLaunchKernelGGL((stem_fwd_u8_kernel<32>), grid, dim3(64), lds, s, *d, d->wt, spw, segs_per_row, (int)nsegs);
-        DYK_LAUNCH_CHECK();
-        return DYK_OK;
+        {
+#define DYK_STEM_T(S_, A_, T_) hipLaunchKernelGGL((stem_fwd_u8t_kernel<S_, A_, T_>), grid, dim3(64), 0, s, *d, d->wt, spw, segs_per_row, (int)nsegs)
+#define DYK_STEM_S(S_)                                                                                     \
+            do {                                                                                           \
+                if (d->scale) { if (d->stats) DYK_STEM_T(S_, true, true); else DYK_STEM_T(S_, true, false); } \
+                else { if (d->stats) DYK_STEM_T(S_, false, true); else DYK_STEM_T(S_, false, false); }     \
+            } while (0)
+            if (d->stride == 1) DYK_STEM_S(1); else DYK_STEM_S(2);
+#undef DYK_STEM_S
+#undef DYK_STEM_T
+            DYK_LAUNCH_CHECK();
+            return DYK_OK;
+        }
     }
     long blocks = (npix + 255) / 256;
     // a fixed, bounded grid: every block folds its statistics once (2 * Cout atomics per block)

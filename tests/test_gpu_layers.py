@@ -184,3 +184,35 @@ def test_cast_pad_table_matches_per_pack_casts():
             ref = torch.zeros(r, cp, device="cuda")
             ref[:, :c] = s
             assert torch.equal(d, ref.bfloat16())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_transpose_taps_table(dtype):
+    """dyk_transpose_taps (the [tap][Cin][Cout] packs the data gradients read, rebuilt from the fp32 masters after every
+    optimizer step): a table of ragged entries -- several taps, extents off the 32 x 32 tile, zero-filled row tails, more tiles
+    than one workgroup's run and entries that end inside a run -- against torch."""
+    import ctypes
+    from dyk import lib as L
+    g = torch.Generator().manual_seed(11)
+    shapes = [(9, 64, 32, 0), (1, 33, 70, 64), (9, 255, 40, 256), (1, 8, 8, 0), (25, 16, 16, 32), (1, 300, 513, 0), (9, 32, 3, 32)]
+    src = torch.randn(sum(t * r * c for t, r, c, _ in shapes) + 5, generator=g).cuda()
+    arr = (L.DykTransposeEntry * len(shapes))()
+    so, do, tiles = 5, 3 * 0, 0
+    for i, (t, r, c, ld) in enumerate(shapes):
+        arr[i].src_off, arr[i].dst_off, arr[i].taps, arr[i].rows, arr[i].cols, arr[i].dst_ld, arr[i].tile_begin = so, do, t, r, c, ld, tiles
+        so += t * r * c
+        do += t * (ld or r) * c
+        tiles += t * ((r + 31) // 32) * ((c + 31) // 32)
+    dst = torch.full((do,), 7.0, device="cuda").to(dtype)
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    code = L.DYK_BF16 if dtype == torch.bfloat16 else L.DYK_F32
+    L.check(L.load().dyk_transpose_taps(src.data_ptr(), dst.data_ptr(), tab.data_ptr(), len(shapes), tiles, code, None), "dyk_transpose_taps")
+    torch.cuda.synchronize()
+    for i, (t, r, c, ld) in enumerate(shapes):
+        s = src[arr[i].src_off:arr[i].src_off + t * r * c].view(t, r, c)
+        ldd = ld or r
+        d = dst[arr[i].dst_off:arr[i].dst_off + t * ldd * c].view(t, c, ldd)
+        assert torch.equal(d[:, :, :r], s.transpose(1, 2).to(dtype)), i
+        if ldd > r:                              # the tail of a padded row is zero-filled up to the next multiple of 32 it covers
+            assert float(d[:, :, r:min(ldd, (r + 31) // 32 * 32)].float().abs().max()) == 0.0, i
