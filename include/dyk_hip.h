@@ -486,7 +486,10 @@ int dyk_dwconv_fwd(const DykDwDesc* desc, void* stream);
 int dyk_dwconv_tile_ok(const DykDwDesc* desc);
 int dyk_dwconv_dgrad(const DykDwDesc* desc, void* stream);
 int dyk_dwconv_wgrad(const DykDwDesc* desc, void* stream);
-/* number of workgroup rows (= planes of `part`) dyk_dwconv_wgrad uses for this descriptor; negative = error code */
+/* number of workgroup rows (= planes of `part`) dyk_dwconv_wgrad uses for this descriptor; negative = error code.  Stride-1
+ * 3x3 / 5x5 bf16 problems run on the LDS-tiled persistent kernel (round 5: one pass over dy and x, the next tile's loads in flight
+ * while a tile is computed; planes = its workgroups per channel group), everything else on the row kernel (planes = workgroup rows
+ * per kernel row); the count depends on the descriptor's shape fields only, never on `part` / `dw`. */
 int dyk_dwconv_wgrad_rows(const DykDwDesc* desc);
 
 /* ------------------------------------------------------------------------------------
