@@ -24,7 +24,7 @@ static int conv_validate(const DykConvDesc* d) {
             return DYK_ERR_ARG;
     if ((d->flags & DYK_EPI_STATS) && !d->stats) return DYK_ERR_ARG;
     if ((d->flags & DYK_EPI_RESIDUAL) && !d->res) return DYK_ERR_ARG;
-    if ((d->flags & DYK_EPI_ADDEND) && (!(d->flags & DYK_EPI_BNBWD) || !d->add || ((uintptr_t)d->add % 16))) return DYK_ERR_ARG;
+    if ((d->flags & DYK_EPI_ADDEND) && (!(d->flags & DYK_EPI_BNBWD) || ((uintptr_t)d->add % 16))) return DYK_ERR_ARG;     // (add == NULL: zero addend)
     if (d->flags & DYK_EPI_BNFWD) {
         // conv + BatchNorm + activation in one launch: statistics on, bf16, one problem, whole 16-byte channel chunks
         if (!(d->flags & DYK_EPI_STATS) || (d->flags & (DYK_EPI_AFFINE | DYK_EPI_ACCUM | DYK_EPI_OUT_F32 | DYK_EPI_BNBWD | DYK_EPI_ADDEND)))

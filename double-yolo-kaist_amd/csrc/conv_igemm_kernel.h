@@ -400,7 +400,7 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& desc, f32x4_t (
                             const int po = q < nchunk ? t_out[row] : -1;
                             rows[u] = row; pos[u] = po;
                             yraw[u] = *(const uint4*)((const T*)a.res + (po >= 0 ? (long)t_res[row] + mc : 0L));
-                            if constexpr (CH) adv[u] = *(const uint4*)((const T*)a.add + (po >= 0 ? (long)po + mc : 0L));
+                            if constexpr (CH) adv[u] = a.add ? *(const uint4*)((const T*)a.add + (po >= 0 ? (long)po + mc : 0L)) : make_uint4(0u, 0u, 0u, 0u);   // (no addend: zero)
                         }
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
@@ -504,7 +504,7 @@ __device__ __forceinline__ void conv_epilogue(const DykConvDesc& desc, f32x4_t (
                     const int nl = (r >> 4) * WTN + ni * 16 + (r & 15);
                     const int ch = (pc ^ (r & (CPRW - 1))) * EPVT;          // logical chunk stored at physical chunk pc
                     glds16((const T*)a.res + (long)t_res[nl] + m0 + ch, ubuf_u + buf * SB + inst * 1024);
-                    if constexpr (CH) glds16((const T*)a.add + (long)t_out[nl] + m0 + ch, ubuf_u + (3 + buf) * SB + inst * 1024);
+                    if constexpr (CH) glds16(a.add ? (const T*)a.add + (long)t_out[nl] + m0 + ch : (const T*)dyk_zero_page, ubuf_u + (3 + buf) * SB + inst * 1024);   // (no addend: the zero page)
                 }
             };
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // (the vector loads above)

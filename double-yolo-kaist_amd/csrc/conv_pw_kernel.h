@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const PwArgs g) {
                 const int n = n0 + row, ch = m0 + wm * WTM + (pc ^ (row & (CPR - 1))) * 8;
                 const bool ok = live && n < Ntot && ch < Cout;
                 glds16(ok ? ug + (long)n * ldr + ch : zero, sEw_u + buf * C::UB_BYTES + j * 1024);
-                if constexpr (EPI == 3) glds16(ok ? ag + (long)n * ldy + ch : zero, sEw_u + (2 + buf) * C::UB_BYTES + j * 1024);
+                if constexpr (EPI == 3) glds16(ok && ag ? ag + (long)n * ldy + ch : zero, sEw_u + (2 + buf) * C::UB_BYTES + j * 1024);   // (chain form without an addend: zeros)
             }
         }
     };

@@ -1075,6 +1075,19 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
                 prod["keep_dz"] = addend is not None
                 bw = dict(act=prod["act"], raw=prod["y_raw"], vecs=prod["vecs"], vs=prod["vs"], red=prod["red_fused"])
+            # ... or x_in is the output of the LAST [shortcut] of a residual chain, riding on its conv's normalise pass
+            # (fused_shortcut): this launch is the only writer of that gradient, which the skip branch still needs as dz itself --
+            # the keep-dz (chain) form of the epilogue without an addend (DYK_EPI_ADDEND, add == NULL)
+            zero_chain = (not fuse and addend is None and first and prod is not None and prod is not rec
+                          and prod.get("fused_shortcut") and prod.get("bn") and "vecs" in prod and tcons.get(x_in.tid, 0) == 2
+                          and x_in.C % (16 // es) == 0 and stride == 1 and len(dgrad_classes(k, pad, 1, x_in.H, x_in.W)) == 1
+                          and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
+                          and os.environ.get("DYK_CHAIN_FUSE", "1") != "0" and os.environ.get("DYK_LAST_SHORTCUT_FUSE", "1") != "0")
+            if zero_chain:
+                fuse = True
+                prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
+                prod["keep_dz"] = True
+                bw = dict(act=prod["act"], raw=prod["y_raw"], vecs=prod["vecs"], vs=prod["vs"], red=prod["red_fused"])
             # ... or of ALL the conv + BatchNorm sections concatenated into x_in (joint_of, decided in the forward): one launch,
             # replicas [slots][2][ctot]; every section's apply pass folds its own columns (DykEwDesc.H / W: replica stride and
             # offset of the second sum)
@@ -1125,6 +1138,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     if addend is not None:
                         d.flags |= L.EPI_ADDEND
                         later(lambda d=d, ad=addend[0]: setattr(d, "add", ptr_of(ad)))
+                    elif zero_chain:
+                        d.flags |= L.EPI_ADDEND           # (add stays NULL)
                     later(lambda d=d, bw=bw: (
                         setattr(d, "res", ptr_of(bw["raw"])), setattr(d, "scale", ws.ptr(bw["vecs"])),
                         setattr(d, "shift", ws.ptr(bw["vecs"] + bw["vs"])), setattr(d, "aux0", ws.ptr(bw["vecs"] + 2 * bw["vs"])),

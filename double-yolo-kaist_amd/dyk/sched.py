@@ -149,7 +149,7 @@ def accesses(op, d, mem, plan):
             rd(V(p))
         if d.flags & (L.EPI_RESIDUAL | L.EPI_BNBWD):
             rd(T(d.res, d.ldr, d.Cout, es))
-        if d.flags & L.EPI_ADDEND:
+        if d.flags & L.EPI_ADDEND and d.add:          # (add == NULL: the keep-dz form without an addend)
             rd(T(d.add, d.ldy, d.Cout, es))
         wr(T(d.y, d.ldy, d.Cout, eso))
         if d.flags & (L.EPI_STATS | L.EPI_BNBWD):

@@ -107,7 +107,8 @@ enum {
                              link of the residual chain needs it), rounded to dtype, and reduces the sums of
                              da = dz * act'(...) computed from the rounded value; the BatchNorm-backward apply pass
                              then applies act' itself.  Removes the gradient copy of the [shortcut] and the separate
-                             reduce pass for residual blocks. */
+                             reduce pass for residual blocks.  add == NULL: no addend (dz = v) -- the keep-dz form alone,
+                             for the LAST [shortcut] of a residual chain, whose gradient the skip branch still needs. */
 };
 
 typedef struct DykConvDesc {

@@ -404,6 +404,19 @@ def test_dgrad_with_fused_batchnorm_backward_reduce(dtype, act):
         st = red.sum(0).cpu()
         assert torch.allclose(st[0], s1c, rtol=2e-3, atol=(5e-4 if dtype == torch.float32 else 5e-2) * n ** 0.5), hex(tune)
         assert torch.allclose(st[1], s2c, rtol=2e-3, atol=(5e-4 if dtype == torch.float32 else 5e-2) * n ** 0.5), hex(tune)
+    # the keep-dz form WITHOUT an addend (add == NULL: the last [shortcut] of a residual chain, whose gradient the skip branch
+    # still needs): the same bits as an all-zero addend tensor, on the generic tiles and on the persistent pointwise kernel
+    zer = torch.zeros_like(addd)
+    for tune in (0, 64 | (2 << 8) | (1 << 12), 64 | (2 << 8) | (4 << 12), (7 << 12) | (2 << 8) | (1 << 24), (7 << 12) | (3 << 8) | (1 << 25)):
+        res = []
+        for ptr in (zer.data_ptr(), None):
+            red.zero_()
+            out.zero_()
+            d.tune, d.add = tune, ptr
+            L.check(L.load().dyk_conv_igemm(ctypes.byref(d), None), "dyk_conv_igemm(BNBWD|ADDEND, add == NULL)")
+            res.append((out.clone(), red.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), hex(tune)
+    d.add = addd.data_ptr()
     # illegal flag combinations are rejected
     d.flags = L.EPI_BNBWD | L.EPI_ACCUM
     assert L.load().dyk_conv_igemm(ctypes.byref(d), None) != 0
