@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256) void axpby_kernel(DykEwPair pr) {
     }
 }
 
-// red[0] += sum a*b  over all pixels/channels (weighted-fusion weight gradient)
+// red[0] += sum a*b  over all pixels/channels (weighted-fusion weight gradient).  With `out` (round 5): the same pass also
+// leaves out = sa * a (+ out with DYK_EW_ACCUM), sa = alpha * (p0 ? p0[0] : 1) -- the scaled gradient copy dyk_axpby would make
+// (same arithmetic, same rounding): the backward of one source of a weighted fusion in ONE pass over the gradient
 template <typename T>
 __global__ __launch_bounds__(256) void dot_kernel(DykEwDesc d) {
     constexpr int EPV = ElemTraits<T>::EPV;
@@ -62,6 +64,9 @@ __global__ __launch_bounds__(256) void dot_kernel(DykEwDesc d) {
     const long total = (long)d.npix * CV;
     const T* __restrict__ a = (const T*)d.a;
     const T* __restrict__ b = (const T*)d.b;
+    T* __restrict__ o = (T*)d.out;
+    const float sa = d.alpha * (d.p0 ? d.p0[0] : 1.f);
+    const bool accum = d.flags & DYK_EW_ACCUM;
     float s = 0.f;
     for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
         const long p = v / CV;
@@ -71,6 +76,17 @@ __global__ __launch_bounds__(256) void dot_kernel(DykEwDesc d) {
         vec_unpack<T>(*(const uint4*)(b + p * d.ldb + c), y);
 #pragma unroll
         for (int j = 0; j < EPV; ++j) s += x[j] * y[j];
+        if (o) {
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) x[j] *= sa;
+            if (accum) {
+                float z[EPV];
+                vec_unpack<T>(*(const uint4*)(o + p * d.ldo + c), z);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) x[j] += z[j];
+            }
+            *(uint4*)(o + p * d.ldo + c) = vec_pack<T>(x);
+        }
     }
     __shared__ float ws[4];
     s = wave_sum(s);
@@ -923,7 +939,7 @@ extern "C" int dyk_axpby(const DykEwDesc* d, void* stream) {
 extern "C" int dyk_dot(const DykEwDesc* d, void* stream) {
     const int rc = check_ew(d, true, false);
     if (rc) return rc;
-    if (d->npix <= 0 || !d->red) return DYK_ERR_ARG;
+    if (d->npix <= 0 || !d->red || (d->out && d->ldo % epv_of(d->dtype))) return DYK_ERR_ARG;
     long g = ((long)d->npix * (d->C / epv_of(d->dtype)) + 256 * 8 - 1) / (256 * 8);
     if (g > 1024) g = 1024;
     if (g < 1) g = 1;

@@ -1285,7 +1285,21 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                         tail = ga.chan_slice(nx, na - nx)
                         plan.bwd.append((L.OP_AXPBY, ew_desc(a=tail, out=tail, C=na - nx, alpha=0.0)))     # alpha = 0: `a` is not read
 
-                if rec["weighted"]:
+                if rec["weighted"] and nx == na and os.environ.get("DYK_WFUSE_BWD_FUSED", "1") != "0":
+                    # weighted fusion, equal channel counts: per source ONE pass over dz leaves its fusion-weight dot product AND
+                    # its scaled gradient copy (dyk_dot with `out`, round 5: two dots + two scaled copies read dz four times)
+                    red = new_red(16)
+                    weff = rec["weff"]
+                    for q, src in enumerate((x_in, a)):
+                        dq = ew_desc(a=dz, b=src, out=gref(src), flags=acc_flag(src))
+                        later(lambda dq=dq, red=red, weff=weff, q=q: (setattr(dq, "red", ws.ptr(red + 8 * q)), setattr(dq, "p0", ws.ptr(weff + 4 * q))))
+                        plan.bwd.append((L.OP_DOT, dq))
+                    pm = misc()
+                    pm.p[0], pm.p[2] = store.p_ptr("module_list.%d.w" % i), store.g_ptr("module_list.%d.w" % i)
+                    pm.i[0] = 2
+                    later(lambda pm=pm, red=red: pm.p.__setitem__(1, ws.ptr(red)))
+                    plan.bwd.append((L.OP_WFUSE_BWD_PARAMS, pm))
+                elif rec["weighted"]:
                     red = new_red(16)
                     d0 = ew_desc(a=dz, b=x_in)
                     later(lambda d0=d0, red=red: setattr(d0, "red", ws.ptr(red)))

@@ -341,7 +341,9 @@ int dyk_bn_act_bwd_apply(const DykEwDesc* desc, void* stream);
  * (layers.py:79), the weighted fusion x*w0 + a*w1 (layers.py:66-73) and every gradient
  * accumulation (flags & DYK_EW_ACCUM). */
 int dyk_axpby(const DykEwDesc* desc, void* stream);
-/* red[0] += sum over pixels/channels of a*b   (gradient of a fusion weight) */
+/* red[0] += sum over pixels/channels of a*b   (gradient of a fusion weight).  With desc->out the same pass also stores
+ * out = alpha*s0*a (+ out with DYK_EW_ACCUM), s0 = p0 ? p0[0] : 1 -- the scaled gradient copy of that source, exactly as
+ * dyk_axpby would make it (autograd of layers.py:66-73 for one source in ONE pass over the gradient) */
 int dyk_dot(const DykEwDesc* desc, void* stream);
 /* WeightedFeatureFusion weights (layers.py:66): weff[i] = sigmoid(w[i]) * 2/n, and its backward
  * dw[i] += red[i] * 2/n * sigmoid'(w[i]) */

@@ -134,6 +134,15 @@ def test_axpby_dot_wfuse(dtype):
     da = torch.empty_like(ad)
     ops.call("dyk_axpby", ops.ew_desc(a=dzd, out=da, p0=weff[0:1]))
     _close(ops.to_nchw(da).cpu(), ar.grad, tol, "da")
+    # one pass per source (how the plan runs it): dyk_dot with `out` leaves the dot product AND the scaled copy -- the same bits
+    # as the two separate calls, store and accumulate forms
+    for accumulate in (False, True):
+        base = ops.to_nhwc(torch.randn(B, C, H, W, generator=g).cuda(), dtype)
+        ref = base.clone()
+        ops.call("dyk_axpby", ops.ew_desc(a=dzd, out=ref, p0=weff[1:2], flags=EW_ACCUM if accumulate else 0))
+        got, red2 = base.clone(), torch.zeros(1, dtype=torch.float64, device="cuda")
+        ops.call("dyk_dot", ops.ew_desc(a=dzd, b=bd, out=got, p0=weff[1:2], red=red2, flags=EW_ACCUM if accumulate else 0))
+        assert torch.equal(got, ref) and torch.equal(red2, red[1:2])
 
 
 @pytest.mark.parametrize("weighted", [False, True])
