@@ -774,7 +774,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DykDwDesc d, int CVB)
 // group owns plane wg (DykDwDesc.part: plain stores, folded in plane order by dyk_grad_reduce -- same sums from run to run);
 // without planes, one fp32 atomic per (tap, channel) and workgroup.
 typedef __bf16 dw_bf16x2_t __attribute__((ext_vector_type(2)));
-template <int K, bool PRE, bool DOT2>
+template <int K, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dwconv_wgrad_tile_kernel(DykDwDesc d, int CT, int groups, unsigned m_ct, int tiles_x,
                                                                 int tiles_y, int P) {
     using T = bf16_t;
@@ -897,47 +897,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int r = s / SPR, strip = s - r * SPR;
                 const uint4* grow = gtile + (r * TW + strip * XT) * S + cct;
                 const uint4* prow = patch + ((r + kh) * IC + strip * XT) * S + cct;
-                if constexpr (DOT2) {
-                    // v_dot2c_f32_bf16: acc += x.lo * g.lo + x.hi * g.hi on the PACKED pairs -- with one half of g masked to zero
-                    // it is the fp32 multiply-add of one channel (a bf16 x bf16 product is exact in fp32: one rounding, as the
-                    // fma), and the x vectors need no unpacking: 8 VALU ops fewer per input vector
-                    unsigned gm[XT][EPV];
+                // v_dot2c_f32_bf16: acc += x.lo * g.lo + x.hi * g.hi on the PACKED pairs -- with one half of g masked to zero
+                // it is the fp32 multiply-add of one channel (a bf16 x bf16 product is exact in fp32: one rounding, as the
+                // fma), and the x vectors need no unpacking: 8 VALU ops fewer per input vector
+                unsigned gm[XT][EPV];
+#pragma unroll
+                for (int o = 0; o < XT; ++o) {
+                    const uint4 gr = grow[o * S];
+                    const unsigned gw[4] = {gr.x, gr.y, gr.z, gr.w};
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { gm[o][2 * m] = gw[m] & 0xffffu; gm[o][2 * m + 1] = gw[m] & 0xffff0000u; }
+                }
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    const uint4 xr = prow[q * S];
+                    const unsigned xw[4] = {xr.x, xr.y, xr.z, xr.w};
 #pragma unroll
                     for (int o = 0; o < XT; ++o) {
-                        const uint4 gr = grow[o * S];
-                        const unsigned gw[4] = {gr.x, gr.y, gr.z, gr.w};
+                        const int tp = q - o;
+                        if (tp < 0 || tp >= K) continue;
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) { gm[o][2 * m] = gw[m] & 0xffffu; gm[o][2 * m + 1] = gw[m] & 0xffff0000u; }
-                    }
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) {
-                        const uint4 xr = prow[q * S];
-                        const unsigned xw[4] = {xr.x, xr.y, xr.z, xr.w};
-#pragma unroll
-                        for (int o = 0; o < XT; ++o) {
-                            const int tp = q - o;
-                            if (tp < 0 || tp >= K) continue;
-#pragma unroll
-                            for (int j = 0; j < EPV; ++j)
-                                acc[tp][j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dw_bf16x2_t, xw[j >> 1]),
-                                                                             __builtin_bit_cast(dw_bf16x2_t, gm[o][j]), acc[tp][j], false);
-                        }
-                    }
-                } else {
-                    float g[XT][EPV];
-#pragma unroll
-                    for (int o = 0; o < XT; ++o) vec_unpack<T>(grow[o * S], g[o]);
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) {
-                        float xv[EPV];
-                        vec_unpack<T>(prow[q * S], xv);
-#pragma unroll
-                        for (int o = 0; o < XT; ++o) {
-                            const int tp = q - o;                      // tap within the kernel row (compile-time after unrolling)
-                            if (tp < 0 || tp >= K) continue;
-#pragma unroll
-                            for (int j = 0; j < EPV; ++j) acc[tp][j] += g[o][j] * xv[j];
-                        }
+                        for (int j = 0; j < EPV; ++j)
+                            acc[tp][j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dw_bf16x2_t, xw[j >> 1]),
+                                                                         __builtin_bit_cast(dw_bf16x2_t, gm[o][j]), acc[tp][j], false);
                     }
                 }
             }
@@ -999,6 +981,7 @@ inline bool dw_wgrad_tile_cfg(const DykDwDesc* d, DwWgTile* c) {
     c->tiles_y = (d->Ho + TH - 1) / TH;
     const long ntiles = (long)d->B * c->tiles_x * c->tiles_y;
     if (ntiles >= (1L << 30)) return false;
+    // (two workgroups per CU; three for the 3x3 kernel at 164 VGPRs measured equal: 70 / 87 / 20 / 29 us against 65 / 88 / 20 / 29)
     long p0 = dw_wgrad_tile_target() / c->groups;
     if (p0 < 1) p0 = 1;
     if (p0 > ntiles) p0 = ntiles;
@@ -1011,13 +994,7 @@ inline bool dw_wgrad_tile_cfg(const DykDwDesc* d, DwWgTile* c) {
 }
 inline int launch_dw_wgrad_tile(const DykDwDesc* d, const DwWgTile& c, hipStream_t s) {
     const dim3 grid((unsigned)(c.groups * c.P));
-    static int dot2 = -1;
-    if (dot2 < 0) { const char* e = getenv("DYK_DW_WGRAD_DOT2"); dot2 = (e && e[0] == '0') ? 0 : 1; }
-#define DYK_DWW(KK, PP)                                                                                                                  \
-    do {                                                                                                                                  \
-        if (dot2) hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<KK, PP, true>), grid, dim3(256), c.lds, s, *d, c.CT, c.groups, c.m_ct, c.tiles_x, c.tiles_y, c.P); \
-        else hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<KK, PP, false>), grid, dim3(256), c.lds, s, *d, c.CT, c.groups, c.m_ct, c.tiles_x, c.tiles_y, c.P);    \
-    } while (0)
+#define DYK_DWW(KK, PP) hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<KK, PP>), grid, dim3(256), c.lds, s, *d, c.CT, c.groups, c.m_ct, c.tiles_x, c.tiles_y, c.P)
     if (d->k == 3) { if (d->pre) DYK_DWW(3, true); else DYK_DWW(3, false); }
     else { if (d->pre) DYK_DWW(5, true); else DYK_DWW(5, false); }
 #undef DYK_DWW
