@@ -710,20 +710,7 @@ __global__ __launch_bounds__(256) void se_scale_kernel(DykEwDesc d, int CVB) {
     const bool active = cv * EPV < d.C;
     if (!RED && !active) return;
     const int c = active ? cv * EPV : 0;
-    const int b = blockIdx.z;
     const int HW = d.H * d.W;
-    float f0[EPV], f1[EPV];
-#pragma unroll
-    for (int j = 0; j < EPV; j += 4) {
-        const float4 q = *(const float4*)(d.p0 + (long)b * d.C + c + j);
-        f0[j] = q.x; f0[j + 1] = q.y; f0[j + 2] = q.z; f0[j + 3] = q.w;
-        if (d.p1) {
-            const float4 r = *(const float4*)(d.p1 + (long)b * d.C + c + j);
-            f1[j] = r.x * d.alpha; f1[j + 1] = r.y * d.alpha; f1[j + 2] = r.z * d.alpha; f1[j + 3] = r.w * d.alpha;
-        } else {
-            f1[j] = f1[j + 1] = f1[j + 2] = f1[j + 3] = 0.f;
-        }
-    }
     float sc[EPV], sh[EPV], mu[EPV], rs[EPV], s1[EPV], s2[EPV];
     if constexpr (RED) {
 #pragma unroll
@@ -732,13 +719,28 @@ __global__ __launch_bounds__(256) void se_scale_kernel(DykEwDesc d, int CVB) {
             s1[j] = s2[j] = 0.f;
         }
     }
-    const T* __restrict__ a = (const T*)d.a + (long)b * HW * d.lda + c;
-    const T* __restrict__ yr = (const T*)d.b + (long)b * HW * d.ldb + c;
-    T* __restrict__ o = (T*)d.out + (long)b * HW * d.ldo + c;
     const bool accum = d.flags & DYK_EW_ACCUM;
     constexpr int U = 4;
     const int pstep = (int)gridDim.y * PY;
-    if (active) {
+    // (with the reduce a workgroup walks several images: on the small maps a (channel group, pixel group, image) cell is 64 pixels,
+    // less work than the workgroup's own fold + 2 x 256 atomics -- 36 us per launch on the MobileNetV3 cfg's 16 x 20 blocks)
+    for (int b = blockIdx.z; b < d.B; b += gridDim.z) {
+        float f0[EPV], f1[EPV];
+#pragma unroll
+        for (int j = 0; j < EPV; j += 4) {
+            const float4 q = *(const float4*)(d.p0 + (long)b * d.C + c + j);
+            f0[j] = q.x; f0[j + 1] = q.y; f0[j + 2] = q.z; f0[j + 3] = q.w;
+            if (d.p1) {
+                const float4 r = *(const float4*)(d.p1 + (long)b * d.C + c + j);
+                f1[j] = r.x * d.alpha; f1[j + 1] = r.y * d.alpha; f1[j + 2] = r.z * d.alpha; f1[j + 3] = r.w * d.alpha;
+            } else {
+                f1[j] = f1[j + 1] = f1[j + 2] = f1[j + 3] = 0.f;
+            }
+        }
+        const T* __restrict__ a = (const T*)d.a + (long)b * HW * d.lda + c;
+        const T* __restrict__ yr = (const T*)d.b + (long)b * HW * d.ldb + c;
+        T* __restrict__ o = (T*)d.out + (long)b * HW * d.ldo + c;
+        if (!active) continue;
         for (int p0 = (int)blockIdx.y * PY + ty; p0 < HW; p0 += pstep * U) {
             uint4 va[U], vo[U], vy[U];
 #pragma unroll
@@ -1126,9 +1128,13 @@ extern "C" int dyk_se_scale(const DykEwDesc* d, void* stream) {
     const long cap = 4096 / ((long)gx * d->B) > 0 ? 4096 / ((long)gx * d->B) : 1;
     if (gy > cap) gy = cap;
     if (gy < 1) gy = 1;
-    const dim3 grid(gx, (int)gy, d->B);
+    dim3 grid(gx, (int)gy, d->B);
     if (d->red) {          // with the BatchNorm-backward reduce of the producer of `out`'s tensor (see the kernel)
         if (!d->b || !d->p2 || d->ldb % epv_of(d->dtype)) return DYK_ERR_ARG;
+        long nz = 768 / ((long)gx * gy);                 // ~3 workgroups per CU, each over B / nz images
+        if (nz < 1) nz = 1;
+        if (nz > d->B) nz = d->B;
+        grid.z = (unsigned)nz;
 #define DYK_SE_RED(A)                                                                                                     \
         do {                                                                                                              \
             if (d->dtype == DYK_BF16) hipLaunchKernelGGL((se_scale_kernel<bf16_t, A>), grid, dim3(256), 0, (hipStream_t)stream, *d, CVB); \
