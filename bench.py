@@ -29,7 +29,8 @@ import torch  # noqa: E402
 CFG = "kaist_dyolov4_fshare_global_concat_se3"
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
-PROFILE_TAG = "r05"            # profiles/<tag>_*.json written by tools/run_gpu_round.sh for this round
+PEAK_HBM_GBPS = 8000.0         # HBM3E (MI355X_MICROARCH.md)
+PROFILE_TAG = "r06"            # profiles/<tag>_*.json written by tools/run_gpu_round.sh for this round
 
 
 def synth_batch(B, H, W, rank, device):
@@ -65,6 +66,32 @@ def conv_flops(plan, stems=True):
             cin = 3 if r["stem"] else (1 if r["dw"] else r["x"].C)
             total += 2.0 * z.B * z.H * z.W * r["cout"] * cin * r["k"] * r["k"]
     return total
+
+
+def layer_fused_floor(plan, es, peak_flops, bw):
+    """SURVEY 8(d)(ii), literally: per [convolutional] layer of ONE pair's forward pass `max(flops_l / peak, bytes_l / BW)` with
+    `bytes_l = elem_size * (|in| + |out| + |W|)` -- every layer fused with its BatchNorm / activation, every tensor crossing
+    HBM once; a train step is 3 x B of it.  (C3: 150.7 us per pair = compute 85.7 / memory 129.1; the survey's probe: 150.9.)
+    Also returns the share of the flops that sits in compute-bound layers: which roofline bounds the cfg."""
+    tot = t_c = t_m = by_ = fl_ = fl_cb = 0.0
+    for rec in plan.info:
+        for r in (rec["parts"] if rec.get("kind") == "dwsep" else [rec]):
+            if r.get("kind") != "conv":
+                continue
+            z, k, s = r["z"], r["k"], r["stride"]
+            cin = 3 if r["stem"] else r["x"].C
+            cin_g = 1 if r["dw"] else cin
+            fl = 2.0 * z.H * z.W * r["cout"] * cin_g * k * k
+            by = es * (z.H * s * z.W * s * cin + z.H * z.W * r["cout"] + r["cout"] * cin_g * k * k)
+            tot += max(fl / peak_flops, by / bw)
+            t_c += fl / peak_flops
+            t_m += by / bw
+            by_ += by
+            fl_ += fl
+            if fl / peak_flops > by / bw:
+                fl_cb += fl
+    return {"s_per_pair": tot, "compute_s": t_c, "memory_s": t_m, "bytes_per_pair": by_, "flops_per_pair": fl_,
+            "compute_bound_flop_share": fl_cb / max(fl_, 1.0)}
 
 
 def profile_plan(plan, stream, dump=None, cmds_out=None):
@@ -220,6 +247,21 @@ def eval_bench(args):
            "nms": {"rows_per_image": int(io.shape[1]),
                    "dense_all_survive": {"ms_per_batch": t_dense * 1e3, "images_per_s": B / t_dense, "candidates_per_s": B * io.shape[1] / t_dense},
                    "sparse_300_survivors": {"ms_per_batch": t_sparse * 1e3, "images_per_s": B / t_sparse}}}
+    # AP of the 64-pair trained-head fixture on both arithmetic paths, as measured by tests/test_eval_ap.py on the running
+    # code (the test writes profiles/<tag>_ap_64pair.json through DYK_AP_JSON; reported only when its code hash matches)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from code_sha import code_sha
+        with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_ap_64pair.json")) as f:
+            aj = json.load(f)
+        if aj.get("code_sha") == code_sha() and "fp32" in aj and "bf16" in aj:
+            out["ap_64pair"] = {"reference_fp32": aj["reference"], "hip_fp32": aj["fp32"]["ap"], "hip_bf16": aj["bf16"]["ap"],
+                                "bf16_minus_fp32_ap_points": 100.0 * (aj["bf16"]["ap"] - aj["fp32"]["ap"]),
+                                "bf16_emulating_oracle": aj["bf16"].get("emulated_ap"),
+                                "this_line_dtype": args.dtype,
+                                "source": "profiles/%s_ap_64pair.json (tests/test_eval_ap.py on this code)" % PROFILE_TAG}
+    except Exception:
+        pass
     print(json.dumps(out), flush=True)
 
 
@@ -425,68 +467,114 @@ def main():
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = 2.0 * f1 / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0      # forward + data-gradient launches
             tot_ms = sum(a[1] for w in prof.values() for a in w.values())
-            # composite roofline -- every command at max(HBM time, MFMA time) of its algorithmic work
-            # (forward + data gradient + weight gradient of every layer) over the measured step
-            comp = None
+            es = 2 if args.dtype == "bf16" else 4
+            peak_f = peak * 1e12
+            # composite roofline per LAYER-FUSED pass (every layer's in + out + W once) -- `composite_roofline`;
+            # beside it, under its own name, the floor of the launches this design actually makes (every command's own
+            # algorithmic bytes / flops, i.e. the separate BatchNorm passes counted as work): `per_command_floor`
+            lf = layer_fused_floor(plan, es, peak_f, PEAK_HBM_GBPS * 1e9)
+            lf_ms = lf["s_per_pair"] * 3.0 * B * 1e3
+            comp = {"floor_ms": lf_ms, "frac": lf_ms / ms,
+                    "definition": "SURVEY 8d(ii): sum over layers of max(flops/peak, es*(|in|+|out|+|W|)/8 TB/s) of one pair's forward "
+                                  "x 3 x B / t_step", "per_pair_fwd_us": lf["s_per_pair"] * 1e6,
+                    "compute_us": lf["compute_s"] * 1e6, "memory_us": lf["memory_s"] * 1e6,
+                    "bytes_per_pair_fwd": lf["bytes_per_pair"], "compute_bound_flop_share": lf["compute_bound_flop_share"]}
+            per_cmd = None
             try:
                 from cmd_roofline import cmd_model
                 fl_ms = 0.0
                 for which in ("fwd", "bwd"):
                     for op, desc in (plan.fwd if which == "fwd" else plan.bwd):
                         _, by, fl = cmd_model(L, op, desc, plan)
-                        fl_ms += max(by / 8.0e12, fl / (PEAK_BF16_TFLOPS * 1e12 if args.dtype == "bf16" else PEAK_F32_TFLOPS * 1e12)) * 1e3
-                comp = {"floor_ms": fl_ms, "frac": fl_ms / ms}
+                        fl_ms += max(by / (PEAK_HBM_GBPS * 1e9), fl / peak_f) * 1e3
+                per_cmd = {"floor_ms": fl_ms, "frac": fl_ms / ms,
+                           "definition": "sum over the step's COMMANDS of max(bytes/8 TB/s, flops/peak) / t_step: the floor of the "
+                                         "launches as designed (separate BatchNorm passes count as work); not SURVEY 8d(ii)"}
             except Exception:
                 pass
-            # HBM-side bytes per launch and the IN-STEP durations of the same kernel come from rocprofv3 runs of this very
+            # which roofline bounds the cfg: MFMA when most of its flops sit in layers whose flop time exceeds their byte time
+            # (C3: the 3x3 convs, 84 % of the flops), HBM otherwise (the MobileNet cfgs: SURVEY 8d "(ii) with HBM only")
+            hbm_bound = lf["compute_bound_flop_share"] < 0.5
+            # HBM-side bytes per launch and the IN-STEP durations of the same kernels come from rocprofv3 runs of this very
             # command (tools/run_gpu_round.sh -> profiles/): they are reported only when those files were produced by
             # the code that is running now (hash over the kernel sources and the plan compiler), otherwise null
-            traffic, in_step, src = None, None, None
+            FAM = ("conv_igemm_kernel", "conv_halo_kernel", "conv_lt_kernel", "conv_sc_kernel", "conv_pw_kernel")
+            traffic, in_step, src, step_hbm = None, None, None, None
+            is_headline = args.cfg == CFG and B == 16 and args.dtype == "bf16"     # what profiles/<tag>_* were taken on
             try:
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
                 from code_sha import code_sha
                 sha = code_sha()
                 with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_summary.json")) as f:
                     pj = json.load(f)
-                if pj.get("code_sha") == sha:
-                    traffic = pj["kernels"]["conv_igemm_kernel"]["hbm_bytes_per_launch"]
+                if pj.get("code_sha") == sha and is_headline:
+                    ks = [pj["kernels"][k] for k in FAM if k in pj["kernels"]]
+                    # family-wide, the same base as `launches` / `flops_per_launch` below
+                    traffic = sum(k_["fetch_bytes"] + k_["write_bytes"] for k_ in ks) / max(sum(k_["dispatches"] for k_ in ks), 1)
+                    step_hbm = pj.get("step_hbm_bytes")
                     src = "profiles/%s_pmc_summary.json" % PROFILE_TAG
                 with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_step_kernels.json")) as f:
                     kj = json.load(f)
-                if kj.get("code_sha") == sha:
-                    fams = [kj["families"][k] for k in ("conv_igemm_kernel", "conv_halo_kernel", "conv_lt_kernel", "conv_sc_kernel", "conv_pw_kernel") if k in kj["families"]]
+                if kj.get("code_sha") == sha and is_headline:
+                    fams = [kj["families"][k] for k in FAM if k in kj["families"]]
                     t_us = sum(f_["total_us"] for f_ in fams)
                     in_step = {"tflops": 2.0 * f1 / (t_us * 1e-6) / 1e12, "frac": 2.0 * f1 / (t_us * 1e-6) / 1e12 / peak,
                                "launches": sum(f_["n"] for f_ in fams), "total_us": t_us,
-                               "source": "profiles/%s_step_kernels.json (rocprofv3 kernel trace of one step, three streams "
-                                         "running concurrently: durations include time shared with other kernels)" % PROFILE_TAG}
+                               "avg_launch_us": t_us / max(sum(f_["n"] for f_ in fams), 1),
+                               "source": "profiles/%s_step_kernels.json (rocprofv3 kernel trace of one step; four streams run "
+                                         "concurrently, so a launch's duration includes the time it shares the chip: the summed "
+                                         "durations exceed the step)" % PROFILE_TAG}
             except Exception:
                 pass
-            # `frac` follows from profiles/ whenever the committed rocprofv3 trace is of the running code: the
-            # in-step figure; the isolated-launch figure of this run is always reported beside it
-            frac_rocprof = in_step["frac"] if in_step else None
-            out["roofline"] = {
-                "bound": "mfma", "kernel": "conv_igemm_kernel + conv_lt_kernel + conv_halo_kernel + conv_sc_kernel + conv_pw_kernel (forward + data-gradient launches)",
-                "achieved": (in_step["tflops"] if in_step else ach), "peak": peak, "unit": "TFLOP/s",
-                "frac": (frac_rocprof if frac_rocprof is not None else ach / peak), "traffic": traffic,
-                "traffic_unit": "bytes per launch (rocprofv3 PMC, %s)" % src if src else None,
-                "frac_is": ("rocprofv3 in-step fraction (profiles/%s_step_kernels.json, code hash matches this run)" % PROFILE_TAG) if in_step
-                           else "isolated-kernel fraction: every launch timed alone on the chip with HIP events (this run; no rocprofv3 "
-                                "trace of this code hash under profiles/)",
-                "frac_rocprof": frac_rocprof,
-                "frac_isolated": ach / peak, "achieved_isolated": ach,
-                "in_step": in_step,
-                "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1),
-                "flops_per_launch": 2.0 * f1 / max(ig_n, 1),
-                "detail": {
-                    "conv_fwd_flops_per_step": f1_all, "igemm_fwd_flops_per_step": f1,
-                    "wgrad_tflops": (f1 / (wg_ms * 1e-3) / 1e12) if wg_ms > 0 else 0.0, "wgrad_ms": wg_ms, "wgrad_launches": wg_n,
-                    "igemm_ms": ig_ms, "all_kernels_ms": tot_ms,
-                    "step_mfma_frac": 3.0 * f1_all / (ms * 1e-3) / 1e12 / peak,
-                    "composite_roofline": comp,
-                    "launches_per_step": sum(a[0] for w in prof.values() for a in w.values()),
-                    "commands_per_step": sum(a[2] for w in prof.values() for a in w.values()),
-                    "per_op_ms": {w: {str(k): [a[0], round(a[1], 4)] for k, a in prof[w].items()} for w in prof}}}
+            alg_bytes_launch = None
+            try:
+                from cmd_roofline import cmd_model
+                ab = sum(cmd_model(L, op, desc, plan)[1] for which in ("fwd", "bwd")
+                         for op, desc in (plan.fwd if which == "fwd" else plan.bwd) if op == L.OP_CONV)
+                alg_bytes_launch = ab / max(ig_n, 1)
+            except Exception:
+                pass
+            detail = {
+                "conv_fwd_flops_per_step": f1_all, "igemm_fwd_flops_per_step": f1,
+                "wgrad_tflops": (f1 / (wg_ms * 1e-3) / 1e12) if wg_ms > 0 else 0.0, "wgrad_ms": wg_ms, "wgrad_launches": wg_n,
+                "igemm_ms": ig_ms, "all_kernels_ms": tot_ms,
+                "step_mfma_frac": 3.0 * f1_all / (ms * 1e-3) / 1e12 / peak,
+                "step_hbm_frac": lf["bytes_per_pair"] * 3.0 * B / (ms * 1e-3) / (PEAK_HBM_GBPS * 1e9),
+                "composite_roofline": comp, "per_command_floor": per_cmd,
+                "step_hbm_bytes_pmc": step_hbm,
+                "launches_per_step": sum(a[0] for w in prof.values() for a in w.values()),
+                "commands_per_step": sum(a[2] for w in prof.values() for a in w.values()),
+                "per_op_ms": {w: {str(k): [a[0], round(a[1], 4)] for k, a in prof[w].items()} for w in prof}}
+            if hbm_bound:
+                # "For C5 the figure is (ii) with HBM only: achieved_GBps = bytes_per_pair x 3 x B / t_step vs 8 TB/s"
+                gbps = lf["bytes_per_pair"] * 3.0 * B / (ms * 1e-3) / 1e9
+                out["roofline"] = {
+                    "bound": "hbm", "kernel": "whole step (the cfg's layers are HBM-bound: %.0f %% of its flops sit in compute-bound "
+                                              "layers)" % (100 * lf["compute_bound_flop_share"]),
+                    "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                    "traffic": step_hbm, "traffic_unit": "HBM bytes per step (rocprofv3 PMC)" if step_hbm else None,
+                    "frac_is": "layer-fused algorithmic bytes of a train step (3 x B x %.1f MB) over the measured step time"
+                               % (lf["bytes_per_pair"] / 1e6),
+                    "conv_family_mfma": {"achieved_isolated": ach, "frac_isolated": ach / peak, "launches": ig_n},
+                    "detail": detail}
+            else:
+                # `achieved` / `frac`: measured in THIS run -- every launch of the family timed alone with HIP events on the launch
+                # stream right after the timed steps (dyk_run_schedule_timed).  `in_step` is the rocprofv3 figure of the same
+                # launches while four streams share the chip (only when profiles/ holds a trace of the running code).
+                out["roofline"] = {
+                    "bound": "mfma", "kernel": "conv_igemm_kernel + conv_lt_kernel + conv_halo_kernel + conv_sc_kernel + conv_pw_kernel (forward + data-gradient launches)",
+                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                    "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch, family-wide (rocprofv3 PMC, %s)" % src if src else None,
+                    "algorithmic_bytes_per_launch": alg_bytes_launch,
+                    "frac_is": "every launch of the family timed ALONE with HIP events on its launch stream, in this run "
+                               "(profiles/%s_serial_kernels.txt: rocprofv3 --stats of the same plan on one stream); `in_step`: the "
+                               "same launches inside the four-stream step" % PROFILE_TAG,
+                    "frac_isolated": ach / peak, "achieved_isolated": ach,
+                    "frac_in_step": in_step["frac"] if in_step else None,
+                    "in_step": in_step,
+                    "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1),
+                    "flops_per_launch": 2.0 * f1 / max(ig_n, 1),
+                    "detail": detail}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cfg)
         json_out.write(json.dumps(out) + "\n")

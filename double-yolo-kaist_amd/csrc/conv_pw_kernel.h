@@ -353,6 +353,9 @@ inline bool conv_pw_eligible(const DykConvDesc* d) {
     if (d->Hg != d->Hi || d->Wg != d->Wi || d->Ho != d->Hi || d->Wo != d->Wi) return false;
     const int f = d->flags;
     if (f != 0 && f != DYK_EPI_STATS && f != DYK_EPI_BNBWD && f != (DYK_EPI_BNBWD | DYK_EPI_ADDEND)) return false;
+    // the plain / statistics epilogues (EPI 0 / 1) store the raw sums: an activation without DYK_EPI_AFFINE -- which the generic
+    // tiles do apply -- is not theirs to take
+    if (!(f & DYK_EPI_BNBWD) && d->act != DYK_ACT_LINEAR) return false;
     if (d->Cin % 32 || d->Cin > 256 || d->Cout % 8 || d->ldx % 8 || d->ldy % 8 || ((uintptr_t)d->y % 16)) return false;
     if ((f & DYK_EPI_BNBWD) && (d->ldr % 8 || ((uintptr_t)d->res % 16))) return false;
     if ((f & DYK_EPI_ADDEND) && ((uintptr_t)d->add % 16)) return false;

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "dyk_common.h"
+#include "conv_wgrad_tile.h"
 
 namespace {
 
@@ -47,64 +48,9 @@ inline unsigned wg_fill_args(WgArgs& args, const DykWgradDesc* d, int blocks) {
     return 2u * (unsigned)args.pair_blocks;
 }
 
-// a wave-uniform pointer pinned in SGPRs (the compiler cannot re-materialise it by re-loading the kernel argument in the loop)
-template <typename P> __device__ inline P* wg_sgpr_ptr(P* p) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (P*)(((unsigned long long)hi << 32) | lo);
-}
-
-typedef short v4i16_t __attribute__((__vector_size__(4 * sizeof(short))));
-#define LDS_AS __attribute__((address_space(3)))
-
 template <typename T> struct WgTraits;
 template <> struct WgTraits<bf16_t> { static constexpr int ROWS = 64; };  // pixels per K step
 template <> struct WgTraits<float>  { static constexpr int ROWS = 32; };
-
-// byte offset of (row, channel) in a [ROWS][C] tile, row bytes RB = C*sizeof(T)
-template <typename T, int C> __device__ inline int wg_off(int row, int ch) {
-    constexpr int RB = C * (int)sizeof(T);
-    if (sizeof(T) == 2) {
-        constexpr int NCH = RB / 32;                     // 32-byte chunks per row
-        // A 32-lane group of the transposing fragment read touches ONE 32-byte chunk column of the eight rows
-        // b + {0,1,2,3, 8,9,10,11} (b = K offset of the step, plus the tap shift in the multi-tap kernel: any value).  Rows
-        // that are congruent modulo 256 / RB share their banks, so the XOR key must tell exactly those rows apart -- from row
-        // bits that differ for ANY b: 256-byte rows (all eight collide) bits 0,1,3; 128-byte rows (the four of equal parity
-        // collide) bits 1,3; 64-byte rows (b + i and b + 8 + i collide) bit 3.  (Rounds 1-3 keyed every width with
-        // `row & 3 | bit 3 << 2` masked to the chunk count: right for 256-byte rows only -- 64-wide tiles, i.e. every dy tile
-        // of the multi-tap kernel, read with 2-way conflicts: 57 % of its LDS cycles in the round-3 counters.)
-        const int f = NCH >= 8 ? ((row & 3) | (((row >> 3) & 1) << 2)) & (NCH - 1)
-                    : NCH == 4 ? (((row >> 1) & 1) | (((row >> 3) & 1) << 1))
-                    : NCH == 2 ? ((row >> 3) & 1) : 0;
-        const int chunk = (ch >> 4) ^ f;
-        return row * RB + chunk * 32 + (ch & 15) * 2;
-    } else {
-        constexpr int NCH = RB / 64;                     // 64-byte chunks per row
-        const int chunk = (ch >> 4) ^ (row & 1 & (NCH - 1));
-        return row * RB + chunk * 64 + (ch & 15) * 4;
-    }
-}
-
-// one LDS-DMA wave instruction (see conv_igemm.hip: issued via inline asm so that hipcc does not
-// drain vmcnt(0) in front of every LDS read while the ring is in flight)
-__device__ uint4 dyk_wg_zero_page[8];
-__device__ inline void wg_glds16(const void* gsrc, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_addr)
-                 : "memory");
-}
-__device__ inline unsigned wg_lds_addr(const void* p) {
-    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(LDS_AS const char*)p);
-}
-
-// logical channel stored at physical 16-byte slot `ps` of tile row `row` (inverse of wg_off's swizzle,
-// which is an XOR on the 32-byte (bf16) / 64-byte (f32) chunk index and therefore its own inverse)
-template <typename T, int C> __device__ inline int wg_logical_ch(int row, int ps) {
-    constexpr int EPV = 16 / (int)sizeof(T);
-    return (wg_off<T, C>(row, ps * EPV) - row * C * (int)sizeof(T)) / (int)sizeof(T);
-}
 
 // PIPE: LDS-DMA ring stages (2 | 3)
 // KG:   K-groups per workgroup.  The fp32 atomics of the epilogue run at ~1 element/clk/L2 channel, so their
@@ -746,6 +692,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(float* __restrict__ G,
 // row-block 3x3 kernel (conv_wgrad_rb.hip): tune bits 28..30 == 2; bits 8..15 == 2 selects 256-pixel K steps
 bool dyk_wgrad_rb_eligible(const DykWgradDesc* d);
 int dyk_wgrad_rb_dispatch(const DykWgradDesc* d, hipStream_t s, int* query);
+// pixel-streaming 1x1 kernel (conv_wgrad_ps.hip): tune bits 28..30 == 3
+bool dyk_wgrad_ps_eligible(const DykWgradDesc* d);
+int dyk_wgrad_ps_dispatch(const DykWgradDesc* d, hipStream_t s, int* query_splits, int* query_tiles, int64_t* query_slab);
 
 static int wgrad_validate(const DykWgradDesc* d) {
     if (!d || !d->x || !d->dy || !d->dw) return DYK_ERR_ARG;
@@ -773,6 +722,8 @@ extern "C" int dyk_conv_wgrad(const DykWgradDesc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (((d->tune >> 28) & 7) == 1 && mt_eligible(d)) return dispatch_wgrad_mt(d, s, nullptr);    // multi-tap 3x3 variant
     if (((d->tune >> 28) & 7) == 2 && dyk_wgrad_rb_eligible(d)) return dyk_wgrad_rb_dispatch(d, s, nullptr);   // row-block 3x3 variant
+    if (((d->tune >> 28) & 7) == 3 && dyk_wgrad_ps_eligible(d)) return dyk_wgrad_ps_dispatch(d, s, nullptr, nullptr, nullptr);   // pixel-streaming 1x1 variant
+    if (d->sk_cnt && !d->part) return DYK_ERR_UNSUPPORTED;      // the in-launch fold exists in the pixel-streaming and row-block kernels only
     if (d->dtype == DYK_BF16) return dispatch_wgrad<bf16_t>(d, s, nullptr);
     if (d->dtype == DYK_F32) return dispatch_wgrad<float>(d, s, nullptr);
     return DYK_ERR_ARG;
@@ -785,6 +736,7 @@ extern "C" int dyk_conv_wgrad_splits(const DykWgradDesc* d) {
     int rc = DYK_ERR_ARG;
     if (((d->tune >> 28) & 7) == 1 && mt_eligible(d)) rc = dispatch_wgrad_mt(d, nullptr, &q);
     else if (((d->tune >> 28) & 7) == 2 && dyk_wgrad_rb_eligible(d)) rc = dyk_wgrad_rb_dispatch(d, nullptr, &q);
+    else if (((d->tune >> 28) & 7) == 3 && dyk_wgrad_ps_eligible(d)) rc = dyk_wgrad_ps_dispatch(d, nullptr, &q, nullptr, nullptr);
     else if (d->dtype == DYK_BF16) rc = dispatch_wgrad<bf16_t>(d, nullptr, &q);
     else if (d->dtype == DYK_F32) rc = dispatch_wgrad<float>(d, nullptr, &q);
     return rc == DYK_OK ? q : rc;
@@ -794,7 +746,29 @@ extern "C" int dyk_conv_wgrad_variant(const DykWgradDesc* d) {
     if (!d || d->ntaps <= 0 || d->ntaps > DYK_MAX_TAPS) return DYK_ERR_ARG;
     if (((d->tune >> 28) & 7) == 1 && mt_eligible(d)) return 1;
     if (((d->tune >> 28) & 7) == 2 && dyk_wgrad_rb_eligible(d)) return 2;
+    if (((d->tune >> 28) & 7) == 3 && dyk_wgrad_ps_eligible(d)) return 3;
     return 0;
+}
+
+extern "C" int64_t dyk_conv_wgrad_fold_ws_bytes(const DykWgradDesc* d, int32_t* tiles) {
+    if (!d || d->ntaps <= 0 || d->ntaps > DYK_MAX_TAPS || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0 || d->Cin <= 0)
+        return DYK_ERR_ARG;
+    if (tiles) *tiles = 0;
+    if (d->splits < 2) return 0;
+    int sp = 0, nt = 0;
+    int64_t slab = 0;
+    if (((d->tune >> 28) & 7) == 3 && dyk_wgrad_ps_eligible(d)) {
+        DykWgradDesc q = *d;                      // (the count as the fold mode will see it: `splits` taken literally)
+        q.part = nullptr;
+        uint32_t dummy = 0;
+        q.sk_cnt = &dummy;
+        if (dyk_wgrad_ps_dispatch(&q, nullptr, &sp, &nt, &slab) != DYK_OK) return DYK_ERR_ARG;
+    } else {
+        return 0;                                 // kernels without the in-launch fold
+    }
+    if (sp < 2) return 0;
+    if (tiles) *tiles = nt;
+    return (int64_t)nt * sp * slab;
 }
 
 extern "C" int dyk_grad_reduce(float* G, const float* part, const DykGradReduceEntry* tab, int32_t n_entries,

@@ -899,7 +899,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const uint4* prow = patch + ((r + kh) * IC + strip * XT) * S + cct;
                 // v_dot2c_f32_bf16: acc += x.lo * g.lo + x.hi * g.hi on the PACKED pairs -- with one half of g masked to zero
                 // it is the fp32 multiply-add of one channel (a bf16 x bf16 product is exact in fp32: one rounding, as the
-                // fma), and the x vectors need no unpacking: 8 VALU ops fewer per input vector
+                // fma), and the x vectors need no unpacking: 8 VALU ops fewer per input vector.
+                // PROPERTY: the unmasked neighbour half of x still meets the zero half of g, so a NON-FINITE x in
+                // channel c ^ 1 turns the gradient of channel c into NaN (0 * Inf) where the row kernel (fp32 fma per channel,
+                // stride 2 / fp32 shapes) keeps the channels apart; finite inputs give the same sums as that kernel up to the
+                // summation order.  Masking x as well would put the 8 VALU ops per vector back that this form saves; a
+                // non-finite activation already poisons the step's loss (GradScaler skips it), so the forms are not unified.
                 unsigned gm[XT][EPV];
 #pragma unroll
                 for (int o = 0; o < XT; ++o) {

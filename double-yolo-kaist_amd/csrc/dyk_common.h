@@ -230,11 +230,9 @@ struct DykDeviceOnce {
     bool first() {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return true;
-        unsigned long long& w = seen[(dev >> 6) & 3];
+        // (atomic: two host threads launching on different devices share the word)
         const unsigned long long bit = 1ull << (dev & 63);
-        if (w & bit) return false;
-        w |= bit;
-        return true;
+        return (__atomic_fetch_or(&seen[(dev >> 6) & 3], bit, __ATOMIC_ACQ_REL) & bit) == 0;
     }
 };
 

@@ -268,6 +268,10 @@ extern "C" int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream,
             case DYK_OP_MEMSET:
                 rc = (m->p[0] && m->n > 0 && hipMemsetAsync(m->p[0], m->i[0], (size_t)m->n, (hipStream_t)stream) == hipSuccess)
                          ? DYK_OK : DYK_ERR_HIP;
+                // second region (p[1], i[1] bytes, zeros): the split-K tile counters of the plan's convolutions, re-armed once
+                // per pass so that a launch that faulted / was aborted cannot leave a ticket behind for every later step
+                if (rc == DYK_OK && m->p[1] && m->i[1] > 0 &&
+                    hipMemsetAsync(m->p[1], 0, (size_t)m->i[1], (hipStream_t)stream) != hipSuccess) rc = DYK_ERR_HIP;
                 break;
             case DYK_OP_YOLO_DECODE: rc = dyk_yolo_decode((const DykDecodeDesc*)dp, stream); break;
             case DYK_OP_DW_FWD: rc = dyk_dwconv_fwd((const DykDwDesc*)dp, stream); break;

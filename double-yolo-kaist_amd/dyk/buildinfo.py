@@ -21,11 +21,16 @@ def native_sources():
 
 
 def native_sha():
+    """digest of the in-tree native sources, or None when the sources are not there (a deployment that ships only the
+    library: nothing to compare the build against)"""
     h = hashlib.sha1()
-    for f in native_sources():
-        h.update(os.path.relpath(f, ROOT).encode())
-        with open(f, "rb") as fh:
-            h.update(fh.read())
+    try:
+        for f in native_sources():
+            h.update(os.path.relpath(f, ROOT).encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    except OSError:
+        return None
     return h.hexdigest()[:16]
 
 

@@ -67,6 +67,7 @@ class DykWgradDesc(ctypes.Structure):
         ("tdy", _i8 * MAX_TAPS), ("tdx", _i8 * MAX_TAPS), ("twt", _i8 * MAX_TAPS), ("_pad", _i8),
         ("splits", _i32), ("lddw", _i32), ("tune", _i32),
         ("twin", _vp),
+        ("sk_ws", _vp), ("sk_cnt", _vp), ("sk_ws_bytes", _i64), ("sk_cnt_n", _i32), ("_pad2", _i32),
     ]
 
 
@@ -192,6 +193,7 @@ SIGNATURES = {
     "dyk_conv_wgrad": (_i32, [_P(DykWgradDesc), _vp]),
     "dyk_conv_wgrad_splits": (_i32, [_P(DykWgradDesc)]),
     "dyk_conv_wgrad_variant": (_i32, [_P(DykWgradDesc)]),
+    "dyk_conv_wgrad_fold_ws_bytes": (_i64, [_P(DykWgradDesc), _P(_i32)]),
     "dyk_grad_reduce": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dyk_bn_finalize": (_i32, [_P(DykBnFinalizeDesc), _vp]),
     "dyk_bn_finalize_act_fwd": (_i32, [_P(DykBnFinalizeDesc), _P(DykEwDesc), _vp]),
@@ -256,7 +258,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 4          # = DYK_ABI_VERSION of include/dyk_hip.h: a stale .so with older descriptor layouts is refused
+ABI_VERSION = 5          # = DYK_ABI_VERSION of include/dyk_hip.h: a stale .so with older descriptor layouts is refused
 
 
 def load(path=None):
@@ -287,7 +289,7 @@ def load(path=None):
         # caller's business: tools/ab.sh compares builds of different sources)
         from .buildinfo import native_sha
         built, tree = lib.dyk_build_sha().decode(), native_sha()
-        if built != tree:
+        if tree is not None and built != tree:      # (None: no sources beside the library -- a packaged copy; nothing to check)
             raise DykLibraryError("%s was built from other sources (digest %s, tree %s): rebuild it with "
                                   "`python -c 'import __graft_entry__ as g; g.build()'`" % (p, built, tree))
     _lib = lib

@@ -1423,6 +1423,10 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     plan.sk_bytes = 0
     if not dry:
         _setup_splitk(plan, device)
+        if training and plan.sk_cnt is not None:
+            # the pass's statistics memset (head of the forward list, a barrier for the scheduler) also zeroes the tile
+            # counters: they re-arm themselves, but only if every split-K launch runs to its end
+            stats_memset.p[1], stats_memset.i[1] = plan.sk_cnt.data_ptr(), 4 * plan.sk_cnt.numel()
     plan.part = None
     plan.bwd_cut_ok = None
     if training and not dry and os.environ.get("DYK_WGRAD_PARTIALS", "1") != "0":
@@ -1750,6 +1754,8 @@ def pw_eligible(d):
         return False
     if d.flags not in (0, L.EPI_STATS, L.EPI_BNBWD, L.EPI_BNBWD | L.EPI_ADDEND):
         return False
+    if not (d.flags & L.EPI_BNBWD) and d.act != L.ACT_CODES["linear"]:      # (EPI 0 / 1 never apply an activation)
+        return False
     return d.Cin % 32 == 0 and d.Cin <= 256 and d.Cout % 8 == 0 and d.ldx % 8 == 0 and d.ldy % 8 == 0
 
 
@@ -1860,6 +1866,13 @@ WGRAD_EXCLUSIVE = 1 << 20      # the plan's weight gradients have one writer eac
 _WGRAD_CANDIDATES = [2, 3, 2 | (2 << 8), 2 | (1 << 24), 3 | (1 << 24), 2 | (2 << 8) | (1 << 24), 2 | (1 << 28)]
 if os.environ.get("DYK_WGRAD_RB", "1") != "0":
     _WGRAD_CANDIDATES.append(2 | (1 << 8) | (2 << 28) | WGRAD_EXCLUSIVE)
+if os.environ.get("DYK_WGRAD_PS", "1") != "0":
+    # pixel-streaming 1x1 kernel (round 6, csrc/conv_wgrad_ps.hip): ring stages in the low byte, 64 x 64 tile cap << 8,
+    # 64-pixel stages for the 64 x 64 tile << 12; ignored (falls back to the per-tap kernel = candidate 2) where it does not apply
+    _WGRAD_PS = 3 << 28
+    _WGRAD_CANDIDATES += [_WGRAD_PS | 2 | WGRAD_EXCLUSIVE, _WGRAD_PS | 3 | WGRAD_EXCLUSIVE, _WGRAD_PS | 4 | WGRAD_EXCLUSIVE,
+                          _WGRAD_PS | 6 | WGRAD_EXCLUSIVE, _WGRAD_PS | 4 | (1 << 8) | WGRAD_EXCLUSIVE,
+                          _WGRAD_PS | 8 | (1 << 8) | (1 << 12) | WGRAD_EXCLUSIVE]
 # LDS ring stages (2 | 3; 4 exists in the kernel, measured never the fastest: DESIGN 9.4) | K-groups per workgroup << 8 | tile cap << 24 (1 = 64 x 64) | 1 << 28 = multi-tap 3x3 kernel
 # | 2 << 28 = row-block 3x3 kernel (round 4: 128-pixel block steps, 64 x 32 x 9-tap tiles)
 
@@ -2032,6 +2045,8 @@ def autotune(plan, cache=None):
                     combos, times = [], []
                     for c in cands:
                         d.tune, d.part, d.part_stride, d.splits = c, None, 0, 0
+                        if (c >> 28) & 7 and lib.dyk_conv_wgrad_variant(ctypes.byref(d)) != (c >> 28) & 7:
+                            continue           # a kernel variant this problem is not eligible for (it would time the fallback again)
                         auto = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
                         if auto < 1:
                             continue
@@ -2068,6 +2083,8 @@ def autotune(plan, cache=None):
                                 sk_scratch[0] = torch.empty(need, dtype=torch.uint8, device=dev)
                             if sk_scratch[1] is None or sk_scratch[1].numel() < nt.value:
                                 sk_scratch[1] = torch.zeros(max(nt.value, 4096), dtype=torch.int32, device=dev)
+                            else:
+                                sk_scratch[1].zero_()          # (a trial of another shape must not have left a ticket behind)
                             d.sk_ws, d.sk_ws_bytes = sk_scratch[0].data_ptr(), need
                             d.sk_cnt, d.sk_cnt_n = sk_scratch[1].data_ptr(), nt.value
                             if fn(ctypes.byref(d), stream) != 0:       # (a shape the chosen kernel cannot split: not a candidate)

@@ -111,8 +111,8 @@ def pair_signature(op, d, plan):
                                             # two-problem launch it would fall back to the generic kernel, whose epilogue rounds differently
         return (op, _bytes(d, L.DykConvDesc, "dtype", "twin"), _nulls(d, ("scale", "shift", "res", "stats", "aux0", "aux1", "add")))
     if op == L.OP_WGRAD:
-        if ((d.tune >> 28) & 7) == 2:
-            return None                     # row-block 3x3 kernel (csrc/conv_wgrad_rb.hip): single problem only
+        if ((d.tune >> 28) & 7) in (2, 3):
+            return None                     # row-block 3x3 / pixel-streaming 1x1 kernels (csrc/conv_wgrad_rb.hip, conv_wgrad_ps.hip): single problem only
         return (op, _bytes(d, L.DykWgradDesc, "part_stride", "twin"), bool(d.part))
     if op in (L.OP_BN_ACT_FWD, L.OP_BN_BWD_REDUCE, L.OP_BN_BWD_APPLY, L.OP_AXPBY):
         return (op, _bytes(d, L.DykEwDesc, "dtype", "twin"), _nulls(d, _EW_PTRS))

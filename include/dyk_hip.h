@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DYK_ABI_VERSION 4   /* 4: round 5, DykConvDesc split-K fields (sk_ws .. splitk), dyk_build_sha; 3: round 4, DykStemDesc fused BatchNorm-backward apply (bn_* fields); 2: round-3 descriptor layouts */
+#define DYK_ABI_VERSION 5   /* 5: round 6, DykWgradDesc in-launch fold fields (sk_ws .. sk_cnt_n), dyk_conv_wgrad_fold_ws_bytes, second region of DYK_OP_MEMSET; 4: round 5, DykConvDesc split-K fields (sk_ws .. splitk), dyk_build_sha; 3: round 4, DykStemDesc fused BatchNorm-backward apply (bn_* fields); 2: round-3 descriptor layouts */
 
 enum {
     DYK_OK = 0,
@@ -229,9 +229,23 @@ typedef struct DykWgradDesc {
                                        K steps of 128 pixels -- 256 with K-groups field = 2 -- shaped nimg x rows x columns to
                                        fit the map, 64 x 32 x 9-tap tiles; ignored where it does not apply) | 1 << 20: the caller vouches
                                        that nothing else adds to dw while the launch runs -- a launch with ONE K split may then
-                                       read-add-write its tiles instead of issuing atomics (row-block kernel) */
+                                       read-add-write its tiles instead of issuing atomics (row-block kernel)
+                                       | 3 << 28: pixel-streaming kernel (1x1 / stride 1, bf16: 8-wave workgroups, LDS-DMA ring of up
+                                       to 8 stages; low byte = ring stages, bits 8..11 = 1 caps the tile at 64 x 64, bits 12..15 = 1:
+                                       64-pixel stages for 64 x 64 tiles; ignored where it does not apply) */
     const struct DykWgradDesc* twin;/* HOST pointer or NULL: second problem of identical geometry / splits / tune whose x, dy, dw, part
                                        are used (two-problem launch, see DykConvDesc.twin) */
+    /* In-launch fold of the K splits (ABI 5; part == NULL, splits >= 2; kernels: pixel-streaming 1x1): the S slices of an
+     * output tile hand their accumulators over through private write-through slabs in sk_ws, take a ticket on sk_cnt[tile],
+     * and the workgroup that draws the last ticket adds the S slabs IN SLICE ORDER (bit-reproducible) and adds the folded tile
+     * to dw -- read-add-write when tune bit 20 vouches for a single writer, fp32 atomics otherwise.  No partial planes, no
+     * dyk_grad_reduce entry.  sk_ws: 16-byte aligned, sk_ws_bytes >= dyk_conv_wgrad_fold_ws_bytes(desc); sk_cnt: sk_cnt_n >=
+     * tiles 32-bit words, ZERO before the first launch (the last arriver re-arms its word).  NULL: off. */
+    void* sk_ws;
+    uint32_t* sk_cnt;
+    int64_t sk_ws_bytes;
+    int32_t sk_cnt_n;
+    int32_t _pad2;
 } DykWgradDesc;
 
 int dyk_conv_wgrad(const DykWgradDesc* desc, void* stream);
@@ -239,9 +253,13 @@ int dyk_conv_wgrad(const DykWgradDesc* desc, void* stream);
  * number of planes a `part` buffer must hold.  Negative = error code. */
 int dyk_conv_wgrad_splits(const DykWgradDesc* desc);
 /* Which kernel dyk_conv_wgrad runs for this descriptor (its `tune` included): 0 = per-tap split-K kernel, 1 = multi-tap
- * 3x3 kernel (row segments), 2 = row-block 3x3 kernel (conv_wgrad_rb.hip).  A tune word that asks for a 3x3 variant the
- * problem is not eligible for falls back to 0.  Negative = error code. */
+ * 3x3 kernel (row segments), 2 = row-block 3x3 kernel (conv_wgrad_rb.hip), 3 = pixel-streaming 1x1 kernel
+ * (conv_wgrad_ps.hip).  A tune word that asks for a variant the problem is not eligible for falls back to 0.
+ * Negative = error code. */
 int dyk_conv_wgrad_variant(const DykWgradDesc* desc);
+/* in-launch fold scratch of `desc` (its tune word and `splits` >= 2, taken literally): bytes of sk_ws, and (via *tiles, may be
+ * NULL) the words of sk_cnt.  0 when the kernel the tune word selects has no in-launch fold or splits < 2; negative = error */
+int64_t dyk_conv_wgrad_fold_ws_bytes(const DykWgradDesc* desc, int32_t* tiles);
 
 /* G[g_off + i] += sum_s part[part_off + s * plane + i], i < n, for every entry of a device table: folds the per-split
  * planes written by dyk_conv_wgrad into the flat gradient buffer, one launch for many layers.  n is a multiple of 4;
@@ -568,7 +586,7 @@ enum {
     DYK_OP_HEAD_PERMUTE_FWD = 21, /* Misc: p0=y p1=p i0=B i1=ny i2=nx i3=na i4=no i5=ld */
     DYK_OP_HEAD_PERMUTE_BWD = 22, /* Misc: p0=dp p1=dy p2=dbias i0..i5 as fwd, i6=dtype */
     DYK_OP_PATCH_GATHER = 23,   /* Misc: p0=in p1=out i0=B i1=Cin i2=H i3=W i4=k i5=stride i6=pad i7=ld i8=dtype f0=mul */
-    DYK_OP_MEMSET = 24,         /* Misc: p0=ptr n=bytes i0=value */
+    DYK_OP_MEMSET = 24,         /* Misc: p0=ptr n=bytes i0=value; optional second region p1=ptr i1=bytes (zeros) */
     DYK_OP_YOLO_DECODE = 25,    /* DykDecodeDesc */
     DYK_OP_DW_FWD = 26,         /* DykDwDesc -> dyk_dwconv_fwd */
     DYK_OP_DW_DGRAD = 27,       /* DykDwDesc -> dyk_dwconv_dgrad */

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(h, n), "libdyk_hip.so does not export %s" % n
     assert sorted(lib.SIGNATURES) == names, "ctypes table and header disagree: %s" % (
         set(lib.SIGNATURES) ^ set(names))
-    assert h.dyk_abi_version() == 4
+    assert h.dyk_abi_version() == 5
     assert h.dyk_error_string(0) == b"ok" and h.dyk_error_string(-1) != b"ok"
 
 

@@ -316,9 +316,31 @@ def test_oracle_eval_chain_reproduces_the_64_pair_reference_ap():
     assert 0.6 < float(GOLD5["ap"]) < 0.95 and GOLD5["score_hist"][6:].sum() >= 200       # informative AP, a confident mode
 
 
+def _record_ap(dtype, rec):
+    """DYK_AP_JSON=path: keep the measured AP of both arithmetic paths (with the hash of the code that produced them) for
+    `bench.py --mode eval`, which prints the bf16-vs-fp32 gap beside its throughput"""
+    import json
+    import os
+    path = os.environ.get("DYK_AP_JSON")
+    if not path:
+        return
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from code_sha import code_sha
+    doc = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            doc = json.load(f)
+    if doc.get("code_sha") != code_sha():
+        doc = {"code_sha": code_sha(), "reference": float(GOLD5["ap"]), "fixture": "tests/golden/evalap_trained64.npz"}
+    doc[dtype] = rec
+    with open(path, "w") as f:
+        json.dump(doc, f)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_hip_eval_chain_matches_the_64_pair_reference_ap(dtype):
+@pytest.mark.parametrize("dtype,tiles", [("fp32", "tuned"), ("bf16", "pinned"), ("bf16", "tuned")], indirect=["tiles"])
+def test_hip_eval_chain_matches_the_64_pair_reference_ap(dtype, tiles):
     """north_star: "eval AP@IoU=0.5 within +-0.1 of the reference on identical inputs" on the fixture that can resolve it.
     fp32 path: 0.1 AP POINT (1e-3 absolute) of the fp32 reference, same detection count.  bf16 MFMA path (what autocast callers
     and `bench.py --mode eval` run): measured and bounded below; INTEGRATION.md names fp32 evaluation as the parity path."""
@@ -339,6 +361,9 @@ def test_hip_eval_chain_matches_the_64_pair_reference_ap(dtype):
     res, ndet = _ap5(dets, scale_coords, compute_ap_lamr, targets)
     print("64-pair trained-head net, %s: AP %.5f (reference %.5f)  LAMR %.5f (reference %.5f)  %d detections (reference %d)"
           % (dtype, res["ap"], GOLD5["ap"], res["lamr"], GOLD5["lamr"], ndet, int(GOLD5["ndet"].sum())))
+    rec = {"ap": float(res["ap"]), "lamr": float(res["lamr"]), "detections": int(ndet)}
+    if tiles == "tuned":                      # (what `bench.py --mode eval` runs)
+        _record_ap(dtype, rec)
     if dtype == "fp32":
         assert abs(res["ap"] - float(GOLD5["ap"])) <= 1e-3 and abs(res["lamr"] - float(GOLD5["lamr"])) <= 5e-3
         assert ndet == int(GOLD5["ndet"].sum())
@@ -359,12 +384,23 @@ def test_hip_eval_chain_matches_the_64_pair_reference_ap(dtype):
         dets_e = onms.non_max_suppression(io_e, conf_thres=R5.CONF, iou_thres=R5.IOU, multi_label=False)
         emu, nde = _ap5(dets_e, onms.scale_coords, ometrics.compute_ap_lamr, targets)
         print("bf16-emulating oracle: AP %.5f LAMR %.5f, %d detections" % (emu["ap"], emu["lamr"], nde))
+        rec["emulated_ap"] = float(emu["ap"])
+        if tiles == "tuned":
+            _record_ap(dtype, rec)
         # (measured on three boxes / builds whose autotuners chose different tiles: 0.73556, 0.73683 and 0.73110 against the oracle's
         # 0.73561 -- 0.005, 0.12 and 0.45 AP points; one rank swap on this fixture is worth 0.03-0.1 points, 915 / 929 detections
         # against the fp32 reference's 910.  The oracle is ONE summation order of the same bf16 arithmetic, the tuner's choice
         # another.  Over nine tunings (three boxes, then six fresh tunings of one build with DYK_TUNE_CACHE=0) the bf16 AP spans
         # 0.7296 ... 0.7368, i.e. -0.60 ... +0.12 points around the oracle's sample and 1.8 ... 2.5 points below fp32: bounds 1.0
         # and 3.5 points)
-        assert abs(res["ap"] - emu["ap"]) <= 1e-2, (res["ap"], emu["ap"])
+        # (round 6: 0.6 AP point with the tile choice pinned -- the summation order is then part of the fixture; the autotuned
+        # variant is a SMOKE test at the measured spread of nine tunings, 1.0 point)
+        # Pinned, measured (round 6): AP 0.74166 -- BETWEEN the emulating oracle's 0.73561 and the fp32 reference's 0.75445.  A bf16
+        # path that lands closer to the fp32 truth than the emulation is not in error, so the pinned bound is one-sided: at most
+        # 0.6 point BELOW the emulating oracle, at most 0.1 point above the fp32 reference.
+        if tiles == "pinned":
+            assert emu["ap"] - 6e-3 <= res["ap"] <= float(GOLD5["ap"]) + 1e-3, (tiles, res["ap"], emu["ap"], float(GOLD5["ap"]))
+        else:
+            assert abs(res["ap"] - emu["ap"]) <= 1e-2, (tiles, res["ap"], emu["ap"])
         assert abs(res["lamr"] - emu["lamr"]) <= 3e-2, (res["lamr"], emu["lamr"])
         assert abs(res["ap"] - float(GOLD5["ap"])) <= 3.5e-2, (res["ap"], float(GOLD5["ap"]))  # (the cost of bf16 storage itself)

@@ -723,6 +723,112 @@ def test_wgrad_row_block_kernel(case):
 
 
 
+PS_CASES = [
+    # (B, Cin, Cout, H, W)
+    (2, 128, 128, 16, 20),      # one 128 x 128 tile, 640 pixels = 10 stages
+    (2, 256, 128, 16, 20),      # two tiles along Cin
+    (3, 128, 256, 9, 13),       # two tiles along Cout, ragged pixel count (351: the last stage is part zero page)
+    (2, 64, 64, 32, 40),        # 64 x 64 tile, 128-pixel (and 64-pixel) stages
+    (2, 64, 128, 16, 20),       # 128 x 64 tile
+    (2, 128, 64, 16, 20),       # 64 x 128 tile
+    (2, 72, 18, 8, 10),         # head-like: channel counts off the tiles (zero page rows, guarded stores)
+    (1, 512, 256, 16, 20),      # 2 x 4 tiles
+    (1, 32, 96, 8, 8),          # fewer pixels than one ring (64 pixels: a single stage)
+    (2, 1024, 512, 4, 5),       # deep-stage channel counts, 40 pixels: less than one stage
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", PS_CASES, ids=lambda c: "b%d_c%d_%d_%dx%d" % c)
+def test_wgrad_pixel_streaming_kernel(case):
+    """tune bits 28-30 == 3 (conv_wgrad_ps.hip, round 6): the 1x1 weight gradient as a pixel stream -- 8-wave workgroups
+    (2 K-halves x 2 x 2 waves), LDS-DMA ring of 2-8 stages, symmetric K-half exchange.  Every ring depth / tile cap / stage
+    length, in atomic, single-writer, plane and in-launch-fold mode, against torch's conv2d_weight on the same rounded
+    operands; the kernel must be the one that ran; plane and fold results are bit-reproducible."""
+    import ctypes
+    from dyk import lib as L
+    from dyk import ops
+    B, Cin, Cout, H, W = case
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    dy = torch.randn(B, Cout, H, W, generator=g).bfloat16().float()
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 1, 1), dy).reshape(Cout, Cin)
+    xd, dyd = ops.to_nhwc(x.cuda(), dtype), ops.to_nhwc(dy.cuda(), dtype)
+    tol = 2e-4 * ref.abs().max().item()
+    lib = L.load()
+
+    def desc(tune, splits=0):
+        d = L.DykWgradDesc()
+        d.x, d.dy = xd.data_ptr(), dyd.data_ptr()
+        d.dtype = ops.dtype_code(dtype)
+        d.ldx, d.lddy = ops.nhwc_ld(xd), ops.nhwc_ld(dyd)
+        d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, Cin, H, W, Cout
+        d.isy = d.isx = 1
+        d.ntaps = 1
+        d.tdy[0] = d.tdx[0] = d.twt[0] = 0
+        d.tune, d.splits = tune, splits
+        return d
+
+    PS = 3 << 28
+    tunes = [PS | ns for ns in (2, 3, 4, 6, 8)] + [PS | ns | (1 << 8) for ns in (2, 4)] + [PS | ns | (1 << 8) | (1 << 12) for ns in (2, 4, 8)]
+    for tune in tunes:
+        assert lib.dyk_conv_wgrad_variant(ctypes.byref(desc(tune))) == 3, "the pixel-streaming kernel does not cover this case"
+        got = ops.conv2d_wgrad(xd, dyd, 1, 1, 0, tune=tune).view(Cout, Cin)              # atomics, the kernel's own split count
+        assert (got.cpu() - ref).abs().max().item() <= tol, hex(tune)
+        # one split + the caller's word that dw has no other writer: read-add-write, ACCUMULATES
+        acc0 = torch.full((1, Cout, Cin), 0.5, device="cuda")
+        one = ops.conv2d_wgrad(xd, dyd, 1, 1, 0, tune=tune | (1 << 20), splits=1, dw=acc0.clone()).view(Cout, Cin)
+        assert ((one - 0.5).cpu() - ref).abs().max().item() <= tol, hex(tune)
+    for tune in (PS | 4, PS | 4 | (1 << 8)):
+        for want in (0, 3, 7):
+            # planes: exactly `want` of them when given (trailing empty ones hold zeros)
+            d = desc(tune, want)
+            splits = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
+            assert splits >= 1 and (want == 0 or splits <= want)
+            n = max(splits, want)
+            plane = Cout * Cin
+            runs = []
+            for _ in range(2):
+                part = torch.full((n * plane,), float("nan"), device="cuda")
+                G = torch.zeros(plane, device="cuda")
+                d.dw, d.part, d.part_stride, d.splits = G.data_ptr(), part.data_ptr(), plane, n
+                L.check(lib.dyk_conv_wgrad(ctypes.byref(d), None), "dyk_conv_wgrad(pixel-streaming, planes)")
+                got = part.view(n, Cout, Cin).sum(0)
+                assert bool(torch.isfinite(got).all())
+                assert (got.cpu() - ref).abs().max().item() <= tol
+                assert float(G.abs().max()) == 0.0
+                runs.append(part.clone())
+            assert torch.equal(runs[0], runs[1])
+        for want in (2, 3, 5):
+            # in-launch fold: S slices per tile through slabs + ticket; the last arriver adds them in slice order into dw
+            d = desc(tune | (1 << 20), want)
+            nt = ctypes.c_int32(0)
+            need = int(lib.dyk_conv_wgrad_fold_ws_bytes(ctypes.byref(d), ctypes.byref(nt)))
+            if need == 0:
+                continue                               # fewer stages than slices: nothing to fold (single split)
+            assert need > 0 and nt.value >= 1
+            ws = torch.full((need // 4,), float("nan"), device="cuda")
+            cnt = torch.zeros(nt.value, dtype=torch.int32, device="cuda")
+            d.sk_ws, d.sk_ws_bytes, d.sk_cnt, d.sk_cnt_n = ws.data_ptr(), need, cnt.data_ptr(), nt.value
+            runs = []
+            for _ in range(3):                         # (the counters re-arm themselves: three launches on one scratch set)
+                G = torch.full((Cout, Cin), 0.25, device="cuda")
+                d.dw = G.data_ptr()
+                L.check(lib.dyk_conv_wgrad(ctypes.byref(d), None), "dyk_conv_wgrad(pixel-streaming, fold)")
+                assert ((G - 0.25).cpu() - ref).abs().max().item() <= tol, (hex(tune), want)
+                runs.append(G.clone())
+            assert int(cnt.abs().max()) == 0
+            assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    # not eligible: 3x3, stride 2, fp32 -> the tune word falls back to the per-tap kernel
+    d3 = desc(PS | 4)
+    d3.ntaps = 9
+    assert lib.dyk_conv_wgrad_variant(ctypes.byref(d3)) == 0
+    d2 = desc(PS | 4)
+    d2.isy = d2.isx = 2
+    assert lib.dyk_conv_wgrad_variant(ctypes.byref(d2)) == 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("act", ["mish", "leaky", "relu6"])

@@ -16,14 +16,13 @@ sys.path.insert(0, GOLDEN)
 import cases  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-STEP23_RTOL = 0.50          # steps 2-3 of the three-Adam-step fixture (0.30 until round 5: the tuner's tile choice is a summation
-                            # order too -- over fresh tunings of one build the step-3 objectness loss landed 4-33 % off).  Deterministic for a given build, but every change of a
-                            # summation ORDER anywhere in the backward pass draws a new sample: 0.7 % / 1.8 % (box) and 10.8 % / 11.2 % (obj)
-                            # in round 2; 2.9 % / 0.8 % and 5.1 % / 17.7 % after the SE column sums went from 4 to 16 partial sums
-                            # (round 3) -- Adam's first steps move every weight by lr * sign(g), noise-level gradients included.  The
-                            # well-conditioned trajectory test is test_three_sgd_steps_on_the_conditioned_network_match_reference below (round 4:
-                            # 1e-5 ... 1e-3); this one catches gross
-                            # errors (wrong step size, sign, missing parameter)
+# Steps 2-3 of the three-Adam-step fixture on the chaotic random-weight net.  Every fp32 summation ORDER in the backward pass draws
+# a new sample of this deviation (Adam's first steps move every weight by lr * sign(g), noise-level gradients included): 0.7 % / 1.8 %
+# (box) and 10.8 % / 11.2 % (objectness) in round 2, 2.9 % / 0.8 % and 5.1 % / 17.7 % in round 3; over fresh autotunings of ONE build
+# 4-33 % (round 5) -- the tuner's tile choice is a summation order too.  Round 6: the bound is held with
+# the tile choice PINNED (fixture `tiles`: autotuner off, deterministic default tiles, so the order is part of the fixture) at the
+# pre-round-5 value; the autotuned variant of the same test is a SMOKE test with the spread as its bound.
+STEP23_RTOL = {"pinned": 0.30, "tuned": 0.50}
 
 
 # Bounds of test_three_sgd_steps_on_the_conditioned_network_match_reference, per learning rate: (losses of steps 2-3, norm of the
@@ -37,8 +36,11 @@ TRAJ4_TOL = {1e-6: (2e-5, 2e-3), 1e-5: (1e-4, 0.15), 1e-4: (2.5e-3, 0.25)}
 # within 6-49 % of their norm (the 2-element fusion weight is noise there and not bounded).  A smoke bound by construction --
 # the sharp bf16 statements are the per-section backward test (test_gpu_bwd_bf16.py) and the AP test on this same state.
 # (Later in round 5, with the BatchNorm-backward reduces of a [route]'s sources riding together on one data gradient: the bias of
-# `module_list.60.BatchNorm2d` (a plain sum of signed da over every pixel; not itself one of those sources) measures 72 % at lr 1e-4, the others 4-34 %: 1.0.)
-TRAJ4_TOL_BF16 = {1e-6: (0.2, 1.0), 1e-5: (0.2, 1.0), 1e-4: (0.2, 1.0)}
+# `module_list.60.BatchNorm2d` (a plain sum of signed da over every pixel; not itself one of those sources) measures 72 % at lr 1e-4 under
+# ONE autotuned tile set, the others 4-34 %.)  Round 6: with pinned tiles the bound is (0.2, 0.7) again; the autotuned variant is a
+# smoke test bounded at 0.95 -- a bound of 1.0 on an update norm asserts nothing and does not exist any more.
+TRAJ4_TOL_BF16 = {"pinned": {1e-6: (0.2, 0.7), 1e-5: (0.2, 0.7), 1e-4: (0.2, 0.7)},
+                  "tuned": {1e-6: (0.2, 0.95), 1e-5: (0.2, 0.95), 1e-4: (0.2, 0.95)}}
 
 
 def _inputs():
@@ -142,7 +144,8 @@ def test_gradients_against_fp64_oracle_with_fp32_yardstick(name):
     assert worse <= len(names) // 10, "%d of %d tensors are >6x less accurate than torch fp32" % (worse, len(names))
 
 
-def test_three_adam_steps_match_reference_losses():
+@pytest.mark.parametrize("tiles", ["pinned", "tuned"], indirect=True)
+def test_three_adam_steps_match_reference_losses(tiles):
     from build_utils.utils import compute_loss
     from dyk.optim import FusedAdam
     gold = np.load(os.path.join(GOLDEN, "step.npz"))
@@ -166,14 +169,15 @@ def test_three_adam_steps_match_reference_losses():
     # of atomics, see test_baseline_size_train_step_is_bit_reproducible).  The bound is the measured deviation with margin.
     print("three Adam steps: losses", losses.tolist(), "reference", gold["losses"].tolist(),
           "relative deviation", (np.abs(losses - gold["losses"]) / np.maximum(np.abs(gold["losses"]), 1e-9)).tolist())
-    assert np.allclose(losses[1:, :2], gold["losses"][1:, :2], rtol=STEP23_RTOL), (losses, gold["losses"])
+    assert np.allclose(losses[1:, :2], gold["losses"][1:, :2], rtol=STEP23_RTOL[tiles]), (tiles, losses, gold["losses"])
     sd = m.state_dict()
     probes = np.array([[sd[k].double().sum().item(), sd[k].double().abs().sum().item()] for k in cases.step_probe_names()])
     assert np.allclose(probes[:, 1], gold["probes"][:, 1], rtol=5e-3)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_three_sgd_steps_on_the_conditioned_network_match_reference(dtype):
+@pytest.mark.parametrize("dtype,tiles", [("fp32", "pinned"), ("fp32", "tuned"), ("bf16", "pinned"), ("bf16", "tuned")],
+                         indirect=["tiles"])
+def test_three_sgd_steps_on_the_conditioned_network_match_reference(dtype, tiles):
     """a trajectory bound that catches more than gross errors.  traj_trained.npz (make_golden_round4.py traj,
     the REFERENCE): three SGD + Nesterov steps on the whole target network starting from the round-4 fixture state --
     well-conditioned weights, calibrated BatchNorm statistics, trained heads, full batch of the 16 synthetic pairs
@@ -218,7 +222,7 @@ def test_three_sgd_steps_on_the_conditioned_network_match_reference(dtype):
         print("%s lr %g: losses %s reference %s relative deviation %s | update-norm deviation per probe %s"
               % (dtype, lr, losses.tolist(), ref.tolist(), rel.tolist(), ["%.1e" % d for d in drel]))
         worst[float(lr)] = (rel, drel)
-    tol = TRAJ4_TOL if dtype == "fp32" else TRAJ4_TOL_BF16
+    tol = TRAJ4_TOL if dtype == "fp32" else TRAJ4_TOL_BF16[tiles]      # (bf16 + tuned: SMOKE bound, see TRAJ4_TOL_BF16)
     for lr, (rel, drel) in worst.items():
         key = min(tol, key=lambda t: abs(t - lr))
         assert rel[0].max() <= (1e-4 if dtype == "fp32" else tol[key][0]), (lr, rel)     # the first step: forward + loss of the fixture state
@@ -227,7 +231,8 @@ def test_three_sgd_steps_on_the_conditioned_network_match_reference(dtype):
         assert drel[bounded].max() <= tol[key][1], (lr, drel)
 
 
-def test_three_sgd_steps_match_reference():
+@pytest.mark.parametrize("tiles", ["pinned", "tuned"], indirect=True)
+def test_three_sgd_steps_match_reference(tiles):
     """VERDICT r2 weak #2 asked for an optimizer trajectory with a tight bound.  Three steps of the reference's SGD branch
     (train.py:86-89: SGD + Nesterov momentum + weight decay) on seeded batches; fixture step_sgd.npz written by
     tests/golden/make_golden_round3.py running the REFERENCE.  What was measured on the way (HIP fp32 vs reference):
@@ -271,7 +276,8 @@ def test_three_sgd_steps_match_reference():
     # (later in round 5: the squeeze-excitation backward carrying the BatchNorm-backward reduce of three layers moves step 3 to 5.4 % / 1.1 %
     # on the same box, step 2 stays at 0.2 % / 0.8 %: step 2 is held to 1 % / 2 %, step 3 -- two updates into the chaos -- to 20 %)
     # (five fresh tunings of that build: step 3 at 1.3-5.4 % / 1.1-10.4 %: bound 20 %)
-    assert rel[0].max() <= 1e-4 and rel[1, 0] <= 1e-2 and rel[1, 1] <= 2e-2 and rel[2].max() <= 0.2, rel
+    # (round 6: pinned tiles -> step 3 back at 10 %; the autotuned variant keeps the 20 % SMOKE bound)
+    assert rel[0].max() <= 1e-4 and rel[1, 0] <= 1e-2 and rel[1, 1] <= 2e-2 and rel[2].max() <= (0.1 if tiles == "pinned" else 0.2), (tiles, rel)
     sd = m.state_dict()
     report = []
     for q, k in enumerate(names):
