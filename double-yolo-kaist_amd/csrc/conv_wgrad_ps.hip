@@ -316,8 +316,10 @@ PsPlan ps_plan(const DykWgradDesc* d) {
     }
     if (splits > ksteps) splits = ksteps;
     p.chunk = dyk_div_up(ksteps, splits) * KR;
-    // (plane / fold mode with a given count: exactly that many slices are written, trailing empty ones with zeros)
-    if (!((d->part || d->sk_cnt) && d->splits > 0)) splits = dyk_div_up(Ntot, p.chunk);
+    // (plane / fold mode with a given count: exactly that many slices are written, trailing empty ones with zeros -- also when
+    // the count exceeds the number of stages)
+    if ((d->part || d->sk_cnt) && d->splits > 0) splits = d->splits;
+    else splits = dyk_div_up(Ntot, p.chunk);
     p.splits = splits;
     return p;
 }

@@ -225,10 +225,24 @@ extern "C" int dyk_yolo_decode(const DykDecodeDesc* d, void* stream) {
 
 extern "C" int dyk_run_commands(const DykCommand* cmds, int32_t n, void* stream, int32_t* failed_index) {
     if (!cmds || n < 0) return DYK_ERR_ARG;
+    // analysis (timing only, results are garbage): DYK_SKIP_OPS=<op code>,<op code>,... leaves those commands out of every
+    // pass -- what the step would cost if a kernel family were free (tools/r6_ablate.sh)
+    static const unsigned long long skip_ops = [] {
+        unsigned long long m = 0;
+        if (const char* s = getenv("DYK_SKIP_OPS"))
+            for (const char* p = s; *p;) {
+                const long v = strtol(p, const_cast<char**>(&p), 10);
+                if (v > 0 && v < 64) m |= 1ull << v;
+                while (*p == ',' || *p == ' ') ++p;
+            }
+        return m;
+    }();
     for (int32_t k = 0; k < n; ++k) {
         const void* dp = cmds[k].desc;
         int rc = DYK_ERR_ARG;
-        if (dp) {
+        if (dp && cmds[k].op > 0 && cmds[k].op < 64 && ((skip_ops >> cmds[k].op) & 1)) {
+            rc = DYK_OK;
+        } else if (dp) {
             const DykEwDesc* e = (const DykEwDesc*)dp;
             const DykMiscDesc* m = (const DykMiscDesc*)dp;
             switch (cmds[k].op) {
