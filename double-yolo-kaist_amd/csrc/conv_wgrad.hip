@@ -366,11 +366,6 @@ int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream, int* query) {
     constexpr size_t park = KG > 1 ? (size_t)BM * BN * 4 : 0;
     constexpr size_t lds = ring > park ? ring : park;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static DykDeviceOnce attr_set;   // (the attribute is per DEVICE: one flag per device id)
-    auto kfn = conv_wgrad_kernel<T, BM, BN, PIPE, KG>;
-    if (attr_set.first()) {
-        DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
     const long Ntot = (long)d->B * d->Ho * d->Wo;
     const int tiles = dyk_div_up(d->Cout, BM) * dyk_div_up(d->Cin, BN) * d->ntaps;
     const int ksteps = dyk_div_up(Ntot, ROWS);
@@ -387,6 +382,11 @@ int launch_wgrad_impl(const DykWgradDesc* d, hipStream_t stream, int* query) {
     if (!(d->part && d->splits > 0)) splits = dyk_div_up(Ntot, chunk);  // (plane mode with a given count: exactly that many
                                                                          //  planes are written, trailing empty ones with zeros)
     if (query) { *query = splits; return DYK_OK; }
+    static DykDeviceOnce attr_set;   // (the attribute is per DEVICE: one flag per device id; after the query path: no device there)
+    auto kfn = conv_wgrad_kernel<T, BM, BN, PIPE, KG>;
+    if (attr_set.first()) {
+        DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     WgArgs args;
     const unsigned grid = wg_fill_args(args, d, tiles * splits);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256 * KG), lds, stream, args, splits, chunk);
@@ -615,11 +615,6 @@ int launch_wgrad_mt(const DykWgradDesc* d, hipStream_t stream, int* query) {
     constexpr int NI_B = ((HROWS + RPI_B - 1) / RPI_B + 3) / 4 * 4;
     constexpr size_t lds = 2 * ((size_t)(KW / 8) * 1024 + (size_t)NI_B * 1024);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static DykDeviceOnce attr_set;   // (the attribute is per DEVICE: one flag per device id)
-    auto kfn = conv_wgrad_mt_kernel<BN, SI, KW>;
-    if (attr_set.first()) {
-        DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
     const int tiles = dyk_div_up(d->Cout, 64) * dyk_div_up(d->Cin, BN);
     const int nseg = d->B * d->Ho * ((d->Wo + KW - 1) / KW);
     int splits = d->splits;
@@ -632,6 +627,11 @@ int launch_wgrad_mt(const DykWgradDesc* d, hipStream_t stream, int* query) {
     const int chunk = dyk_div_up(nseg, splits);
     if (!(d->part && d->splits > 0)) splits = dyk_div_up(nseg, chunk);
     if (query) { *query = splits; return DYK_OK; }
+    static DykDeviceOnce attr_set;   // (the attribute is per DEVICE: one flag per device id; after the query path: no device there)
+    auto kfn = conv_wgrad_mt_kernel<BN, SI, KW>;
+    if (attr_set.first()) {
+        DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     WgArgs args;
     const unsigned grid = wg_fill_args(args, d, tiles * splits);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, args, splits, chunk);
@@ -723,7 +723,8 @@ extern "C" int dyk_conv_wgrad(const DykWgradDesc* d, void* stream) {
     if (((d->tune >> 28) & 7) == 1 && mt_eligible(d)) return dispatch_wgrad_mt(d, s, nullptr);    // multi-tap 3x3 variant
     if (((d->tune >> 28) & 7) == 2 && dyk_wgrad_rb_eligible(d)) return dyk_wgrad_rb_dispatch(d, s, nullptr);   // row-block 3x3 variant
     if (((d->tune >> 28) & 7) == 3 && dyk_wgrad_ps_eligible(d)) return dyk_wgrad_ps_dispatch(d, s, nullptr, nullptr, nullptr);   // pixel-streaming 1x1 variant
-    if (d->sk_cnt && !d->part) return DYK_ERR_UNSUPPORTED;      // the in-launch fold exists in the pixel-streaming and row-block kernels only
+    if (d->sk_cnt && !d->part) return DYK_ERR_UNSUPPORTED;      // the in-launch fold exists in the pixel-streaming kernel only
+    if (d->group_n != 0) return DYK_ERR_UNSUPPORTED;            // grouped launches: pixel-streaming and row-block kernels only
     if (d->dtype == DYK_BF16) return dispatch_wgrad<bf16_t>(d, s, nullptr);
     if (d->dtype == DYK_F32) return dispatch_wgrad<float>(d, s, nullptr);
     return DYK_ERR_ARG;

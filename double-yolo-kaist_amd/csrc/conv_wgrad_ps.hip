@@ -66,6 +66,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_ps_kernel(const DykWgradDesc a
     const int tiles_n = (Cin_s + BN - 1) / BN;
     // consecutive remapped ids run on one XCD: the tiles of one pixel range share that XCD's L2
     int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // grouped launch: problem p owns blocks [p per, (p + 1) per); its tensors come out of the device table (scalar loads)
+    const void *x_p = a.x, *dy_p = a.dy;
+    float *dw_p = a.dw, *part_p = a.part;
+    if (a.group_n > 0) {
+        const int per = tiles_m * tiles_n * splits;
+        const int prob = __builtin_amdgcn_readfirstlane(bid / per);
+        bid -= prob * per;
+        const DykWgradGroupEntry* e = wg_sgpr_ptr(a.group) + prob;
+        x_p = e->x; dy_p = e->dy; dw_p = e->dw; part_p = e->part;
+    }
     const int tile = bid % (tiles_m * tiles_n);
     const int tm = bid % tiles_m; bid /= tiles_m;
     const int tn = bid % tiles_n;
@@ -75,8 +85,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_ps_kernel(const DykWgradDesc a
     const int p_begin = sp * chunk;
     const int p_end = min(Ntot, p_begin + chunk);
     const int S = p_end > p_begin ? (p_end - p_begin + KR - 1) / KR : 0;
-    const T* __restrict__ dyg = wg_sgpr_ptr((const T*)a.dy);
-    const T* __restrict__ xg = wg_sgpr_ptr((const T*)a.x);
+    const T* __restrict__ dyg = wg_sgpr_ptr((const T*)dy_p);
+    const T* __restrict__ xg = wg_sgpr_ptr((const T*)x_p);
 
     f32x4_t acc[MI][NI];
 #pragma unroll
@@ -228,10 +238,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_ps_kernel(const DykWgradDesc a
     const long toff = (long)a.twt[0] * Cout_s * lddw;
     const bool exclusive = (a.tune >> 20) & 1;
     bool rmw = exclusive && splits == 1;          // single writer, single split: read-add-write instead of atomics
-    float* dst = a.dw + toff;
+    float* dst = dw_p + toff;
     bool plain = false;
-    if (a.part) {
-        dst = a.part + (long)sp * a.part_stride + toff;
+    if (part_p) {
+        dst = part_p + (long)sp * a.part_stride + toff;
         plain = true;
     } else if (a.sk_cnt && splits > 1) {
         // in-launch fold of the S = splits slices of this tile (protocol of conv_igemm_kernel.h splitk_exchange): write-through
@@ -329,6 +339,7 @@ int launch_ps(const DykWgradDesc* d, hipStream_t stream, PsPlan* query) {
     using C = PsCfg<BM, BN, KR, NS>;
     const PsPlan p = ps_plan<BM, BN, KR>(d);
     if (query) { *query = p; return DYK_OK; }
+    if (d->group_n < 0 || d->group_n == 1 || (d->group_n > 0 && (!d->group || (d->sk_cnt && !d->part)))) return DYK_ERR_ARG;
     if (d->sk_cnt && !d->part && p.splits > 1) {
         if (p.tiles > d->sk_cnt_n || (int64_t)p.tiles * p.splits * BM * BN * 4 > d->sk_ws_bytes || ((uintptr_t)d->sk_ws % 16)) return DYK_ERR_ARG;
     }
@@ -337,7 +348,8 @@ int launch_ps(const DykWgradDesc* d, hipStream_t stream, PsPlan* query) {
     if (attr_set.first()) {
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
     }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)(p.tiles * p.splits)), dim3(512), C::LDS, stream, *d, p.splits, p.chunk);
+    const unsigned nprob = d->group_n > 0 ? (unsigned)d->group_n : 1u;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(p.tiles * p.splits) * nprob), dim3(512), C::LDS, stream, *d, p.splits, p.chunk);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

@@ -98,6 +98,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_rb_kernel(const DykWgradDesc a
     const int tiles_n = (a.Cin + RB_BN - 1) / RB_BN;
     // consecutive remapped ids share an XCD: the channel tiles of one pixel range read the same dy / x lines through one L2
     int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // grouped launch (DykWgradDesc.group): problem p owns blocks [p per, (p + 1) per); its tensors come out of the device table
+    const void *x_p = a.x, *dy_p = a.dy;
+    float *dw_p = a.dw, *part_p = a.part;
+    if (a.group_n > 0) {
+        const int per = tiles_m * tiles_n * splits;
+        const int prob = __builtin_amdgcn_readfirstlane(bid / per);
+        bid -= prob * per;
+        const DykWgradGroupEntry* e = rb_sgpr_ptr(a.group) + prob;
+        x_p = e->x; dy_p = e->dy; dw_p = e->dw; part_p = e->part;
+    }
     const int tm = bid % tiles_m; bid /= tiles_m;
     const int tn = bid % tiles_n;
     const int sp = bid / tiles_n;
@@ -105,8 +115,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_rb_kernel(const DykWgradDesc a
     const int g_begin = sp * chunk;
     const int g_end = min(g.nsteps, g_begin + chunk);
     const int S = g_end > g_begin ? g_end - g_begin : 0;
-    const T* __restrict__ dyg = rb_sgpr_ptr((const T*)a.dy);
-    const T* __restrict__ xg = rb_sgpr_ptr((const T*)a.x);
+    const T* __restrict__ dyg = rb_sgpr_ptr((const T*)dy_p);
+    const T* __restrict__ xg = rb_sgpr_ptr((const T*)x_p);
 
     const int Cout_s = __builtin_amdgcn_readfirstlane(a.Cout), Cin_s = __builtin_amdgcn_readfirstlane(a.Cin);
     const int lddy_s = __builtin_amdgcn_readfirstlane(a.lddy), ldx_s = __builtin_amdgcn_readfirstlane(a.ldx);
@@ -286,10 +296,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_rb_kernel(const DykWgradDesc a
                 for (int r = 0; r < 4; ++r) dst[(t * 64 + mi * 16 + r) * 32] = acc[t][mi][r];
     }
     __syncthreads();
-    if (S == 0 && !a.part) return;
+    if (S == 0 && !part_p) return;
     const int lddw = a.Cin;
-    const bool plane = a.part != nullptr;
-    float* out = plane ? a.part + (long)sp * a.part_stride : a.dw;
+    const bool plane = part_p != nullptr;
+    float* out = plane ? part_p + (long)sp * a.part_stride : dw_p;
     // one K split and a caller that vouches for it (tune bit 20: nobody else adds to dw while this launch runs): every
     // gradient element has exactly one writer, read-add-write replaces 4.7 M atomics on the 16x20 layers (53 -> 8 us)
     const bool rmw = !plane && splits == 1 && ((a.tune >> 20) & 1);
@@ -362,11 +372,6 @@ bool rb_geometry(const DykWgradDesc* d, int KP, RbGeom* out) {
 template <int KKW, int NXW>
 int rb_launch(const DykWgradDesc* d, const RbGeom& g, hipStream_t stream, int* query) {
     using C = RbCfg<KKW, NXW>;
-    static DykDeviceOnce attr_set;   // (the attribute is per DEVICE: one flag per device id)
-    auto kfn = conv_wgrad_rb_kernel<KKW, NXW>;
-    if (attr_set.first()) {
-        DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
-    }
     const int tiles = dyk_div_up(d->Cout, RB_BM) * dyk_div_up(d->Cin, RB_BN);
     int splits = d->splits;
     if (splits <= 0) {
@@ -379,9 +384,16 @@ int rb_launch(const DykWgradDesc* d, const RbGeom& g, hipStream_t stream, int* q
     const int chunk = dyk_div_up(g.nsteps, splits);
     if (!(d->part && d->splits > 0)) splits = dyk_div_up(g.nsteps, chunk);
     if (query) { *query = splits; return DYK_OK; }
+    if (d->group_n < 0 || d->group_n == 1 || (d->group_n > 0 && !d->group)) return DYK_ERR_ARG;
+    static DykDeviceOnce attr_set;   // (the attribute is per DEVICE: one flag per device id; after the query path: no device there)
+    auto kfn = conv_wgrad_rb_kernel<KKW, NXW>;
+    if (attr_set.first()) {
+        DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+    }
     DykWgradDesc a = *d;
     a.twin = nullptr;
-    hipLaunchKernelGGL(kfn, dim3(tiles * splits), dim3(512), C::LDS, stream, a, g, splits, chunk);
+    const unsigned nprob = d->group_n > 0 ? (unsigned)d->group_n : 1u;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles * splits) * nprob), dim3(512), C::LDS, stream, a, g, splits, chunk);
     DYK_LAUNCH_CHECK();
     return DYK_OK;
 }

@@ -68,7 +68,12 @@ class DykWgradDesc(ctypes.Structure):
         ("splits", _i32), ("lddw", _i32), ("tune", _i32),
         ("twin", _vp),
         ("sk_ws", _vp), ("sk_cnt", _vp), ("sk_ws_bytes", _i64), ("sk_cnt_n", _i32), ("_pad2", _i32),
+        ("group", _vp), ("group_n", _i32), ("_pad3", _i32),
     ]
+
+
+class DykWgradGroupEntry(ctypes.Structure):
+    _fields_ = [("x", _vp), ("dy", _vp), ("dw", _vp), ("part", _vp)]
 
 
 class DykEwDesc(ctypes.Structure):

@@ -107,6 +107,7 @@ class Plan:
         self._keep = []
         self._cfwd = self._cbwd = None
         self._cmd_us, self._rw_extra, self._part_extent = {}, {}, {}
+        self._wg_groups, self._wg_group_info = {}, []        # grouped weight-gradient launches: lead descriptor -> members
         self.has_bnfwd, self.bnfwd_counters = False, []      # one-launch conv + BatchNorm blocks (DYK_EPI_BNFWD): counter offsets in `ws`
 
     def bnfwd_error_words(self):
@@ -1419,6 +1420,10 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         _fuse_late_reduces(plan, store)
     if not dry and os.environ.get("DYK_AUTOTUNE", "1") != "0":
         autotune(plan, _TUNE_CACHE)
+    elif training:
+        _default_wgrad_tunes(plan)
+    if training and os.environ.get("DYK_WGRAD_PARTIALS", "1") != "0":
+        _group_wgrads(plan, store)
     plan.sk_ws = plan.sk_cnt = None
     plan.sk_bytes = 0
     if not dry:
@@ -1440,6 +1445,8 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     force.add(j - 1)
                     break
         _setup_wgrad_partials(plan, store, device, force)
+    if training:
+        _finish_wgrad_groups(plan, device)
 
     # ---------------------------------------------------------------- branch lanes (dual-stream nets)
     # sections [second, F) -- the second backbone up to the first section that reads anything of the first one -- are
@@ -1580,6 +1587,158 @@ def _setup_splitk(plan, device):
         d.sk_cnt, d.sk_cnt_n = plan.sk_cnt.data_ptr() + 4 * woff, nt
 
 
+def _default_wgrad_tunes(plan):
+    """without the autotuner (DYK_AUTOTUNE=0, dry plans): the kernels the tuner ends up with on the target cfg -- row-block for
+    3x3 / pad 1, pixel-streaming for 1x1 / stride 1 (bf16), the per-tap kernel for everything else -- with their default
+    configurations, so that untuned plans (the pinned-tile tests, the CPU-side scheduler tests) run the product's kernels"""
+    lib = L.load()
+    for op, d in plan.bwd:
+        if op != L.OP_WGRAD or d.tune:
+            continue
+        for v, t in ((2, 2 | (1 << 8) | (2 << 28) | WGRAD_EXCLUSIVE), (3, (3 << 28) | 4 | WGRAD_EXCLUSIVE)):
+            d.tune = t
+            if (v == 2 and os.environ.get("DYK_WGRAD_RB", "1") == "0") or (v == 3 and os.environ.get("DYK_WGRAD_PS", "1") == "0") \
+                    or lib.dyk_conv_wgrad_variant(ctypes.byref(d)) != v:
+                d.tune = 0
+                continue
+            break
+
+
+# members of a grouped weight-gradient launch lie within this many backward commands of each other: one stage of one backbone
+# (8 residual units ~ 60-100 commands).  Without a window twin layers of the two backbones -- different buffers, no conflict --
+# would share a launch: the first one's gradient would wait for the whole other backbone, and no data-parallel bucket could
+# close in between (tests/test_ddp_gloo.py counts the buckets)
+WGRAD_GROUP_WINDOW = 100
+
+
+def _group_wgrads(plan, store):
+    """Grouped weight-gradient launches (round 6, DykWgradDesc.group).  The repeated units of a stage have weight gradients of
+    ONE geometry that become ready one after the other and are nobody's input before the gradient fold / the optimizer; as
+    183 separate launches each pays its launch, prologue and epilogue and needs many K splits (= partial planes) to occupy the
+    chip.  Here the weight gradients of equal signature (row-block 3x3 / pixel-streaming 1x1 kernels) are collected into ONE
+    launch at the position of the LAST member, as far as the access sets allow: a member may move from position i to j only if
+    no command in (i, j] writes what it reads (x, dy: gradient buffers are recycled) or touches what it writes.  The members
+    then share the chip: K splits per member = what fills 256 workgroups over the whole group (planes 32 -> 4 on the 64x80
+    stage).  Rewrites plan.bwd / plan.bwd_marks; every member's result is what its own launch would give with that split
+    count."""
+    plan._wg_groups, plan._wg_group_info = {}, []
+    maxg = int(os.environ.get("DYK_WGRAD_GROUP", "8"))
+    if maxg < 2 or not plan.bwd:
+        return
+    from . import sched
+    lib = L.load()
+    cmds = plan.bwd
+    n = len(cmds)
+    cand = {}
+    for i, (op, d) in enumerate(cmds):
+        if op != L.OP_WGRAD or d.twin or d.part or d.sk_cnt or not (d.tune & WGRAD_EXCLUSIVE):
+            continue
+        v = lib.dyk_conv_wgrad_variant(ctypes.byref(d))
+        if v not in (2, 3):
+            continue
+        key = (v, d.dtype, d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout, d.isy, d.ntaps, d.tune, d.splits, d.ldx, d.lddy, d.lddw)
+        cand.setdefault(key, []).append(i)
+    cand = {k: v for k, v in cand.items() if len(v) >= 2}
+    if not cand:
+        return
+    mem = sched.Memory(plan, store)
+    acc = [sched.accesses(op, d, mem, plan) for op, d in cmds]
+
+    def conflict(i, k):
+        Ri, Wi, _ = acc[i]
+        Rk, Wk, bk = acc[k]
+        return bk or any(w.overlaps(r) for w in Wk for r in Ri) or any(a.overlaps(w) for w in Wi for a in Rk + Wk)
+
+    late = {}
+    for idxs in cand.values():
+        for i in idxs:
+            j = i
+            for k in range(i + 1, n):
+                if conflict(i, k):
+                    break
+                j = k
+            late[i] = j
+    layer_at = [-1] * n                       # cfg section whose backward a command belongs to (plan.bwd_marks)
+    marks = plan.bwd_marks
+    for k in range(len(marks)):
+        hi = marks[k + 1][0] if k + 1 < len(marks) else n
+        for q in range(marks[k][0], hi):
+            layer_at[q] = marks[k][1]
+    groups = []
+    for key, idxs in cand.items():
+        cur, lim = [idxs[0]], late[idxs[0]]
+        for i in idxs[1:] + [None]:
+            if i is not None and i <= lim and len(cur) < maxg and i - cur[0] <= WGRAD_GROUP_WINDOW:
+                cur.append(i)
+                lim = min(lim, late[i])
+                continue
+            if len(cur) >= 2:
+                groups.append(cur)
+            if i is not None:
+                cur, lim = [i], late[i]
+    if not groups:
+        return
+    removed = []
+    for g in groups:
+        members = [cmds[i][1] for i in g]
+        lead = members[-1]                    # its command stays where it is: every member's inputs exist by then
+        s1 = lib.dyk_conv_wgrad_splits(ctypes.byref(lead))
+        if s1 < 1:
+            continue
+        if lib.dyk_conv_wgrad_variant(ctypes.byref(lead)) == 2:          # workgroups of one problem per K split
+            tiles = -(-lead.Cout // 64) * -(-lead.Cin // 32)
+        else:
+            cap64 = ((lead.tune >> 8) & 0xf) == 1
+            bm, bn = (128 if lead.Cout > 64 and not cap64 else 64), (128 if lead.Cin > 64 and not cap64 else 64)
+            tiles = -(-lead.Cout // bm) * -(-lead.Cin // bn)
+        # as many workgroups as ONE member's tuned launch had, at least one per CU, spread over the whole group
+        sg = max(1, min(s1, -(-max(tiles * s1, 256) // (tiles * len(g)))))
+        for m in members:
+            m.splits = sg
+        plan._wg_groups[ctypes.addressof(lead)] = members
+        plan._wg_group_info.append(dict(lead=lead, lmax=max(layer_at[i] for i in g)))
+        t = [plan._cmd_us.get(ctypes.addressof(m)) for m in members]
+        if all(x is not None for x in t):
+            plan._cmd_us[ctypes.addressof(lead)] = 0.75 * sum(t)
+        removed += g[:-1]
+    removed.sort()
+    gone = set(removed)
+    import bisect
+    plan.bwd = [c for q, c in enumerate(cmds) if q not in gone]
+    plan.bwd_marks = [(cnt - bisect.bisect_left(removed, cnt), layer) for cnt, layer in plan.bwd_marks]
+    plan.wgrad_grouped = (len(groups), len(removed) + len(groups))
+
+
+def _finish_wgrad_groups(plan, device):
+    """device tables of the grouped weight-gradient launches (after the planes are handed out), and the data-parallel cut
+    positions they forbid: a bucket must not close at a position where a member of a LATER launch still owes the gradient of a
+    layer the bucket covers"""
+    groups = getattr(plan, "_wg_groups", None)
+    if not groups:
+        return
+    for lead_addr, members in groups.items():
+        arr = (L.DykWgradGroupEntry * len(members))()
+        for i, m in enumerate(members):
+            arr[i].x, arr[i].dy, arr[i].dw, arr[i].part = m.x, m.dy, m.dw, m.part
+        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        lead = members[-1]
+        assert ctypes.addressof(lead) == lead_addr
+        lead.group, lead.group_n = tab.data_ptr(), len(members)
+        plan._keep.append(tab)
+    pos = {ctypes.addressof(d): q for q, (op, d) in enumerate(plan.bwd) if op == L.OP_WGRAD}
+    marks = plan.bwd_marks
+    bad = set()
+    for info in plan._wg_group_info:
+        P, lmax = pos[ctypes.addressof(info["lead"])], info["lmax"]
+        for k in range(1, len(marks)):
+            c_end, layer_done = marks[k][0], marks[k - 1][1]
+            if c_end <= P and layer_done <= lmax:
+                bad.add(c_end)
+    if plan.bwd_cut_ok is None:
+        plan.bwd_cut_ok = {c for c, _ in marks}
+    plan.bwd_cut_ok = set(plan.bwd_cut_ok) - bad
+
+
 def _setup_wgrad_partials(plan, store, device, force_layers=()):
     """Atomic-free weight gradients: every K split of a weight-gradient launch gets its own plane of a partial buffer
     (dyk_conv_wgrad_splits planes per layer), and a table-driven dyk_grad_reduce folds the planes into the flat gradient
@@ -1594,33 +1753,34 @@ def _setup_wgrad_partials(plan, store, device, force_layers=()):
             plane = d.k * d.k * d.C
             if splits < 2 or plane % 4:
                 continue
-            items[q] = dict(d=d, splits=splits, plane=plane, part_off=total, g_off=(d.dw - G0) // 4, dw=True)
+            items[q] = [dict(d=d, splits=splits, plane=plane, part_off=total, g_off=(d.dw - G0) // 4, dw=True)]
             total += splits * plane
             continue
         if op != L.OP_WGRAD:
             continue
-        splits = lib.dyk_conv_wgrad_splits(ctypes.byref(d))
-        if splits < 2:
-            continue
-        plane = d.ntaps * d.Cout * (d.lddw if d.lddw > 0 else d.Cin)       # stems: [Cout][k*k*3] rows of lddw floats
-        if plane % 4:
-            continue
-        items[q] = dict(d=d, splits=splits, plane=plane, part_off=total, g_off=(d.dw - G0) // 4)
-        total += splits * plane
+        for m in plan._wg_groups.get(ctypes.addressof(d), [d]):          # (a grouped launch: every member has its own planes)
+            splits = lib.dyk_conv_wgrad_splits(ctypes.byref(m))
+            if splits < 2:
+                continue
+            plane = m.ntaps * m.Cout * (m.lddw if m.lddw > 0 else m.Cin)   # stems: [Cout][k*k*3] rows of lddw floats
+            if plane % 4:
+                continue
+            items.setdefault(q, []).append(dict(d=m, splits=splits, plane=plane, part_off=total, g_off=(m.dw - G0) // 4))
+            total += splits * plane
     if not items:
         return
     plan.part = torch.empty(total, dtype=torch.float32, device=device)
     plan.part_bytes = total * 4
     base = plan.part.data_ptr()
     plan._rw_extra, plan._part_extent = {}, {}
-    for it in items.values():
+    for it in (it_ for lst in items.values() for it_ in lst):
         d = it["d"]
         if it.get("dw"):
             d.part = base + 4 * it["part_off"]
             plan._part_extent[ctypes.addressof(d)] = 4 * it["splits"] * it["plane"]
         else:
             d.part, d.part_stride, d.splits = base + 4 * it["part_off"], it["plane"], it["splits"]
-    target = sum(it["plane"] for it in items.values()) // 16
+    target = sum(it["plane"] for lst in items.values() for it in lst) // 16
 
     def reduce_cmd(entries):
         arr = (L.DykGradReduceEntry * len(entries))()
@@ -1656,8 +1816,8 @@ def _setup_wgrad_partials(plan, store, device, force_layers=()):
         if idx < len(plan.bwd):
             new.append(plan.bwd[idx])
             if idx in items:
-                pend.append(items[idx])
-                acc += items[idx]["plane"]
+                pend.extend(items[idx])
+                acc += sum(it["plane"] for it in items[idx])
     assert not pend
     plan.bwd, plan.bwd_marks, plan.bwd_cut_ok = new, marks, cut_ok
 

@@ -160,13 +160,15 @@ def accesses(op, d, mem, plan):
                 wr(V(p))
     elif op == L.OP_WGRAD:
         es = _es(d.dtype)
-        rd(T(d.x, d.ldx, d.Cin, es))
-        rd(T(d.dy, d.lddy, d.Cout, es))
-        plane = d.ntaps * d.Cout * (d.lddw if d.lddw > 0 else d.Cin) * 4
-        if d.part:
-            wr(mem.interval(_v(d.part), max(d.splits, 1) * d.part_stride * 4))
-        else:
-            wr(mem.interval(_v(d.dw), plane))
+        # (a grouped launch -- DykWgradDesc.group, dyk/plan.py _group_wgrads -- reads and writes what its members do)
+        for m in getattr(plan, "_wg_groups", {}).get(ctypes.addressof(d), [d]):
+            rd(T(m.x, m.ldx, m.Cin, es))
+            rd(T(m.dy, m.lddy, m.Cout, es))
+            plane = m.ntaps * m.Cout * (m.lddw if m.lddw > 0 else m.Cin) * 4
+            if m.part:
+                wr(mem.interval(_v(m.part), max(m.splits, 1) * m.part_stride * 4))
+            else:
+                wr(mem.interval(_v(m.dw), plane))
     elif op in (L.OP_DW_FWD, L.OP_DW_DGRAD, L.OP_DW_WGRAD):
         es = _es(d.dtype)
         if d.pre and op != L.OP_DW_DGRAD:     # normalise + activation on load: scale | shift of the producer's BatchNorm

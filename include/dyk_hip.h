@@ -202,6 +202,14 @@ int64_t dyk_conv_splitk_ws_bytes(const DykConvDesc* desc, int32_t* tiles);
  * gradient is wanted.  Replaces autograd's convolution_backward(weight) for models.py:34-42.
  * Rows of x / dy must be readable up to round_up(C, 16 bytes) (ld >= that).
  * ---------------------------------------------------------------------------------- */
+/* one problem of a GROUPED weight-gradient launch (DykWgradDesc.group): identical geometry, own tensors */
+typedef struct DykWgradGroupEntry {
+    const void* x;
+    const void* dy;
+    float* dw;
+    float* part;
+} DykWgradGroupEntry;
+
 typedef struct DykWgradDesc {
     const void* x;
     const void* dy;
@@ -246,6 +254,15 @@ typedef struct DykWgradDesc {
     int64_t sk_ws_bytes;
     int32_t sk_cnt_n;
     int32_t _pad2;
+    /* Grouped launch (round 6; kernels: pixel-streaming 1x1, row-block 3x3): group_n >= 2 problems of THIS geometry / tune /
+     * splits / part_stride in one launch -- the weight gradients of the repeated residual units of a stage, which become
+     * ready one after the other and are nobody's input before the optimizer.  `group` is a DEVICE array of group_n entries
+     * (x, dy, dw, part per problem; this descriptor's own x / dy / dw / part are ignored); the workgroups of problem p are
+     * blocks [p * tiles * splits, (p + 1) * tiles * splits).  Every problem's result is what its own launch would give, bit for
+     * bit.  Not combinable with twin or the in-launch fold. */
+    const DykWgradGroupEntry* group;
+    int32_t group_n;
+    int32_t _pad3;
 } DykWgradDesc;
 
 int dyk_conv_wgrad(const DykWgradDesc* desc, void* stream);

@@ -831,6 +831,86 @@ def test_wgrad_pixel_streaming_kernel(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,case", [(1, (2, 128, 128, 16, 20)), (1, (2, 64, 64, 32, 40)), (1, (1, 256, 72, 9, 13)),
+                                    (3, (2, 64, 128, 16, 40)), (3, (4, 64, 64, 16, 20)), (3, (2, 24, 40, 16, 16))])
+def test_grouped_weight_gradient_launch(k, case):
+    """DykWgradDesc.group (round 6): G problems of one geometry in ONE launch of the pixel-streaming (1x1) / row-block (3x3)
+    kernel -- the repeated units of a stage.  Every member's planes (and, with one split, its read-add-written gradient) equal
+    those of its own launch with the same split count BIT FOR BIT; the other kernels refuse a group."""
+    import ctypes
+    from dyk import lib as L
+    from dyk import ops
+    B, Cin, Cout, H, W = case
+    dtype = torch.bfloat16
+    G = 3
+    g = torch.Generator().manual_seed(43)
+    xs = [ops.to_nhwc(torch.randn(B, Cin, H, W, generator=g).cuda(), dtype) for _ in range(G)]
+    dys = [ops.to_nhwc(torch.randn(B, Cout, H, W, generator=g).cuda(), dtype) for _ in range(G)]
+    lib = L.load()
+    tune = ((3 << 28) | 4 | (1 << 20)) if k == 1 else (2 | (1 << 8) | (2 << 28) | (1 << 20))
+    plane = k * k * Cout * Cin
+
+    def desc(i, splits):
+        d = L.DykWgradDesc()
+        d.x, d.dy = xs[i].data_ptr(), dys[i].data_ptr()
+        d.dtype = ops.dtype_code(dtype)
+        d.ldx, d.lddy = ops.nhwc_ld(xs[i]), ops.nhwc_ld(dys[i])
+        d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, Cin, H, W, Cout
+        d.isy = d.isx = 1
+        taps = ops.fwd_taps(k, k // 2)
+        d.ntaps = len(taps)
+        for q, (ty, tx, wt) in enumerate(taps):
+            d.tdy[q], d.tdx[q], d.twt[q] = ty, tx, wt
+        d.tune, d.splits = tune, splits
+        return d
+
+    assert lib.dyk_conv_wgrad_variant(ctypes.byref(desc(0, 0))) == (3 if k == 1 else 2)
+    for S in (1, 3):
+        # every member alone
+        alone, alone_g = [], []
+        for i in range(G):
+            d = desc(i, S)
+            Gd = torch.full((plane,), 0.5, device="cuda")
+            d.dw = Gd.data_ptr()
+            if S > 1:
+                part = torch.full((S * plane,), float("nan"), device="cuda")
+                d.part, d.part_stride = part.data_ptr(), plane
+                alone.append(part)
+            L.check(lib.dyk_conv_wgrad(ctypes.byref(d), None), "single launch")
+            alone_g.append(Gd)
+        # the group
+        members = [desc(i, S) for i in range(G)]
+        grads = [torch.full((plane,), 0.5, device="cuda") for _ in range(G)]
+        parts = [torch.full((S * plane,), float("nan"), device="cuda") for _ in range(G)] if S > 1 else None
+        arr = (L.DykWgradGroupEntry * G)()
+        for i, m in enumerate(members):
+            m.dw = grads[i].data_ptr()
+            if S > 1:
+                m.part, m.part_stride = parts[i].data_ptr(), plane
+            arr[i].x, arr[i].dy, arr[i].dw, arr[i].part = m.x, m.dy, m.dw, m.part
+        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+        lead = members[-1]
+        lead.group, lead.group_n = tab.data_ptr(), G
+        L.check(lib.dyk_conv_wgrad(ctypes.byref(lead), None), "grouped launch")
+        for i in range(G):
+            if S > 1:
+                assert torch.equal(parts[i], alone[i]), (S, i)
+                assert float((grads[i] - 0.5).abs().max()) == 0.0
+            else:
+                assert torch.equal(grads[i], alone_g[i]), (S, i)
+                ref = torch.nn.grad.conv2d_weight(ops.to_nchw(xs[i]).cpu(), (Cout, Cin, k, k),
+                                                  ops.to_nchw(dys[i]).cpu(), padding=k // 2)
+                ref = ref.permute(2, 3, 0, 1).reshape(-1)
+                assert ((grads[i] - 0.5).cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+    # the per-tap kernel does not take groups
+    bad = desc(0, 1)
+    bad.tune = 2
+    bad.dw = grads[0].data_ptr()
+    bad.group, bad.group_n = tab.data_ptr(), G
+    assert lib.dyk_conv_wgrad(ctypes.byref(bad), None) != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("act", ["mish", "leaky", "relu6"])
 def test_small_channel_dgrad_kernel(stride, act):

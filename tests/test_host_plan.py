@@ -1,6 +1,7 @@
 """Host logic (no GPU): model construction mirrors the reference's graph, the parameter store
 round-trips state_dicts through its flat tap-major storage, and the plan compiler (dry mode)
 produces consistent command lists / buffer assignments for every BASELINE cfg it supports."""
+import ctypes
 import json
 import os
 
@@ -104,7 +105,10 @@ def test_plan_compiles_consistently(name, training, one_launch, monkeypatch):
         assert ops[0] == L.OP_MEMSET
         bops = [op for op, _ in plan.bwd]
         assert bops[0] == L.OP_MEMSET
-        assert bops.count(L.OP_WGRAD) == n_conv - n_stem and bops.count(L.OP_STEM_WGRAD) == n_stem
+        # (round 6: weight gradients of one geometry may share a grouped launch, DykWgradDesc.group -- every layer is in exactly one)
+        assert sum(max(d.group_n, 1) for op, d in plan.bwd if op == L.OP_WGRAD) == n_conv - n_stem and bops.count(L.OP_STEM_WGRAD) == n_stem
+        members = [ctypes.addressof(m) for lst in plan._wg_groups.values() for m in lst]
+        assert len(members) == len(set(members)) and all(len(lst) >= 2 for lst in plan._wg_groups.values())
         # every BatchNorm layer's reduce is its own pass or rides on the launch that produces its gradient: a data gradient's
         # epilogue (one layer, or all the sections a [route] concatenates: their apply passes read columns of its replicas) or
         # the squeeze-excitation backward
@@ -252,7 +256,8 @@ def test_mobilenet_plans_use_depthwise_and_padded_channel_rows(name):
     assert n_stem == 2                                        # both 3x3 stride-2 stems run in the direct kernel
     assert ops.count(L.OP_CONV) == n_dense + n_sep - n_stem
     assert bops.count(L.OP_DW_WGRAD) == bops.count(L.OP_DW_DGRAD) == n_dw + n_sep
-    assert bops.count(L.OP_WGRAD) == n_dense + n_sep - n_stem and bops.count(L.OP_STEM_WGRAD) == n_stem
+    assert sum(max(d.group_n, 1) for op, d in plan.bwd if op == L.OP_WGRAD) == n_dense + n_sep - n_stem     # (grouped launches: round 6)
+    assert bops.count(L.OP_STEM_WGRAD) == n_stem
     for op, d in plan.fwd + plan.bwd:
         if op == L.OP_CONV:
             assert d.Cin % 32 == 0 and d.ldx > d.Cin - 32 and d.ldx % 8 == 0 and d.ldy % 8 == 0
@@ -341,8 +346,9 @@ def test_frozen_layers_shrink_the_backward_list():
     assert st.frozen_key()
     part = compile_plan(m, st, 2, 64, 96, torch.bfloat16, True, torch.device("cpu"), dry=True)
     n_conv_trainable = sum(1 for i, d in enumerate(m.module_defs) if d["type"] == "convolutional" and i > cut)
-    assert [op for op, _ in part.bwd].count(L.OP_WGRAD) == n_conv_trainable
-    assert len(part.bwd) < len(full.bwd) // 2
+    assert sum(max(d.group_n, 1) for op, d in part.bwd if op == L.OP_WGRAD) == n_conv_trainable
+    n_members = lambda plan: len(plan.bwd) + sum(max(d.group_n, 1) - 1 for op, d in plan.bwd if op == L.OP_WGRAD)
+    assert n_members(part) < n_members(full) // 2
     assert len(part.fwd) == len(full.fwd)               # train-mode BatchNorm of frozen layers still runs (model.train())
     # the first trainable conv has a weight gradient but no data gradient: nothing upstream needs it
     first = min(e.layer for e in st.entries if e.param.requires_grad)

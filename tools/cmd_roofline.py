@@ -29,7 +29,8 @@ def cmd_model(L, op, d, plan=None):
         es = _es(d.dtype)
         by = d.B * d.Hi * d.Wi * d.Cin * es + d.B * d.Ho * d.Wo * d.Cout * es
         fl = 2.0 * d.B * d.Ho * d.Wo * d.Cin * d.Cout * d.ntaps
-        return "%s %dx%d c%d>%d t%d sp%d" % (n, d.Ho, d.Wo, d.Cin, d.Cout, d.ntaps, d.splits), by, fl
+        g = max(d.group_n, 1)              # grouped launch (DykWgradDesc.group): g problems of this geometry
+        return "%s %dx%d c%d>%d t%d sp%d%s" % (n, d.Ho, d.Wo, d.Cin, d.Cout, d.ntaps, d.splits, " g%d" % g if g > 1 else ""), by * g, fl * g
     if op in (L.OP_DW_FWD, L.OP_DW_DGRAD, L.OP_DW_WGRAD):
         es = _es(d.dtype)
         by = (d.B * d.Hi * d.Wi + d.B * d.Ho * d.Wo) * d.C * es
