@@ -1604,11 +1604,12 @@ def _default_wgrad_tunes(plan):
             break
 
 
-# members of a grouped weight-gradient launch lie within this many backward commands of each other: one stage of one backbone
-# (8 residual units ~ 60-100 commands).  Without a window twin layers of the two backbones -- different buffers, no conflict --
-# would share a launch: the first one's gradient would wait for the whole other backbone, and no data-parallel bucket could
-# close in between (tests/test_ddp_gloo.py counts the buckets)
-WGRAD_GROUP_WINDOW = 100
+# members of a grouped weight-gradient launch lie within this many backward commands of each other: a stage or two of one
+# backbone (8 residual units ~ 60-100 commands).  Without a window twin layers of the two backbones -- different buffers, no
+# conflict -- would share a launch: the first one's gradient would wait for the whole other backbone, and no data-parallel
+# bucket could close in between (tests/test_ddp_gloo.py counts the buckets).  Measured in-call (r6_ab_wgrad_group_knobs.log):
+# 50 / 100 / 200 commands 26.96 / 26.91 / 26.67 ms; 8 / 16 / 32 members per launch and 128 / 256 / 512 workgroups within +-0.1
+WGRAD_GROUP_WINDOW = 200
 
 
 def _group_wgrads(plan, store):
@@ -1622,7 +1623,7 @@ def _group_wgrads(plan, store):
     stage).  Rewrites plan.bwd / plan.bwd_marks; every member's result is what its own launch would give with that split
     count."""
     plan._wg_groups, plan._wg_group_info = {}, []
-    maxg = int(os.environ.get("DYK_WGRAD_GROUP", "8"))
+    maxg = int(os.environ.get("DYK_WGRAD_GROUP", "16"))
     if maxg < 2 or not plan.bwd:
         return
     from . import sched
@@ -1668,7 +1669,7 @@ def _group_wgrads(plan, store):
     for key, idxs in cand.items():
         cur, lim = [idxs[0]], late[idxs[0]]
         for i in idxs[1:] + [None]:
-            if i is not None and i <= lim and len(cur) < maxg and i - cur[0] <= WGRAD_GROUP_WINDOW:
+            if i is not None and i <= lim and len(cur) < maxg and i - cur[0] <= int(os.environ.get("DYK_WGRAD_GROUP_WINDOW", WGRAD_GROUP_WINDOW)):
                 cur.append(i)
                 lim = min(lim, late[i])
                 continue
@@ -1692,7 +1693,8 @@ def _group_wgrads(plan, store):
             bm, bn = (128 if lead.Cout > 64 and not cap64 else 64), (128 if lead.Cin > 64 and not cap64 else 64)
             tiles = -(-lead.Cout // bm) * -(-lead.Cin // bn)
         # as many workgroups as ONE member's tuned launch had, at least one per CU, spread over the whole group
-        sg = max(1, min(s1, -(-max(tiles * s1, 256) // (tiles * len(g)))))
+        wgs = int(os.environ.get("DYK_WGRAD_GROUP_WGS", "256"))
+        sg = max(1, min(s1, -(-max(tiles * s1, wgs) // (tiles * len(g)))))
         for m in members:
             m.splits = sg
         plan._wg_groups[ctypes.addressof(lead)] = members
