@@ -404,8 +404,7 @@ inline int ew_grid2d(int CV, long npix, int* gx, int* gy) {
     while (CVB < CV && CVB < 32) CVB <<= 1;
     const int PY = 256 / CVB;
     *gx = (CV + CVB - 1) / CVB;
-    static int ppt = 0, capb = 0;                               // DYK_EW_PPT / DYK_EW_CAP: sweep knobs (tools/gpu_probe.py bnbench)
-    if (!ppt) { const char* e = getenv("DYK_EW_PPT"); ppt = e ? atoi(e) : 8; const char* c = getenv("DYK_EW_CAP"); capb = c ? atoi(c) : 2048; }
+    constexpr int ppt = 8, capb = 2048;                         // (4 / 16 pixels per thread, grid caps 1 024 / 4 096: +-0.2 ms, round 2)
     long g = (npix + (long)PY * ppt - 1) / ((long)PY * ppt);    // >= 8 pixels per thread (2 unrolled iterations)
     const long cap = capb / *gx > 0 ? capb / *gx : 1;
     if (g > cap) g = cap;

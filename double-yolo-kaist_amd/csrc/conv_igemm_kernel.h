@@ -1600,9 +1600,6 @@ int launch_conv_impl(const DykConvDesc* d, hipStream_t stream) {
     // the staged epilogue needs 16-byte aligned pixel rows of the output (and residual)
     const int eso = of32 ? 4 : 2;
     bool vec = conv_vec_ok(d, eso, sizeof(T)) && (!d->twin || conv_vec_ok(d->twin, eso, sizeof(T)));
-    static int force_scatter = -1;
-    if (force_scatter < 0) { const char* e = getenv("DYK_CONV_EPI"); force_scatter = (e && e[0] == 's') ? 1 : 0; }
-    if (force_scatter) vec = false;
     const int sk = conv_splitk_of(d);
     if (sk > 1) {
         if constexpr (EPIK == 3) return DYK_ERR_UNSUPPORTED;

@@ -389,8 +389,7 @@ int launch_conv_pw(const DykConvDesc* d, hipStream_t stream) {
         DYK_HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     // persistent: as many workgroups per CU as the LDS holds (at most two), a multiple of the channel tiles
-    static int cap = 0;
-    if (!cap) { const char* e = getenv("DYK_PW_WGS"); cap = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 2; }
+    constexpr int cap = 2;                                     // (1 / 2 / 3 / 4 per CU: 18.85 / 18.31 / 18.31 / 18.21 ms on C5, round 5)
     int per_cu = (160 * 1024) / (int)lds;
     if (per_cu > cap) per_cu = cap;
     if (per_cu < 1) per_cu = 1;

@@ -602,7 +602,7 @@ bool mt_eligible(const DykWgradDesc* d) {
     if (d->dtype != DYK_BF16 || d->ntaps != 9 || d->isy != d->isx || (d->isy != 1 && d->isy != 2)) return false;
     // (Wo need not be a multiple of the 32-pixel segment: ragged last segments are zero filled -- 80-, 40- and 20-pixel rows
     // of the deep stages waste 17 / 37 / 37 % of the MFMA work of a row but stage dy and x once for all nine taps)
-    static const bool ragged = !(getenv("DYK_MT_RAGGED") && getenv("DYK_MT_RAGGED")[0] == '0');     // (A/B switch)
+    constexpr bool ragged = true;
     if (d->Wo < 16 || (!ragged && d->Wo % 32) || d->Cin % 8 || d->Cout % 8 || (d->lddw > 0 && d->lddw != d->Cin)) return false;
     for (int t = 0; t < 9; ++t)
         if (d->tdy[t] != t / 3 - 1 || d->tdx[t] != t % 3 - 1) return false;

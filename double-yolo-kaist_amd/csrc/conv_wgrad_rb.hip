@@ -375,7 +375,7 @@ int rb_launch(const DykWgradDesc* d, const RbGeom& g, hipStream_t stream, int* q
     const int tiles = dyk_div_up(d->Cout, RB_BM) * dyk_div_up(d->Cin, RB_BN);
     int splits = d->splits;
     if (splits <= 0) {
-        static const int target = getenv("DYK_RB_WGS") ? atoi(getenv("DYK_RB_WGS")) : 256;     // (A/B switch)
+        constexpr int target = 256;                            // (128 ... 384 workgroups: +-0.1 ms in the step, round 4)
         splits = dyk_div_up(target, tiles);                    // one workgroup (8 waves, its LDS) per CU
         const int max_splits = g.nsteps / 4 > 0 ? g.nsteps / 4 : 1;
         if (splits > max_splits) splits = max_splits;

@@ -490,11 +490,7 @@ int launch_dw_tile(const DykDwDesc* d, hipStream_t stream) {
                        m_ct, tiles_x, tiles_y);
     return DYK_OK;
 }
-inline bool dw_tile_on() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("DYK_DW_TILE"); on = (e && e[0] == '0') ? 0 : 1; }
-    return on != 0;
-}
+inline bool dw_tile_on() { return true; }
 
 // Stride-2 fast path (MobileNet down-sampling layers): K and the stride are compile-time, so the taps of a pixel are a
 // fixed, unrolled set whose loads are issued together -- clamped coordinates, values zeroed afterwards (the generic kernel
@@ -969,9 +965,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 struct DwWgTile { int CT, groups, tiles_x, tiles_y, P; unsigned m_ct; size_t lds; };
 inline int dw_wgrad_tile_target() {
-    static int n = -1;
-    if (n < 0) { const char* e = getenv("DYK_DW_WGRAD_TILE"); n = e ? atoi(e) : 512; }     // workgroups per launch (two resident per CU); 0 = the row kernel
-    return n;
+    return 512;                                                // workgroups per launch (two resident per CU)
 }
 // geometry of the tiled weight gradient for this problem; false = not eligible (the row kernel runs)
 inline bool dw_wgrad_tile_cfg(const DykDwDesc* d, DwWgTile* c) {

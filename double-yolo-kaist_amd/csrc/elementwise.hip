@@ -1001,9 +1001,7 @@ extern "C" int dyk_upsample2x_bwd(const DykEwDesc* d, void* stream) {
 
 // the LDS-plane kernels: stride 1, odd window (output map = input map), map of at most 1024 pixels, 4-byte aligned argmax rows
 static bool maxpool_tile_ok(const DykEwDesc* d) {
-    static int off = -1;
-    if (off < 0) { const char* e = getenv("DYK_MAXPOOL_TILE"); off = (e && e[0] == '0') ? 1 : 0; }
-    return !off && d->slots <= 1 && (d->k & 1) && d->H * d->W <= 1024 && d->C % 4 == 0;
+    return d->slots <= 1 && (d->k & 1) && d->H * d->W <= 1024 && d->C % 4 == 0;
 }
 static int maxpool_tile_threads(int HW) { const int t = (HW + 63) / 64 * 64; return t > 1024 ? 1024 : t; }
 

@@ -374,11 +374,10 @@ extern "C" int dyk_run_commands_overlap(const DykCommand* cmds, int32_t n, void*
     static hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr;
     if (!branch) {
         // the weight gradients are filler work: lowest priority, so that their workgroups do not delay the kernels of
-        // the critical chain (DYK_SIDE_PRIORITY=0 disables the distinction)
+        // the critical chain
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);             // lo = least, hi = greatest priority (numerically smaller)
-        const char* pe = getenv("DYK_SIDE_PRIORITY");
-        const bool prio = !(pe && pe[0] == '0');
+        const bool prio = true;
         if (hipStreamCreateWithPriority(&branch, hipStreamNonBlocking, prio ? hi : 0) != hipSuccess) return DYK_ERR_HIP;
         if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio ? lo : 0) != hipSuccess) return DYK_ERR_HIP;
         for (auto& e : ring)
@@ -473,9 +472,8 @@ int sched_prepare(SchedRuntime& rt, int32_t n, int32_t n_streams, int32_t low_pr
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
             int prio = (lp && s == n_streams - 1) ? lo : 0;
-            // DYK_SCHED_PRIO=1: the second chain (stream 1) at the highest priority, the filler streams (2..) at the lowest
-            static const bool tiered = getenv("DYK_SCHED_PRIO") && getenv("DYK_SCHED_PRIO")[0] == '1';
-            if (tiered) prio = (s == 1) ? hi : lo;
+            // (tiered priorities -- second chain highest, filler streams lowest -- cost 11 ms per step: ANY stream created with a
+            // non-default priority gets a hardware queue of its own, r04_ab_sched_stream_priorities.log; removed in round 6)
             if (hipStreamCreateWithPriority(&rt.aux[lp][s], hipStreamNonBlocking, prio) != hipSuccess) return DYK_ERR_HIP;
         }
     return DYK_OK;
@@ -716,7 +714,7 @@ extern "C" int dyk_dag_graph_create(const DykCommand* cmds, int32_t n, const int
                                     void** graph_out, int32_t* failed_index) {
     if (!cmds || n <= 0 || !dep_off || !graph_out) return DYK_ERR_ARG;
     static hipStream_t origin = nullptr;
-    static const bool dbg = getenv("DYK_GRAPH_DEBUG") != nullptr;
+    constexpr bool dbg = false;
     if (!origin && hipStreamCreateWithFlags(&origin, hipStreamNonBlocking) != hipSuccess) return DYK_ERR_HIP;
     SchedGraph* g = new SchedGraph();
     if (hipGraphCreate(&g->graph, 0) != hipSuccess) { delete g; return DYK_ERR_HIP; }

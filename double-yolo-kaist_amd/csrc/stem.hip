@@ -670,8 +670,7 @@ extern "C" int dyk_stem_conv_fwd(const DykStemDesc* d, void* stream) {
     if (!d->wt || !d->y || d->ldy < d->Cout || (d->ldy * (d->dtype == DYK_BF16 ? 2 : 4)) % 16 || ((uintptr_t)d->y % 16)) return DYK_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long npix = (long)d->B * d->Ho * d->Wo;
-    static int fast = -1;
-    if (fast < 0) { const char* e = getenv("DYK_STEM_FWD_U8"); fast = (e && e[0] == '0') ? 0 : 1; }
+    constexpr bool fast = true;
     // (16 filters / stride 2 -- the MobileNet stem -- measured faster in the scalar kernel: half of the 32-wide tile idles)
     if (fast && d->in_u8 && d->dtype == DYK_BF16 && d->Cout == 32 && d->W % 4 == 0 && ((uintptr_t)d->img % 4) == 0 && (d->stride == 1 || d->stride == 2)) {
         const int segs_per_row = (d->Wo + STEM_SEG - 1) / STEM_SEG;
@@ -713,8 +712,7 @@ extern "C" int dyk_stem_wgrad_planes(const DykStemDesc* d) {
 
 // the conditions of the uint8 / bf16 MFMA kernel (the only one that carries the fused BatchNorm-backward apply)
 static bool stem_wgrad_u8_ok(const DykStemDesc* d, const void* grad) {
-    static int fast = -1;
-    if (fast < 0) { const char* e = getenv("DYK_STEM_WGRAD_U8"); fast = (e && e[0] == '0') ? 0 : 1; }
+    constexpr bool fast = true;
     return fast && d->in_u8 && d->dtype == DYK_BF16 && d->lddy == d->Cout && d->W % 4 == 0 && ((uintptr_t)d->img % 4) == 0 &&
            ((uintptr_t)grad % 16) == 0 && STEM_SEG * d->stride + 2 + 6 <= 4 * 128 && (d->Cout == 32 || d->Cout == 16);
 }

@@ -194,14 +194,23 @@ class Engine:
             # single GPU, fused optimizer attached (dyk/optim.py): the backward runs in two segments; an event after the first marks
             # the point where the gradients of the deep layers (95 % of the parameters) are final -- optimizer.step() starts on
             # them on a side stream while the second segment (the early layers: most of the TIME of a backward pass) still runs
-            segs = self.opt_overlap.segments(plan, fractions=(float(os.environ.get("DYK_OPT_OVERLAP_FRAC", "0.95")),))
+            segs = self.opt_overlap.segments(plan, fractions=(0.95,))      # (70-95 % equal, 99 % worse: r04_ab_optimizer_overlap.log)
             if len(segs) == 2 and segs[0][2] % 8 == 0 and segs[0][2] > 0:
                 (c0, c1, lo, hi), (d0, d1, _, _) = segs
-                plan.run("bwd", stream, c0, c1)
-                ev = self._early_event = self._early_event or torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                plan.run("bwd", stream, d0, d1)
-                self._early = (ev, lo)
+                if getattr(self, "opt_early", False):
+                    # DYK_OPT_OVERLAP=early: the update of G[lo:] may start in the MIDDLE of the pass, so the pass is cut there
+                    plan.run("bwd", stream, c0, c1)
+                    ev = self._early_event = self._early_event or torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                    plan.run("bwd", stream, d0, d1)
+                    self._early = (ev, lo)
+                else:
+                    # default: the optimizer's side stream waits for everything the caller enqueued anyway (dyk/optim.py), so the
+                    # pass stays ONE schedule and only the split point of the update is handed over.  (Round 6: a cut joins all
+                    # streams, i.e. the critical chain waits for whatever weight-gradient launch is in flight -- with grouped
+                    # launches that cost the MobileNetV3 cfg 0.65 ms per step, r6_ab_opt_overlap_c5.log)
+                    plan.run("bwd", stream)
+                    self._early = (None, lo)
             else:
                 plan.run("bwd", stream)
         elif self.grad_sync is None:

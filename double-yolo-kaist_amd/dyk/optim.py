@@ -37,6 +37,7 @@ class _FusedBase(torch.optim.Optimizer):
         if mode != "0":
             from .ddp import GradAllReduce
             model.engine.opt_overlap = GradAllReduce(model, None, attach=False)
+            model.engine.opt_early = self.early_start
 
     def _store(self):
         st = self.model.engine.store
@@ -106,15 +107,10 @@ class _FusedBase(torch.optim.Optimizer):
             # library stream 3 of the schedule runtime (dyk_sched_stream), not a fifth stream: the HIP runtime maps all streams
             # of the process onto four hardware queues and a fifth one shares a queue with whichever stream the runtime picks
             # (in-call, round 4: 28.39 / 28.47 ms with a stream of its own, 28.19 / 28.31 on library stream 3, 28.39 / 28.32 on 2,
-            # 28.60 / 28.47 on 1 -- stream 1 carries the second backbone).  DYK_OPT_SIDE_AUX=0: a torch stream of its own
-            import os
-            k = int(os.environ.get("DYK_OPT_SIDE_AUX", "3"))
-            if k > 0:
-                h = ctypes.c_void_p()
-                check(load().dyk_sched_stream(k, ctypes.byref(h)), "dyk_sched_stream")
-                self._side = torch.cuda.ExternalStream(h.value)
-            else:
-                self._side = torch.cuda.Stream()
+            # 28.60 / 28.47 on 1 -- stream 1 carries the second backbone)
+            h = ctypes.c_void_p()
+            check(load().dyk_sched_stream(3, ctypes.byref(h)), "dyk_sched_stream")
+            self._side = torch.cuda.ExternalStream(h.value)
         side = self._side
 
         def sub(off, cnt):
@@ -145,7 +141,7 @@ class _FusedBase(torch.optim.Optimizer):
             main.wait_event(done)
             return
         ev, lo = early
-        if self.early_start:
+        if self.early_start and ev is not None:
             # opt-in (DYK_OPT_OVERLAP=early / optimizer.early_start = True): the side stream waits for the event recorded in the
             # MIDDLE of the backward pass only.  Anything the caller enqueued on its own stream between backward() and step() that
             # touches gradients -- clip_grad_norm_, manual scaling, gradient-norm logging -- is NOT ordered against it (a clip
@@ -191,8 +187,7 @@ class _FusedBase(torch.optim.Optimizer):
             st.grads_dirty = False
         st.mark_dirty()
         if bf is not None:                # the bf16 copy was written by the step kernel: refresh the rest only
-            import os
-            side = self._side if (self._side is not None and os.environ.get("DYK_OPT_OVERLAP_WT", "1") != "0") else None
+            side = self._side
             st.compute_weights(torch.bfloat16, skip_cast=True, side=side)
         for dt in list(st._compute):
             if dt != torch.bfloat16:

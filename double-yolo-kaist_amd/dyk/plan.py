@@ -22,11 +22,11 @@ from .ops import conv_out_size, dgrad_classes, fwd_taps
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 HEAD_LD = 32            # head conv outputs / their gradients live in 32-channel rows
-FWD_SLOTS_CAP = int(os.environ.get("DYK_FWD_SLOTS_CAP", "32"))    # most replicas of a forward statistics buffer.  32 = every layer's
+FWD_SLOTS_CAP = 32    # most replicas of a forward statistics buffer.  32 = every layer's
 # finalize rides on its normalise launch (42 launches of 9 us fewer on the forward chain of the target cfg: -0.2 ms in an A/B
 # against 256 replicas, round 3; the 10 240 tiles of a 256 x 320 layer then put 320 fp64 atomics on an address -- the backward
 # pass has always run such layers with 16 replicas)
-FWD_SLOT_WG = int(os.environ.get("DYK_FWD_SLOT_WG", "128"))        # conv workgroups per replica of a forward statistics buffer
+FWD_SLOT_WG = 128        # (64 / 256 / 1024: -0.2 / -0.1 / -0.15 ms against 32, round 3; 128: -0.27) conv workgroups per replica of a forward statistics buffer
 def _bnfwd_on():
     """conv + BatchNorm forward in one launch on the deep stages (DYK_EPI_BNFWD).  OFF by default (DYK_BNFWD=1 enables): built,
     bit-identical to the two-launch path, and measured NEUTRAL on MI355X (round 3, C3 at batch 16, same box: 31.79 / 31.99 ms
@@ -40,8 +40,8 @@ def _bnfwd_on():
 
 
 BNFWD_MAX_GRID = 256                                             # = dyk_conv_bnfwd_max_grid(): two such launches are resident together
-DW_SLOTS = int(os.environ.get("DYK_DW_SLOTS", "32"))                # replicas of a depthwise conv's forward statistics buffer
-STAT_SLOTS = int(os.environ.get("DYK_STAT_SLOTS", "16"))   # replicas of every per-channel fp64 reduction buffer of the backward (bounds atomic
+DW_SLOTS = 32                # replicas of a depthwise conv's forward statistics buffer
+STAT_SLOTS = 16   # replicas of every per-channel fp64 reduction buffer of the backward (bounds atomic
                                                             # contention; every apply workgroup folds them: 32 -> 16 measured -0.15 ms, 64 +0.4 ms)
 
 
@@ -197,7 +197,7 @@ class Plan:
         mode = os.environ.get("DYK_SCHED", "dag")
         if mode == "dag" and os.environ.get("DYK_OVERLAP", "1") != "0":
             sc = self.schedule(which, start, end)
-            lp = 1 if os.environ.get("DYK_SCHED_LOWPRIO", "0") != "0" else 0       # (low-priority streams: 40 ms against 28.5, round 4)
+            lp = 0       # (low-priority side streams: 40 ms against 28.5, round 4 -- never)
             rc = None
             # hipGraph replay of the dependency graph: built and tested, OFF by default -- on this stack (HIP runtime of
             # PyTorch-ROCm 7.0) a graph launch of the 435 + 671 child nodes runs the step in 46.3 ms against 36.1 ms for the
@@ -245,7 +245,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     # 72-channel ones.  Tight rows (a multiple of the 16-byte vector): the last K step of a pixel then runs into the
     # NEXT pixel's first channels -- finite values that meet the zero rows of the padded weight matrix (Wc_pad / Wt_pad),
     # so they contribute exactly 0; every arena ends in 256 spare zero bytes for the last pixel of the last tensor.
-    tight = os.environ.get("DYK_TIGHT_ROWS", "1") != "0"
+    tight = True             # rows of ceil(C / 8) * 8 channels (round 2; padding to the 32-channel K step cost the MobileNet cfgs 2 ms)
 
     def kpad_bytes(ld, esize):
         # A tensor (or a channel slice of a concat buffer) whose channel count is not a multiple of the MFMA conv's
@@ -280,7 +280,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 head_conv = q + 1 < len(defs) and defs[q + 1]["type"] == "yolo"
                 if (q not in concat_slot and chans[q] % 32 == 0 and not head_conv
                         and defs[q]["type"] in ("convolutional", "depthwiseconvolutional", "maxpool", "upsample", "se")
-                        and list(mods[j].layers).count(q) == 1 and not os.environ.get("DYK_NO_CONCAT_PLACEMENT")):
+                        and list(mods[j].layers).count(q) == 1):
                     concat_slot[q] = (j, c0, sum(chans[r] for r in mods[j].layers))
                 c0 += chans[q]
 
@@ -299,7 +299,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     # outputs are channel slices of ONE buffer and their scale / shift / mean / rstd vectors sit side by side.  Decided here
     # (layout), confirmed at the route (every source took its slot) and in the backward (sole reader, first writer).
     joint_slot, joint_raw, joint_vecs, joint_of = {}, {}, {}, {}
-    if (training and os.environ.get("DYK_JOINT_BNBWD", "1") != "0" and not os.environ.get("DYK_DEBUG_PLAN")
+    if (training and not os.environ.get("DYK_DEBUG_PLAN")
             and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"):
         for j, md in enumerate(defs):
             if md["type"] != "route" or len(mods[j].layers) < 2:
@@ -431,7 +431,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 d.pre_act = pre[1]
                 later(lambda d=d, pre=pre: setattr(d, "pre", ws.ptr(pre[0])))
         elif (stem_src is not None and k == 3 and pad == 1 and stride in (1, 2) and cout in (16, 32) and bn
-              and os.environ.get("DYK_STEM_DIRECT", "1") != "0"):
+              ):
             # Cin=3 stem straight from the image batch (csrc/stem.hip): no float conversion pass, no im2col
             Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
             Hi, Wi = H, W
@@ -574,7 +574,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     return z, rec
                 a = ew_desc(a=y_raw, out=z, act=act)
                 later(lambda a=a, vecs=vecs, vs=vs: (setattr(a, "p0", ws.ptr(vecs)), setattr(a, "p1", ws.ptr(vecs + vs))))
-                if slots <= 32 and os.environ.get("DYK_BN_FUSED_FWD", "1") != "0":
+                if slots <= 32:
                     fm = misc()                       # finalize folded into the normalise + activation launch
                     fm.p[0], fm.p[1] = ctypes.addressof(f), ctypes.addressof(a)
                     plan.fwd.append((L.OP_BN_FWD_FUSED, fm))
@@ -937,8 +937,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             """the conv whose data gradient can take the [shortcut] gradient of `a` as an addend and reduce the
             BatchNorm backward of a's producer in its epilogue (DYK_EPI_BNBWD | DYK_EPI_ADDEND): `a` is read by that
             conv and the [shortcut] only, the conv comes earlier than layer `before` and covers a in one launch"""
-            if (os.environ.get("DYK_BNBWD_FUSE", "1") == "0" or os.environ.get("DYK_CHAIN_FUSE", "1") == "0"
-                    or os.environ.get("DYK_DEBUG_PLAN")):
+            if os.environ.get("DYK_BNBWD_FUSE", "1") == "0" or os.environ.get("DYK_DEBUG_PLAN"):
                 return None
             prod = producer_of.get(a.tid)
             if prod is None or not prod.get("bn"):
@@ -995,7 +994,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 if (first and prod is not None and prod is not rec and tcons.get(x_in.tid, 0) == 1
                         and stride == 1 and k in (3, 5) and code == L.DYK_BF16 and "vecs" in prod and prod["vs"] == 4 * x_in.C
                         and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
-                        and os.environ.get("DYK_DW_TILE", "1") != "0" and os.environ.get("DYK_DW_BNBWD", "1") != "0"):
+                        ):
                     prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
                     prod["keep_dz"] = False
                     gd.act, gd.stats_slots, gd.ldr = prod["act"], STAT_SLOTS, prod["y_raw"].ld
@@ -1020,7 +1019,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 later(lambda wd=wd, dy=dy, part=part: (setattr(wd, "dy", ptr_of(dy)), setattr(wd, "part", ws.ptr(part))))
                 bap = rec.get("_bn_apply")
                 if (bap is not None and bap[5] and code == L.DYK_BF16 and dy.ld == f.Cout and rec["y_raw"].ld == f.Cout
-                        and os.environ.get("DYK_STEM_BN_FUSE", "1") != "0"):
+                        ):
                     # BatchNorm-backward apply of the stem's own BatchNorm inside this weight gradient (uint8 images: decided per
                     # call by the engine, dyk_stem_wgrad_bn_fusable): da and the raw output are read instead of dz, the separate
                     # pass over the largest activation of the net is skipped (DYK_EW_SKIP on its descriptor)
@@ -1083,7 +1082,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                           and prod.get("fused_shortcut") and prod.get("bn") and "vecs" in prod and tcons.get(x_in.tid, 0) == 2
                           and x_in.C % (16 // es) == 0 and stride == 1 and len(dgrad_classes(k, pad, 1, x_in.H, x_in.W)) == 1
                           and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
-                          and os.environ.get("DYK_CHAIN_FUSE", "1") != "0" and os.environ.get("DYK_LAST_SHORTCUT_FUSE", "1") != "0")
+                          )
             if zero_chain:
                 fuse = True
                 prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
@@ -1107,7 +1106,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
             merged = (len(classes) in (2, 4) and all(c[4] for c in classes)
                       and len({(c[2], c[3]) for c in classes}) == 1
                       and sum(len(c[4]) for c in classes) <= L.MAX_TAPS
-                      and os.environ.get("DYK_DGRAD_MERGE", "1") != "0")
+                      )
             if merged:
                 classes = [(0, 0, classes[0][2], classes[0][3], [t for c in classes for t in c[4]], classes)]
             for cls in classes:
@@ -1286,7 +1285,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                         tail = ga.chan_slice(nx, na - nx)
                         plan.bwd.append((L.OP_AXPBY, ew_desc(a=tail, out=tail, C=na - nx, alpha=0.0)))     # alpha = 0: `a` is not read
 
-                if rec["weighted"] and nx == na and os.environ.get("DYK_WFUSE_BWD_FUSED", "1") != "0":
+                if rec["weighted"] and nx == na:
                     # weighted fusion, equal channel counts: per source ONE pass over dz leaves its fusion-weight dot product AND
                     # its scaled gradient copy (dyk_dot with `out`, round 5: two dots + two scaled copies read dz four times)
                     red = new_red(16)
@@ -1343,7 +1342,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 # the data half (dpooled) stays on the chain to dx; the parameter half is a command of its own that the
                 # dependency scheduler places like a weight gradient (one call held the chain for three launches: 24 us on
                 # each of the 19 squeeze-excitation blocks of the MobileNetV3 cfg).  DYK_SE_SPLIT=0: one command, as before
-                split = os.environ.get("DYK_SE_SPLIT", "1") != "0"
+                split = True
                 fg = L.DykSeFcDesc() if split else fd
                 if split:
                     plan._keep.append(fg)
@@ -1367,7 +1366,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 fuse = (x_in.tid not in ginit and prod is not None and prod.get("bn") and "vecs" in prod and prod["vs"] == 4 * C
                         and tcons.get(x_in.tid, 0) == 1 and x_in.C % (16 // es) == 0 and prod["y_raw"].C == C
                         and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
-                        and os.environ.get("DYK_SE_BNBWD", "1") != "0")
+                        )
                 sd = ew_desc(a=dz, b=prod["y_raw"] if fuse else None, out=gx, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W,
                              alpha=1.0 / (x_in.H * x_in.W), flags=acc_flag(x_in), act=prod["act"] if fuse else 0)
                 later(lambda sd=sd, rec=rec, dpooled=dpooled: (setattr(sd, "p0", ws.ptr(rec["scale"])), setattr(sd, "p1", ws.ptr(dpooled))))
@@ -1415,8 +1414,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         fn()
     plan.training = training
     plan.store = store
-    if training and os.environ.get("DYK_BNBWD_FUSE", "1") != "0" and os.environ.get("DYK_LATE_FUSE", "1") != "0" \
-            and not os.environ.get("DYK_DEBUG_PLAN"):
+    if training and os.environ.get("DYK_BNBWD_FUSE", "1") != "0" and not os.environ.get("DYK_DEBUG_PLAN"):
         _fuse_late_reduces(plan, store)
     if not dry and os.environ.get("DYK_AUTOTUNE", "1") != "0":
         autotune(plan, _TUNE_CACHE)
@@ -1444,7 +1442,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 if defs[j]["type"] in ("route", "shortcut") and any(q < second for q in mods[j].layers):
                     force.add(j - 1)
                     break
-        _setup_wgrad_partials(plan, store, device, force)
+        _setup_wgrad_partials(plan, store, device, force | getattr(plan, "_wg_protect_layers", set()))
     if training:
         _finish_wgrad_groups(plan, device)
 
@@ -1452,7 +1450,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     # sections [second, F) -- the second backbone up to the first section that reads anything of the first one -- are
     # independent of sections [0, second): tag them for the branch stream of dyk_run_commands_overlap
     plan.fwd_lanes, plan.bwd_lanes = {}, {}
-    if second is not None and 0 < second < len(defs) and os.environ.get("DYK_BRANCH_LANES", "1") != "0":
+    if second is not None and 0 < second < len(defs):
         F = len(defs)
         for j in range(second, len(defs)):
             if defs[j]["type"] in ("route", "shortcut") and any(q < second for q in mods[j].layers):
@@ -1477,7 +1475,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     # sections differentiated stay on their own streams instead (measured on the per-stream timeline, tools/trace_timeline.py)
     if training:
         wg = [q for q, (op, _) in enumerate(plan.bwd) if op in (L.OP_WGRAD, L.OP_DW_WGRAD)]
-        ntail = 0 if plan.part is not None else int(os.environ.get("DYK_WGRAD_INPLACE_TAIL", "20"))
+        ntail = 0 if plan.part is not None else 20
         for q in wg[len(wg) - ntail:] if ntail > 0 else []:
             plan.bwd_lanes[q] = plan.bwd_lanes.get(q, 0) | 8
 
@@ -1665,11 +1663,29 @@ def _group_wgrads(plan, store):
         hi = marks[k + 1][0] if k + 1 < len(marks) else n
         for q in range(marks[k][0], hi):
             layer_at[q] = marks[k][1]
+    # positions where the data-parallel exchange closes its default buckets (dyk/ddp.py GEOMETRIC: 50 | 80 | 95 | 99 % of the
+    # gradient buffer in backward order; 95 % is also where the one-GPU optimizer step starts early): no launch may hold back a
+    # gradient across one of them -- a member before the cut, the launch behind it -- or the bucket could not close there
+    total = store.total
+    first_off = {}
+    for e in store.entries:
+        first_off.setdefault(e.layer, e.offset)
+    cuts = [total - int(f * total) for f in (0.5, 0.8, 0.95, 0.99)]
+    protected = []
+    for k in range(1, len(marks)):
+        c_end, layer_done = marks[k][0], marks[k - 1][1]
+        lo = min((o for l, o in first_off.items() if l >= layer_done), default=total)
+        while cuts and lo <= cuts[0]:
+            protected.append(c_end)
+            cuts.pop(0)
+    pos_layer = {cnt: layer for cnt, layer in marks}
+    plan._wg_protect_layers = {pos_layer[c] for c in protected}      # (the plane fold is forced there: _setup_wgrad_partials)
     groups = []
     for key, idxs in cand.items():
         cur, lim = [idxs[0]], late[idxs[0]]
         for i in idxs[1:] + [None]:
-            if i is not None and i <= lim and len(cur) < maxg and i - cur[0] <= int(os.environ.get("DYK_WGRAD_GROUP_WINDOW", WGRAD_GROUP_WINDOW)):
+            if (i is not None and i <= lim and len(cur) < maxg and i - cur[0] <= WGRAD_GROUP_WINDOW
+                    and not any(cur[0] < c <= i for c in protected)):
                 cur.append(i)
                 lim = min(lim, late[i])
                 continue
@@ -1679,6 +1695,13 @@ def _group_wgrads(plan, store):
                 cur, lim = [i], late[i]
     if not groups:
         return
+    def tiles_of(d):                          # workgroups of one problem per K split
+        if lib.dyk_conv_wgrad_variant(ctypes.byref(d)) == 2:
+            return -(-d.Cout // 64) * -(-d.Cin // 32)
+        cap64 = ((d.tune >> 8) & 0xf) == 1
+        bm, bn = (128 if d.Cout > 64 and not cap64 else 64), (128 if d.Cin > 64 and not cap64 else 64)
+        return -(-d.Cout // bm) * -(-d.Cin // bn)
+
     removed = []
     for g in groups:
         members = [cmds[i][1] for i in g]
@@ -1686,15 +1709,11 @@ def _group_wgrads(plan, store):
         s1 = lib.dyk_conv_wgrad_splits(ctypes.byref(lead))
         if s1 < 1:
             continue
-        if lib.dyk_conv_wgrad_variant(ctypes.byref(lead)) == 2:          # workgroups of one problem per K split
-            tiles = -(-lead.Cout // 64) * -(-lead.Cin // 32)
-        else:
-            cap64 = ((lead.tune >> 8) & 0xf) == 1
-            bm, bn = (128 if lead.Cout > 64 and not cap64 else 64), (128 if lead.Cin > 64 and not cap64 else 64)
-            tiles = -(-lead.Cout // bm) * -(-lead.Cin // bn)
-        # as many workgroups as ONE member's tuned launch had, at least one per CU, spread over the whole group
-        wgs = int(os.environ.get("DYK_WGRAD_GROUP_WGS", "256"))
-        sg = max(1, min(s1, -(-max(tiles * s1, wgs) // (tiles * len(g)))))
+        # K splits per member: as many workgroups over the WHOLE group as ONE member's tuned launch had, at least one per CU.
+        # (A model of rounds of 256 workgroups + plane traffic per split, and groups cut to whole rounds -- 5 members of 64 tiles
+        # as 4 + 1 -- measured no better in the step and 0.15 ms worse at batch 1: r6_ab_tree_group_shape.log)
+        tiles = tiles_of(lead)
+        sg = max(1, min(s1, -(-max(tiles * s1, 256) // (tiles * len(g)))))
         for m in members:
             m.splits = sg
         plan._wg_groups[ctypes.addressof(lead)] = members
@@ -1987,7 +2006,7 @@ def _conv_split_candidates(d):
         return []
     es = 2 if d.dtype == L.DYK_BF16 else 4
     npix = d.B * d.Hg * d.Wg
-    max_s = int(os.environ.get("DYK_CONV_SPLITK_MAX", "8"))
+    max_s = 8                # (12 / 16 slices measured equal to 8 at batch 1, round 5)
     out = []
 
     def splits(tiles, kchunks):
@@ -2039,45 +2058,16 @@ if os.environ.get("DYK_WGRAD_PS", "1") != "0":
 # | 2 << 28 = row-block 3x3 kernel (round 4: 128-pixel block steps, 64 x 32 x 9-tap tiles)
 
 
-_TUNE_LOAD = {}
-
-
-def _background_load(kind, reps):
-    """analysis ("tune under load"): DYK_TUNE_LOAD=hbm | mfma | both keeps a side stream busy with copies of a
-    512 MB buffer and / or 4096^3 bf16 matrix products while a candidate is timed, so that candidates are ranked by what
-    they cost beside other kernels (in the step four streams share the chip) instead of alone.  Measured (round 4, in-call,
-    `profiles/r04_ab_tune_under_load.log`): 28.4 ms with candidates timed alone, 29.5 (hbm), 30.5 (mfma), 29.5 (both) -- the load's
-    own jitter decides between close candidates; OFF by default"""
-    if not _TUNE_LOAD:
-        dev = torch.device("cuda", torch.cuda.current_device())
-        _TUNE_LOAD["stream"] = torch.cuda.Stream()
-        _TUNE_LOAD["a"] = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
-        _TUNE_LOAD["b"] = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
-        _TUNE_LOAD["m"] = torch.randn(4096, 4096, device=dev).bfloat16()
-        _TUNE_LOAD["o"] = torch.empty(4096, 4096, dtype=torch.bfloat16, device=dev)
-    st = _TUNE_LOAD["stream"]
-    st.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(st):
-        for _ in range(2 * reps + 2):
-            if kind in ("hbm", "both"):
-                _TUNE_LOAD["b"].copy_(_TUNE_LOAD["a"])
-            if kind in ("mfma", "both"):
-                torch.mm(_TUNE_LOAD["m"], _TUNE_LOAD["m"], out=_TUNE_LOAD["o"])
-    return st
-
-
 def _time_launch(fn, desc, stream, reps=3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     L.check(fn(ctypes.byref(desc), stream), "autotune launch")          # warm-up (also loads the code object)
-    load = os.environ.get("DYK_TUNE_LOAD", "0")
-    side = _background_load(load, reps) if load != "0" else None
+    # (candidates are timed ALONE: timing them beside a side stream of 512 MB copies and / or 4096^3 bf16 products -- "tune under
+    # load", rounds 3-4 -- made the step 1.1-2.1 ms slower, profiles/r04_ab_tune_under_load.log; removed in round 6)
     e0.record()
     for _ in range(reps):
         fn(ctypes.byref(desc), stream)
     e1.record()
     e1.synchronize()
-    if side is not None:
-        side.synchronize()
     return e0.elapsed_time(e1) / reps
 
 
@@ -2086,11 +2076,8 @@ def _refine(cands, times, trial, within=1.10, keep=4, rounds=2, reps=6):
     launches; candidates within a few per cent of each other then win or lose on timer noise, and the step time of one
     build moved by 0.4 ms from run to run on one box (round 3).  The `keep` fastest within `within` of the best are timed
     again, interleaved, `rounds` x `reps` launches each; their times are replaced by the mean of the second look."""
-    knob = os.environ.get("DYK_TUNE_REFINE", "1")          # "0": off; "keep,rounds,reps": sweep knob
-    if knob == "0" or len(cands) < 2:
+    if len(cands) < 2:
         return times
-    if "," in knob:
-        keep, rounds, reps = (int(v) for v in knob.split(","))
     best = min(times)
     short = sorted((t, i) for i, t in enumerate(times) if t <= within * best)[:keep]
     if len(short) < 2:
@@ -2129,7 +2116,7 @@ def autotune(plan, cache=None):
     for (op, d) in plan.fwd + plan.bwd:
         if op == L.OP_CONV:
             key = ("c", d.dtype, d.B, d.Cin, d.Cout, d.Hg, d.Wg, d.ntaps, d.isy, d.osy,
-                   d.flags & (L.EPI_STATS | L.EPI_OUT_F32 | L.EPI_BNBWD | L.EPI_BNFWD | (L.EPI_ADDEND if os.environ.get("DYK_TUNE_KEY_ADDEND", "1") != "0" else 0)), d.ncls)
+                   d.flags & (L.EPI_STATS | L.EPI_OUT_F32 | L.EPI_BNBWD | L.EPI_BNFWD | L.EPI_ADDEND), d.ncls)
         elif op == L.OP_WGRAD:
             key = ("w", d.dtype, d.B, d.Cin, d.Cout, d.Ho, d.Wo, d.ntaps, d.isy)
         else:
@@ -2163,10 +2150,7 @@ def autotune(plan, cache=None):
                         plan.arenas["stats"].tensor.zero_()          # (the filter launches above left sums in the replicas)
                 else:
                     cands, fn = _WGRAD_CANDIDATES, lib.dyk_conv_wgrad
-                    if os.environ.get("DYK_WGRAD_CANDS"):
-                        cands = [int(c, 0) for c in os.environ["DYK_WGRAD_CANDS"].split(",")]
-                planes_on = (key[0] == "w" and plan.training and os.environ.get("DYK_WGRAD_PARTIALS", "1") != "0"
-                             and not os.environ.get("DYK_WGRAD_TUNE_ATOMIC"))    # (analysis: the round-1 way)
+                planes_on = key[0] == "w" and plan.training and os.environ.get("DYK_WGRAD_PARTIALS", "1") != "0"
                 if planes_on:
                     # Weight gradients are timed the way the step runs them: every K split stores its own partial plane
                     # (_setup_wgrad_partials below; the atomic form penalises exactly the many-split shapes the plane form is
@@ -2213,7 +2197,7 @@ def autotune(plan, cache=None):
                         if auto < 1:
                             continue
                         opts = {auto}
-                        if os.environ.get("DYK_WGRAD_TUNE_SPLITS", "1") != "0" and plane % 4 == 0:
+                        if plane % 4 == 0:
                             opts |= {max(1, auto // 2), max(1, auto // 4), max(1, auto // 8)}
                         for o in sorted(opts, reverse=True):
                             t = trial(c, 0 if o == auto else o)
@@ -2280,8 +2264,6 @@ def autotune(plan, cache=None):
                 d.tune, d.splits = best             # (tile configuration, K splits: 0 = the kernel's own count)
             else:
                 d.tune = best
-            if key[0] == "c" and os.environ.get("DYK_EPI_OLD"):
-                d.tune |= 1 << 21                   # analysis: one raw-output load per trip in the fused BN-backward epilogue
             if key in _TUNE_MS:
                 plan._cmd_us[ctypes.addressof(d)] = 1e3 * _TUNE_MS[key]      # measured duration: cost of the scheduler
     plan.tuned = dict(cache)

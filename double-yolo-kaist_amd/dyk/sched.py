@@ -387,7 +387,7 @@ def schedule(cmds, deps, costs, n_streams, first=0, filler=None, klass=None, pol
     for i in range(n - 1, -1, -1):
         blevel[i] = costs[i] + max((blevel[u] for u in users[i]), default=0.0)
     missing = [len(deps[i]) for i in range(n)]
-    n_fill = min(n_streams - 1, max(1, int(os.environ.get("DYK_SCHED_FILLER", "1") or 1))) if (filler and n_streams > 1) else 0
+    n_fill = 1 if (filler and n_streams > 1) else 0
     general = n_streams - n_fill
     avail = [0.0] * n_streams
     start, finish, stream_of = [0.0] * n, [0.0] * n, [0] * n
@@ -525,9 +525,7 @@ def build(plan, store, which, start, end, n_streams=None):
     mem = Memory(plan, store)
     deps = dependencies(cmds, mem, plan)
     costs = [estimate_cost_us(op, d, plan) for op, d in cmds]
-    filler = None
-    if os.environ.get("DYK_SCHED_FILLER", "0") != "0":
-        filler = {i for i, (op, _) in enumerate(cmds) if op in (L.OP_WGRAD, L.OP_DW_WGRAD, L.OP_GRAD_REDUCE)}
+    filler = None        # (weight gradients restricted to dedicated filler streams: neutral, round 4 -- r04_ab_sched_event_filler_streams.log)
     # resource-typed streams (all MFMA kernels on stream 0, streaming kernels beside them): OFF by default -- measured
     # 43.0 ms vs 35.3 (batch 1: 18.1 vs 10.2): every conv -> BatchNorm -> conv hop then crosses streams, and a cross-stream
     # event dependency costs ~7-10 us on this stack, more than the overlap it buys
@@ -550,10 +548,10 @@ def build(plan, store, which, start, end, n_streams=None):
     if twin_of and layer_of is not None and os.environ.get("DYK_PAIR", "0") != "0" and pair_which in ("both", which):
         from . import twins
         pairs = twins.find_pairs(cmds, deps, layer_of[start:end], twin_of, plan, os.environ.get("DYK_PAIR_OPS", "ew"),
-                                 1e6 * float(os.environ.get("DYK_PAIR_MAX_MB", "48")))
+                                 48e6)
     if pairs:
         members, ndeps, ncosts = twins.merge(len(cmds), deps, costs, pairs,
-                                             float(os.environ.get("DYK_PAIR_COST", "0.8")))
+                                             0.8)
         if filler:
             filler = {k for k, m in enumerate(members) if m[0] in filler}
         if klass is not None:
