@@ -1593,7 +1593,7 @@ def _default_wgrad_tunes(plan):
     for op, d in plan.bwd:
         if op != L.OP_WGRAD or d.tune:
             continue
-        for v, t in ((2, 2 | (1 << 8) | (2 << 28) | WGRAD_EXCLUSIVE), (3, (3 << 28) | 4 | WGRAD_EXCLUSIVE)):
+        for v, t in ((2, 2 | (1 << 8) | (2 << 28) | WGRAD_EXCLUSIVE), (3, (3 << 28) | 3 | WGRAD_EXCLUSIVE)):
             d.tune = t
             if (v == 2 and os.environ.get("DYK_WGRAD_RB", "1") == "0") or (v == 3 and os.environ.get("DYK_WGRAD_PS", "1") == "0") \
                     or lib.dyk_conv_wgrad_variant(ctypes.byref(d)) != v:
@@ -2051,9 +2051,12 @@ if os.environ.get("DYK_WGRAD_PS", "1") != "0":
     # pixel-streaming 1x1 kernel (round 6, csrc/conv_wgrad_ps.hip): ring stages in the low byte, 64 x 64 tile cap << 8,
     # 64-pixel stages for the 64 x 64 tile << 12; ignored (falls back to the per-tap kernel = candidate 2) where it does not apply
     _WGRAD_PS = 3 << 28
-    _WGRAD_CANDIDATES += [_WGRAD_PS | 2 | WGRAD_EXCLUSIVE, _WGRAD_PS | 3 | WGRAD_EXCLUSIVE, _WGRAD_PS | 4 | WGRAD_EXCLUSIVE,
-                          _WGRAD_PS | 6 | WGRAD_EXCLUSIVE, _WGRAD_PS | 4 | (1 << 8) | WGRAD_EXCLUSIVE,
-                          _WGRAD_PS | 8 | (1 << 8) | (1 << 12) | WGRAD_EXCLUSIVE]
+    # Rings of at most 96 KB: a weight gradient is filler work beside the critical chain, and a workgroup that holds 128 KB of
+    # LDS keeps every convolution workgroup (45-110 KB) off its CU for its whole life.  Alone, the 4- / 6-stage rings are the
+    # faster ones on the deep layers (tools/wgps_probe.py); in the step every launch forced to 2 / 3 / 4 stages measured
+    # 26.35 / 26.42 / 26.46 ms against 26.53 with the tuner's free choice (r6_ab_ps_ring_in_step.log)
+    _WGRAD_CANDIDATES += [_WGRAD_PS | 2 | WGRAD_EXCLUSIVE, _WGRAD_PS | 3 | WGRAD_EXCLUSIVE,
+                          _WGRAD_PS | 4 | (1 << 8) | WGRAD_EXCLUSIVE, _WGRAD_PS | 4 | (1 << 8) | (1 << 12) | WGRAD_EXCLUSIVE]
 # LDS ring stages (2 | 3; 4 exists in the kernel, measured never the fastest: DESIGN 9.4) | K-groups per workgroup << 8 | tile cap << 24 (1 = 64 x 64) | 1 << 28 = multi-tap 3x3 kernel
 # | 2 << 28 = row-block 3x3 kernel (round 4: 128-pixel block steps, 64 x 32 x 9-tap tiles)
 

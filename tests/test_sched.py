@@ -167,3 +167,49 @@ def test_conv_k_step_overread_stays_inside_the_tensors_own_block(name):
             seen += (d.Cin * es) % 64 != 0 or (d.ldx * es) % 64 != 0
     if name in (C5, MNV2):
         assert seen > 10          # the MobileNet cfgs are the ones with tight rows
+
+
+@pytest.mark.parametrize("name", [C3, C5, C1])
+def test_grouped_weight_gradients_read_what_their_own_launches_would(name, monkeypatch):
+    """Round 6 (dyk/plan.py _group_wgrads): the weight gradients of a stage's repeated units share ONE launch at the position of
+    the last member.  Checked against the UNGROUPED backward list of the same plan (DYK_WGRAD_GROUP=0): every layer's weight
+    gradient is in exactly one launch, a member's inputs (x, dy) are not rewritten and its gradient not touched by any command
+    between its own position and the launch that now carries it, members of one launch share a geometry, and no launch holds
+    a gradient back across a default data-parallel bucket cut."""
+    import ctypes
+    from dyk import lib as L, sched
+    from dyk.ddp import GradAllReduce
+    monkeypatch.setenv("DYK_WGRAD_GROUP", "0")
+    flat, st0 = _plan(name, True, B=4, H=128, W=160)
+    monkeypatch.setenv("DYK_WGRAD_GROUP", "16")
+    plan, st = _plan(name, True, B=4, H=128, W=160)
+    assert not flat._wg_groups and all(d.group_n == 0 for op, d in flat.bwd if op == L.OP_WGRAD)
+    g0f, g0 = st0.G.data_ptr(), st.G.data_ptr()
+    pos_flat = {d.dw - g0f: q for q, (op, d) in enumerate(flat.bwd) if op == L.OP_WGRAD}
+    members = [m for op, d in plan.bwd if op == L.OP_WGRAD for m in plan._wg_groups.get(ctypes.addressof(d), [d])]
+    assert sorted(m.dw - g0 for m in members) == sorted(pos_flat)          # every layer once
+    if name != C1:
+        assert len(plan._wg_groups) >= 8 and len(plan.bwd) < len(flat.bwd) - 30
+    mem = sched.Memory(flat, st0)
+    acc = [sched.accesses(op, d, mem, flat) for op, d in flat.bwd]
+    for lead_addr, ms in plan._wg_groups.items():
+        sig = {(m.dtype, m.B, m.Hi, m.Wi, m.Cin, m.Ho, m.Wo, m.Cout, m.ntaps, m.isy, m.tune, m.splits, m.ldx, m.lddy) for m in ms}
+        assert len(sig) == 1 and len(ms) >= 2
+        qs = [pos_flat[m.dw - g0] for m in ms]
+        assert qs == sorted(qs)
+        last = qs[-1]
+        for q in qs[:-1]:
+            Rq, Wq, _ = acc[q]
+            for k in range(q + 1, last + 1):
+                Rk, Wk, bk = acc[k]
+                assert not bk, (q, k)
+                assert not any(w.overlaps(r) for w in Wk for r in Rq), "command %d rewrites an input of the deferred weight gradient %d" % (k, q)
+                assert not any(a.overlaps(w) for w in Wq for a in Rk + Wk), "command %d touches the gradient of the deferred launch %d" % (k, q)
+    # the default buckets of the data-parallel exchange (and the optimizer's 95 % cut) are all still there
+    red = GradAllReduce.__new__(GradAllReduce)
+    red.n_buckets, red.engine = 0, type("E", (), {"store": st})()
+    segs = red.segments(plan)
+    assert len(segs) == 5, segs
+    total = st.total
+    for (c0, c1, lo, hi), f in zip(segs, GradAllReduce.GEOMETRIC):
+        assert lo <= total - int(f * total)
