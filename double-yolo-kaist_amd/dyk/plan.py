@@ -1404,16 +1404,54 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         memset_desc.n, memset_desc.i[0] = hi - lo, 0
         later(lambda ms=memset_desc, lo=lo: ms.p.__setitem__(0, ws.ptr(lo)))
 
-    # ---------------------------------------------------------------- materialise
+    # ---------------------------------------------------------------- the rest is a pipeline of passes over the two lists
+    # allocate + emit (above)  ->  materialise  ->  fuse  ->  tune  ->  group  ->  scratch  ->  schedule metadata
+    _materialise(plan, device, pending, stats_memset if training else None, st_arena)
+    plan.training = training
+    plan.store = store
+    _post_passes(plan, store, device, dry, training, stats_memset, _backbone_force_layers(defs, mods, second))
+    _assign_lanes(plan, defs, mods, second, fwd_start, training)
+    _layer_maps(plan, model, defs, mods, second, fwd_start, training)
+    plan.finalize()
+    plan.info = info
+    plan.grads = grads if training else {}
+    plan.outs = outs
+    plan.shape = (B, H, W)
+    plan.dtype = dtype
+    plan.training = training
+    return plan
+
+
+# ======================================================================================
+# Passes over the emitted command lists (compile_plan's second half)
+def _materialise(plan, device, pending, stats_memset, st_arena):
+    """arenas get their memory, every deferred pointer assignment of the emission runs"""
     for a in plan.arenas.values():
         a.materialize(device)
-    if training:
+    if stats_memset is not None:
         stats_memset.p[0] = st_arena.ptr(0)
         stats_memset.n, stats_memset.i[0] = max(st_arena.size, 256), 0
     for fn in pending:
         fn()
-    plan.training = training
-    plan.store = store
+
+
+def _backbone_force_layers(defs, mods, second):
+    """the two backbones of a dual-stream net are enqueued interleaved (dyk_run_commands_overlap): a plane fold must not span the
+    boundary between them, or it could run before weight gradients that precede it in the list"""
+    force = set()
+    if second is not None and 0 < second < len(defs):
+        force.add(second - 1)
+        for j in range(second, len(defs)):
+            if defs[j]["type"] in ("route", "shortcut") and any(q < second for q in mods[j].layers):
+                force.add(j - 1)
+                break
+    return force
+
+
+def _post_passes(plan, store, device, dry, training, stats_memset, force_layers):
+    """fuse (BatchNorm-backward reduces onto the last contributor's data gradient) -> tune (tile / kernel per problem) -> group
+    (weight gradients of one geometry into one launch) -> scratch (split-K slabs and counters, weight-gradient planes and their
+    fold commands, device tables of the grouped launches)"""
     if training and os.environ.get("DYK_BNBWD_FUSE", "1") != "0" and not os.environ.get("DYK_DEBUG_PLAN"):
         _fuse_late_reduces(plan, store)
     if not dry and os.environ.get("DYK_AUTOTUNE", "1") != "0":
@@ -1433,22 +1471,14 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
     plan.part = None
     plan.bwd_cut_ok = None
     if training and not dry and os.environ.get("DYK_WGRAD_PARTIALS", "1") != "0":
-        # the two backbones of a dual-stream net are enqueued interleaved (dyk_run_commands_overlap): a reduction must
-        # not span the boundary between them, or it could run before weight gradients that precede it in the list
-        force = set()
-        if second is not None and 0 < second < len(defs):
-            force.add(second - 1)
-            for j in range(second, len(defs)):
-                if defs[j]["type"] in ("route", "shortcut") and any(q < second for q in mods[j].layers):
-                    force.add(j - 1)
-                    break
-        _setup_wgrad_partials(plan, store, device, force | getattr(plan, "_wg_protect_layers", set()))
+        _setup_wgrad_partials(plan, store, device, set(force_layers) | getattr(plan, "_wg_protect_layers", set()))
     if training:
         _finish_wgrad_groups(plan, device)
 
-    # ---------------------------------------------------------------- branch lanes (dual-stream nets)
-    # sections [second, F) -- the second backbone up to the first section that reads anything of the first one -- are
-    # independent of sections [0, second): tag them for the branch stream of dyk_run_commands_overlap
+
+def _assign_lanes(plan, defs, mods, second, fwd_start, training):
+    """branch lanes of the round-1 executor (dyk_run_commands_overlap, DYK_SCHED=lanes): sections [second, F) -- the second
+    backbone up to the first section that reads anything of the first one -- are independent of sections [0, second)"""
     plan.fwd_lanes, plan.bwd_lanes = {}, {}
     if second is not None and 0 < second < len(defs):
         F = len(defs)
@@ -1470,7 +1500,6 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                     plan.bwd_lanes[b0] = 2                          # fork once the fusion sections' gradients exist
                     for q in range(a0, len(plan.bwd)):
                         plan.bwd_lanes[q] = plan.bwd_lanes.get(q, 0) | 1
-
     # the side stream finishes last (its launches contend with the chain for CUs): the weight gradients of the last
     # sections differentiated stay on their own streams instead (measured on the per-stream timeline, tools/trace_timeline.py)
     if training:
@@ -1479,8 +1508,9 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         for q in wg[len(wg) - ntail:] if ntail > 0 else []:
             plan.bwd_lanes[q] = plan.bwd_lanes.get(q, 0) | 8
 
-    plan.store = store
-    # cfg section of every command (dyk/twins.py pairs the commands of twin sections into two-problem launches)
+
+def _layer_maps(plan, model, defs, mods, second, fwd_start, training):
+    """cfg section of every command (dyk/twins.py pairs the commands of twin sections into two-problem launches)"""
     from . import twins
     plan.twin_layer = twins.twin_layers(defs, mods, second)
     plan.fwd_layer = [-1] * len(plan.fwd)
@@ -1494,14 +1524,6 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         for k in range(len(marks) - 1):
             for q in range(marks[k][0], marks[k + 1][0]):
                 plan.bwd_layer[q] = marks[k][1]
-    plan.finalize()
-    plan.info = info
-    plan.grads = grads if training else {}
-    plan.outs = outs
-    plan.shape = (B, H, W)
-    plan.dtype = dtype
-    plan.training = training
-    return plan
 
 
 # ======================================================================================
@@ -1714,6 +1736,8 @@ def _group_wgrads(plan, store):
         # as 4 + 1 -- measured no better in the step and 0.15 ms worse at batch 1: r6_ab_tree_group_shape.log)
         tiles = tiles_of(lead)
         sg = max(1, min(s1, -(-max(tiles * s1, 256) // (tiles * len(g)))))
+        # (shorter-lived workgroups -- K splits for 2 / 4 / 8 rounds of 256 -- do not help the chain beside them: 26.74 / 26.85 /
+        # 27.37 ms against 26.77, r6_ab_filler_rounds.log)
         for m in members:
             m.splits = sg
         plan._wg_groups[ctypes.addressof(lead)] = members
