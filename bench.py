@@ -127,9 +127,10 @@ def profile_plan(plan, stream, dump=None, cmds_out=None):
                                      isy=desc.isy, osy=desc.osy, flags=desc.flags, ms=float(t), problems=nprob,
                                      tflops=2.0 * nprob * desc.B * desc.Hg * desc.Wg * desc.Cin * desc.Cout * desc.ntaps / max(float(t), 1e-6) / 1e9))
                 else:
+                    ng = nprob * max(desc.group_n, 1)          # (a grouped launch carries group_n problems of this geometry)
                     rows.append(dict(pass_=which, op="wgrad", Cin=desc.Cin, Cout=desc.Cout, Hg=desc.Ho, Wg=desc.Wo, taps=desc.ntaps,
-                                     isy=desc.isy, ms=float(t), problems=nprob,
-                                     tflops=2.0 * nprob * desc.B * desc.Ho * desc.Wo * desc.Cin * desc.Cout * desc.ntaps / max(float(t), 1e-6) / 1e9))
+                                     isy=desc.isy, ms=float(t), problems=ng,
+                                     tflops=2.0 * ng * desc.B * desc.Ho * desc.Wo * desc.Cin * desc.Cout * desc.ntaps / max(float(t), 1e-6) / 1e9))
         res[which] = agg
     if dump is not None:
         os.makedirs(os.path.dirname(dump), exist_ok=True)
