@@ -189,3 +189,44 @@ def test_dependency_scheduled_streams_equal_serial_execution_bitwise(name, dtype
             assert torch.equal(a, b)
         assert torch.equal(res[0][1], other[1]), "gradients differ between serial and scheduled execution"
         assert torch.equal(res[0][2], other[2]), "running statistics differ"
+
+
+@pytest.mark.parametrize("name", [C3, C5])
+def test_grouped_weight_gradient_plan_equals_the_ungrouped_plan(name, monkeypatch):
+    """Round 6 (dyk/plan.py _group_wgrads): the plan with grouped weight-gradient launches against the plan without them, same
+    weights, same batch, pinned tiles.  Everything but the weight gradients of the grouped layers is bit-identical (grouping moves
+    launches, it does not touch the data gradients, the BatchNorm passes or the heads); a grouped member runs the same kernel with
+    a different number of K splits, i.e. another fp32 summation order: equal to 1e-3 of the tensor's scale."""
+    monkeypatch.setenv("DYK_AUTOTUNE", "0")
+    monkeypatch.setenv("DYK_TUNE_CACHE", "0")
+    batch = _batch(3, B=4)
+    grads, plans = [], []
+    for g in ("0", "16"):
+        monkeypatch.setenv("DYK_WGRAD_GROUP", g)
+        m = _model(name, "bf16")
+        _backward(m, batch)
+        torch.cuda.synchronize()
+        plan = next(p for k, p in m.engine.plans.items() if k[-1])
+        grads.append(m.engine.store.G.clone())
+        plans.append((plan, m))
+    flat, grouped = plans[0][0], plans[1][0]
+    assert not flat._wg_groups and len(grouped._wg_groups) >= 6
+    assert len(grouped.bwd) < len(flat.bwd)
+    g0, g1 = grads
+    assert bool(torch.isfinite(g1).all())
+    st = plans[1][1].engine.store
+    base = st.G.data_ptr()
+    member_ranges = []
+    for lead_addr, ms in grouped._wg_groups.items():
+        for d in ms:
+            lo = (d.dw - base) // 4
+            n = d.ntaps * d.Cout * (d.lddw if d.lddw > 0 else d.Cin)
+            member_ranges.append((lo, lo + n))
+    mask = torch.zeros(st.total, dtype=torch.bool, device=g0.device)
+    for lo, hi in member_ranges:
+        mask[lo:hi] = True
+    assert torch.equal(g0[~mask], g1[~mask]), "grouping changed a gradient outside the grouped layers"
+    for lo, hi in member_ranges:
+        a, b = g0[lo:hi], g1[lo:hi]
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 1e-3 * max(scale, 1e-20), (lo, hi, scale)
