@@ -365,11 +365,7 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
 
     def consume(t):
         tcons[t.tid] = tcons.get(t.tid, 0) + 1
-    cur = None                # current x
-    img = {"x": None, "y": None}
     yolo_rows = []
-    head_idx = 0
-    na_no = []
 
     def defer_to_dw(i, out_layer, out_ref, Bn, Ho, Wo, cout, is_dw, is_direct):
         """OFF by default (DYK_DW_PRE=1 enables it): built for VERDICT r4 #3a, bit-identical (tests), measured SLOWER -- MobileNetV3
@@ -404,239 +400,297 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
         q.ldx = q.ldy = _ru(cout, 8)
         return L.load().dyk_dwconv_tile_ok(ctypes.byref(q)) == 1
 
-    def conv_forward(i, x_in, stem_src, wname, bnpre, bnm, bias_name, k, stride, pad, cout, act, groups=1, out_layer=None,
-                     out_ref=None, entry=True):
-        """emit forward commands of Conv2d [+ BatchNorm2d] [+ activation]; returns (out TRef, info dict).
-        wname / bnpre / bias_name are parameter-store names (bnpre None = no BatchNorm)."""
-        bn = bnpre is not None
-        dw = groups > 1
-        rec = {"kind": "conv", "bn": bn, "k": k, "stride": stride, "pad": pad, "cout": cout, "act": act, "i": i,
-               "stem": stem_src is not None, "wname": wname, "bnpre": bnpre, "bias_name": bias_name, "dw": dw,
-               "entry": entry}                   # entry: the conv reads the section's input (not an intermediate of it)
-        if dw:
-            if stem_src is not None or groups != x_in.C or cout != x_in.C:
-                raise NotImplementedError("grouped convolution that is not depthwise (layer %d)" % i)
-            Hi, Wi = x_in.H, x_in.W
-            Ho, Wo = conv_out_size(Hi, k, stride, pad), conv_out_size(Wi, k, stride, pad)
-            d = L.DykDwDesc()
-            plan._keep.append(d)
-            d.dtype, d.w = code, store.p_ptr(wname)
-            d.B, d.Hi, d.Wi, d.Ho, d.Wo, d.C = B, Hi, Wi, Ho, Wo, cout
-            d.k, d.stride, d.pad = k, stride, pad
-            d.ldx = x_in.ld
-            conv_op = L.OP_DW_FWD
-            pre = getattr(x_in, "pre", None)
-            if pre is not None:
-                # x_in aliases the RAW output of the expansion conv (deferred normalise, below): z is formed on load
-                d.pre_act = pre[1]
-                later(lambda d=d, pre=pre: setattr(d, "pre", ws.ptr(pre[0])))
-        elif (stem_src is not None and k == 3 and pad == 1 and stride in (1, 2) and cout in (16, 32) and bn
-              ):
-            # Cin=3 stem straight from the image batch (csrc/stem.hip): no float conversion pass, no im2col
-            Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
-            Hi, Wi = H, W
-            d = L.DykStemDesc()
-            plan._keep.append(d)
-            d.dtype, d.B, d.H, d.W, d.Cout, d.k, d.stride, d.pad, d.Ho, d.Wo = code, B, H, W, cout, k, stride, pad, Ho, Wo
-            d.wt = cw["stems_t"][wname].data_ptr()
-            plan.dyn_in.append((d, stem_src))
-            conv_op = L.OP_STEM_FWD
-            rec["stem_direct"] = d
-        elif stem_src is not None:
-            # Cin=3 stem, general shape: gather k*k*3 patches (zero padded to 32) and run a 1x1 MFMA conv on them
-            Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
-            patches = new_act(B, Ho, Wo, 32)
-            g = misc()
-            g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.i[5], g.i[6], g.i[7], g.i[8] = B, 3, H, W, k, stride, pad, 32, code
-            g.f[0] = 1.0
-            later(lambda g=g, patches=patches: g.p.__setitem__(1, ptr_of(patches)))
-            plan.dyn_in.append((g, stem_src))
-            plan.fwd.append((L.OP_PATCH_GATHER, g))
-            x_in = patches
-            wfwd_ptr = cw["stems"][wname].data_ptr()
-            taps, cin_k, cisy = [(0, 0, 0)], 32, 1
-            rec["wgrad"] = dict(x=patches, Cin=k * k * 3, lddw=k * k * 3, taps=[(0, 0, 0)], isy=1, Hi=Ho, Wi=Wo)
-            Hi, Wi = Ho, Wo
+    import functools
+    import types
+    conv_forward = functools.partial(_emit_conv_forward, types.SimpleNamespace(
+        B=B, H=H, W=W, alloc_out=alloc_out, code=code, consume=consume, cw=cw, defer_to_dw=defer_to_dw, defs=defs, es=es,
+        ew_desc=ew_desc, joint_raw=joint_raw, joint_slot=joint_slot, joint_vecs=joint_vecs, later=later, misc=misc,
+        new_act=new_act, new_ws=new_ws, plan=plan, producer_of=producer_of, ptr_of=ptr_of, st_arena=st_arena, store=store,
+        tight=tight, training=training, ws=ws))
+
+    # ---------------------------------------------------------------- forward: _emit_forward below
+    stats_memset, fwd_start = _emit_forward(types.SimpleNamespace(
+        B=B, alloc_out=alloc_out, concat_slot=concat_slot, consume=consume, conv_forward=conv_forward, defs=defs,
+        device=device, es=es, ew_desc=ew_desc, info=info, joint_of=joint_of, joint_raw=joint_raw, joint_vecs=joint_vecs,
+        later=later, misc=misc, model=model, mods=mods, new_act=new_act, new_ws=new_ws, outs=outs, plan=plan, ptr_of=ptr_of,
+        route_buf=route_buf, second=second, store=store, training=training, v4=v4, ws=ws, yolo_rows=yolo_rows))
+
+    # ---------------------------------------------------------------- backward (training plans): _emit_backward below
+    grads = {}
+    if training:
+        grads = _emit_backward(types.SimpleNamespace(
+            B=B, code=code, concat_slot=concat_slot, cw=cw, defs=defs, es=es, ew_desc=ew_desc, grad_arena=grad_arena,
+            info=info, joint_of=joint_of, kpad_bytes=kpad_bytes, later=later, misc=misc, mods=mods, new_ws=new_ws, nrefs=nrefs,
+            plan=plan, producer_of=producer_of, ptr_of=ptr_of, store=store, tcons=tcons, tight=tight, ws=ws))
+
+    # ---------------------------------------------------------------- the rest is a pipeline of passes over the two lists
+    # allocate + emit (above)  ->  materialise  ->  fuse  ->  tune  ->  group  ->  scratch  ->  schedule metadata
+    _materialise(plan, device, pending, stats_memset if training else None, st_arena)
+    plan.training = training
+    plan.store = store
+    _post_passes(plan, store, device, dry, training, stats_memset, _backbone_force_layers(defs, mods, second))
+    _assign_lanes(plan, defs, mods, second, fwd_start, training)
+    _layer_maps(plan, model, defs, mods, second, fwd_start, training)
+    plan.finalize()
+    plan.info = info
+    plan.grads = grads if training else {}
+    plan.outs = outs
+    plan.shape = (B, H, W)
+    plan.dtype = dtype
+    plan.training = training
+    return plan
+
+
+# ======================================================================================
+# The two emission stages of compile_plan
+def _emit_conv_forward(cx, i, x_in, stem_src, wname, bnpre, bnm, bias_name, k, stride, pad, cout, act, groups=1, out_layer=None,
+                       out_ref=None, entry=True):
+    """emit forward commands of Conv2d [+ BatchNorm2d] [+ activation]; returns (out TRef, info dict).
+    wname / bnpre / bias_name are parameter-store names (bnpre None = no BatchNorm)."""
+    (B, H, W, alloc_out, code, consume, cw, defer_to_dw, defs, es, ew_desc, joint_raw, joint_slot, joint_vecs, later, misc,
+    new_act, new_ws, plan, producer_of, ptr_of, st_arena, store, tight, training, ws) = (cx.B, cx.H, cx.W, cx.alloc_out, cx.code,
+    cx.consume, cx.cw, cx.defer_to_dw, cx.defs, cx.es, cx.ew_desc, cx.joint_raw, cx.joint_slot, cx.joint_vecs, cx.later, cx.misc,
+    cx.new_act, cx.new_ws, cx.plan, cx.producer_of, cx.ptr_of, cx.st_arena, cx.store, cx.tight, cx.training, cx.ws)
+    bn = bnpre is not None
+    dw = groups > 1
+    rec = {"kind": "conv", "bn": bn, "k": k, "stride": stride, "pad": pad, "cout": cout, "act": act, "i": i,
+           "stem": stem_src is not None, "wname": wname, "bnpre": bnpre, "bias_name": bias_name, "dw": dw,
+           "entry": entry}                   # entry: the conv reads the section's input (not an intermediate of it)
+    if dw:
+        if stem_src is not None or groups != x_in.C or cout != x_in.C:
+            raise NotImplementedError("grouped convolution that is not depthwise (layer %d)" % i)
+        Hi, Wi = x_in.H, x_in.W
+        Ho, Wo = conv_out_size(Hi, k, stride, pad), conv_out_size(Wi, k, stride, pad)
+        d = L.DykDwDesc()
+        plan._keep.append(d)
+        d.dtype, d.w = code, store.p_ptr(wname)
+        d.B, d.Hi, d.Wi, d.Ho, d.Wo, d.C = B, Hi, Wi, Ho, Wo, cout
+        d.k, d.stride, d.pad = k, stride, pad
+        d.ldx = x_in.ld
+        conv_op = L.OP_DW_FWD
+        pre = getattr(x_in, "pre", None)
+        if pre is not None:
+            # x_in aliases the RAW output of the expansion conv (deferred normalise, below): z is formed on load
+            d.pre_act = pre[1]
+            later(lambda d=d, pre=pre: setattr(d, "pre", ws.ptr(pre[0])))
+    elif (stem_src is not None and k == 3 and pad == 1 and stride in (1, 2) and cout in (16, 32) and bn
+          ):
+        # Cin=3 stem straight from the image batch (csrc/stem.hip): no float conversion pass, no im2col
+        Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+        Hi, Wi = H, W
+        d = L.DykStemDesc()
+        plan._keep.append(d)
+        d.dtype, d.B, d.H, d.W, d.Cout, d.k, d.stride, d.pad, d.Ho, d.Wo = code, B, H, W, cout, k, stride, pad, Ho, Wo
+        d.wt = cw["stems_t"][wname].data_ptr()
+        plan.dyn_in.append((d, stem_src))
+        conv_op = L.OP_STEM_FWD
+        rec["stem_direct"] = d
+    elif stem_src is not None:
+        # Cin=3 stem, general shape: gather k*k*3 patches (zero padded to 32) and run a 1x1 MFMA conv on them
+        Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+        patches = new_act(B, Ho, Wo, 32)
+        g = misc()
+        g.i[0], g.i[1], g.i[2], g.i[3], g.i[4], g.i[5], g.i[6], g.i[7], g.i[8] = B, 3, H, W, k, stride, pad, 32, code
+        g.f[0] = 1.0
+        later(lambda g=g, patches=patches: g.p.__setitem__(1, ptr_of(patches)))
+        plan.dyn_in.append((g, stem_src))
+        plan.fwd.append((L.OP_PATCH_GATHER, g))
+        x_in = patches
+        wfwd_ptr = cw["stems"][wname].data_ptr()
+        taps, cin_k, cisy = [(0, 0, 0)], 32, 1
+        rec["wgrad"] = dict(x=patches, Cin=k * k * 3, lddw=k * k * 3, taps=[(0, 0, 0)], isy=1, Hi=Ho, Wi=Wo)
+        Hi, Wi = Ho, Wo
+    else:
+        Hi, Wi = x_in.H, x_in.W
+        Ho, Wo = conv_out_size(Hi, k, stride, pad), conv_out_size(Wi, k, stride, pad)
+        e = store.by_name[wname]
+        cin_k = _ru(x_in.C, 32)
+        if x_in.ld < cin_k and not tight:
+            raise NotImplementedError("conv input rows narrower than the padded K (layer %d)" % i)
+        if cin_k != x_in.C:
+            wfwd_ptr = cw["Wc_pad"].data_ptr() + cw["fwd_pad_off"][wname] * es
         else:
-            Hi, Wi = x_in.H, x_in.W
-            Ho, Wo = conv_out_size(Hi, k, stride, pad), conv_out_size(Wi, k, stride, pad)
-            e = store.by_name[wname]
-            cin_k = _ru(x_in.C, 32)
-            if x_in.ld < cin_k and not tight:
-                raise NotImplementedError("conv input rows narrower than the padded K (layer %d)" % i)
-            if cin_k != x_in.C:
-                wfwd_ptr = cw["Wc_pad"].data_ptr() + cw["fwd_pad_off"][wname] * es
+            wfwd_ptr = cw["Wc"].data_ptr() + e.offset * es
+        taps, cisy = fwd_taps(k, pad), stride
+        rec["wgrad"] = dict(x=x_in, Cin=x_in.C, lddw=0, taps=taps, isy=stride, Hi=Hi, Wi=Wi)
+    rec["x"] = x_in
+    if stem_src is None:
+        consume(x_in)
+    direct = "stem_direct" in rec
+    if not dw and not direct:
+        d = L.DykConvDesc()
+        plan._keep.append(d)
+        d.dtype = code
+        d.w = wfwd_ptr
+        d.B, d.Hi, d.Wi, d.Cin, d.Cout = B, Hi, Wi, cin_k, cout
+        d.Hg, d.Wg, d.Ho, d.Wo = Ho, Wo, Ho, Wo
+        d.isy = d.isx = cisy
+        d.osy = d.osx = 1
+        d.ntaps = len(taps)
+        for q, (ty, tx, wt) in enumerate(taps):
+            d.tdy[q], d.tdx[q], d.twt[q] = ty, tx, wt
+        d.ldx = x_in.ld
+        conv_op = L.OP_CONV
+    if bn:
+        if training:
+            js = joint_slot.get(out_layer) if (not dw and not direct and stem_src is None and out_ref is None) else None
+            if js is not None:
+                jj, jc0, jctot = js
+                if jj not in joint_raw:
+                    joint_raw[jj] = new_act(B, Ho, Wo, jctot)
+                    joint_vecs[jj] = new_ws(4 * jctot * 4)
+                assert (joint_raw[jj].H, joint_raw[jj].W) == (Ho, Wo)
+                y_raw = joint_raw[jj].chan_slice(jc0, cout)
+                rec["joint"] = jj
             else:
-                wfwd_ptr = cw["Wc"].data_ptr() + e.offset * es
-            taps, cisy = fwd_taps(k, pad), stride
-            rec["wgrad"] = dict(x=x_in, Cin=x_in.C, lddw=0, taps=taps, isy=stride, Hi=Hi, Wi=Wi)
-        rec["x"] = x_in
-        if stem_src is None:
-            consume(x_in)
-        direct = "stem_direct" in rec
-        if not dw and not direct:
-            d = L.DykConvDesc()
-            plan._keep.append(d)
-            d.dtype = code
-            d.w = wfwd_ptr
-            d.B, d.Hi, d.Wi, d.Cin, d.Cout = B, Hi, Wi, cin_k, cout
-            d.Hg, d.Wg, d.Ho, d.Wo = Ho, Wo, Ho, Wo
-            d.isy = d.isx = cisy
-            d.osy = d.osx = 1
-            d.ntaps = len(taps)
-            for q, (ty, tx, wt) in enumerate(taps):
-                d.tdy[q], d.tdx[q], d.twt[q] = ty, tx, wt
-            d.ldx = x_in.ld
-            conv_op = L.OP_CONV
-        if bn:
-            if training:
-                js = joint_slot.get(out_layer) if (not dw and not direct and stem_src is None and out_ref is None) else None
-                if js is not None:
-                    jj, jc0, jctot = js
-                    if jj not in joint_raw:
-                        joint_raw[jj] = new_act(B, Ho, Wo, jctot)
-                        joint_vecs[jj] = new_ws(4 * jctot * 4)
-                    assert (joint_raw[jj].H, joint_raw[jj].W) == (Ho, Wo)
-                    y_raw = joint_raw[jj].chan_slice(jc0, cout)
-                    rec["joint"] = jj
-                else:
-                    y_raw = new_act(B, Ho, Wo, cout)
-                z = None if defer_to_dw(i, out_layer, out_ref, B, Ho, Wo, cout, dw, direct) else (
-                    out_ref if out_ref is not None else alloc_out(out_layer, B, Ho, Wo, cout))
-                # replicas of the fp64 statistics accumulators: keep the atomics per address at a few dozen
-                tiles = (B * Ho * Wo + 127) // 128
-                # (about 32 workgroups per replica), few enough that the consumer folds them cheaply
-                slots = min(FWD_SLOTS_CAP, max(4, 1 << max(0, (tiles * max(1, (cout + 127) // 128) // FWD_SLOT_WG - 1).bit_length())))
-                if dw:
-                    slots = DW_SLOTS                 # 32 replicas: the finalize then rides on the normalise pass (measured
-                                                     # -0.3 ms per MobileNetV3 step against up to 256 replicas + own launch)
-                stats = st_arena.alloc(slots * 2 * cout * 8)   # fp64 replicas; the whole arena is zeroed at the start of a pass
-                if js is not None:                   # this layer's columns of the route's scale | shift | mean | rstd rows
-                    vecs, vs = joint_vecs[jj] + 4 * jc0, 4 * jctot
-                else:
-                    vecs, vs = new_ws(4 * cout * 4), 4 * cout      # scale | shift | mean | rstd, `vs` bytes apart
-                rec["vs"] = vs
-                d.ldy, d.stats_slots = y_raw.ld, slots
-                if not dw and not direct:
-                    d.act, d.flags = 0, L.EPI_STATS
-                # conv + BatchNorm + activation in ONE launch (DYK_EPI_BNFWD) where every workgroup of the conv can be resident at
-                # once: the 32 x 40 and 16 x 20 stages (<= dyk_conv_bnfwd_max_grid() workgroups on the 160-pixel tile).  Saves the
-                # normalise launch (6-10 us + its 5-7 us gap where one stream runs alone) and the re-read of the raw output.
-                fuse_bn = (not dw and not direct and code == L.DYK_BF16 and cout % 8 == 0 and _bnfwd_on()
-                           and ((B * Ho * Wo + 159) // 160) * ((cout + 127) // 128) <= BNFWD_MAX_GRID)
-                if fuse_bn:
-                    cnt = new_ws(16)                     # arrivals | error | departures | - : zero at plan creation, re-armed by the
-                                                         # launch itself; NOT in the statistics arena (zeroed every pass), so that an
-                                                         # error word survives until Plan.bnfwd_error() has looked at it
-                    plan.bnfwd_counters.append(cnt)
-                    d.act, d.flags = act, L.EPI_STATS | L.EPI_BNFWD
-                    d.bn_gamma, d.bn_beta = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
-                    d.bn_running_mean, d.bn_running_var = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
-                    d.bn_count, d.bn_momentum, d.bn_eps = B * Ho * Wo, BN_MOMENTUM, BN_EPS
-                    d.ldy2 = z.ld
-                    later(lambda d=d, z=z, vecs=vecs, cnt=cnt: (
-                        setattr(d, "y2", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)), setattr(d, "shift", ws.ptr(vecs + vs)),
-                        setattr(d, "bn_save_mean", ws.ptr(vecs + 2 * vs)), setattr(d, "bn_save_rstd", ws.ptr(vecs + 3 * vs)),
-                        setattr(d, "bn_counter", ws.ptr(cnt))))
-                    plan.has_bnfwd = True
-                if direct:
-                    later(lambda d=d, y_raw=y_raw, stats=stats: (
-                        setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", st_arena.ptr(stats))))
-                else:
-                    later(lambda d=d, x_in=x_in, y_raw=y_raw, stats=stats: (
-                        setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", st_arena.ptr(stats))))
-                plan.fwd.append((conv_op, d))
-                if fuse_bn:
-                    rec.update(y_raw=y_raw, z=z, vecs=vecs, conv_desc=d)      # (conv_desc: a plain [shortcut] behind it rides on the epilogue)
-                    producer_of[z.tid] = rec
-                    return z, rec
-                f = L.DykBnFinalizeDesc()
-                plan._keep.append(f)
-                f.gamma, f.beta = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
-                f.running_mean, f.running_var = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
-                f.C, f.count, f.momentum, f.eps, f.slots = cout, B * Ho * Wo, BN_MOMENTUM, BN_EPS, slots
-                later(lambda f=f, stats=stats, vecs=vecs, vs=vs: (
-                    setattr(f, "stats", st_arena.ptr(stats)), setattr(f, "scale", ws.ptr(vecs)),
-                    setattr(f, "shift", ws.ptr(vecs + vs)), setattr(f, "save_mean", ws.ptr(vecs + 2 * vs)),
-                    setattr(f, "save_rstd", ws.ptr(vecs + 3 * vs))))
-                if defer_to_dw(i, out_layer, out_ref, B, Ho, Wo, cout, dw, direct):
-                    # Normalise + activation ON LOAD in the consumer (VERDICT r4 #3a): this block's only reader is a stride-1
-                    # depthwise conv on the LDS-tiled kernel (MobileNet expansion conv -> depthwise, reference models.py:34-62
-                    # then :41 groups=C): its forward and its weight gradient form z = dtype(act(scale * u + shift)) from the
-                    # raw output while staging (DykDwDesc.pre) -- the same values this pass would have stored -- so z is never
-                    # written or read back: two tensor passes over the LARGEST tensors of the net less, per block.  Only
-                    # the finalize launch remains.  The output TRef aliases the raw tensor and carries the vectors.
-                    plan.fwd.append((L.OP_BN_FINALIZE, f))
-                    z = TRef(y_raw.arena, y_raw.off, y_raw.B, y_raw.H, y_raw.W, y_raw.C, y_raw.ld, y_raw.esize)
-                    z.pre = (vecs, act)
-                    rec.update(y_raw=y_raw, z=z, vecs=vecs, deferred=True)
-                    producer_of[z.tid] = rec
-                    return z, rec
-                a = ew_desc(a=y_raw, out=z, act=act)
-                later(lambda a=a, vecs=vecs, vs=vs: (setattr(a, "p0", ws.ptr(vecs)), setattr(a, "p1", ws.ptr(vecs + vs))))
-                if slots <= 32:
-                    fm = misc()                       # finalize folded into the normalise + activation launch
-                    fm.p[0], fm.p[1] = ctypes.addressof(f), ctypes.addressof(a)
-                    plan.fwd.append((L.OP_BN_FWD_FUSED, fm))
-                else:
-                    plan.fwd.append((L.OP_BN_FINALIZE, f))
-                    plan.fwd.append((L.OP_BN_ACT_FWD, a))
-                rec.update(y_raw=y_raw, z=z, vecs=vecs, bn_act_desc=a)
+                y_raw = new_act(B, Ho, Wo, cout)
+            z = None if defer_to_dw(i, out_layer, out_ref, B, Ho, Wo, cout, dw, direct) else (
+                out_ref if out_ref is not None else alloc_out(out_layer, B, Ho, Wo, cout))
+            # replicas of the fp64 statistics accumulators: keep the atomics per address at a few dozen
+            tiles = (B * Ho * Wo + 127) // 128
+            # (about 32 workgroups per replica), few enough that the consumer folds them cheaply
+            slots = min(FWD_SLOTS_CAP, max(4, 1 << max(0, (tiles * max(1, (cout + 127) // 128) // FWD_SLOT_WG - 1).bit_length())))
+            if dw:
+                slots = DW_SLOTS                 # 32 replicas: the finalize then rides on the normalise pass (measured
+                                                 # -0.3 ms per MobileNetV3 step against up to 256 replicas + own launch)
+            stats = st_arena.alloc(slots * 2 * cout * 8)   # fp64 replicas; the whole arena is zeroed at the start of a pass
+            if js is not None:                   # this layer's columns of the route's scale | shift | mean | rstd rows
+                vecs, vs = joint_vecs[jj] + 4 * jc0, 4 * jctot
+            else:
+                vecs, vs = new_ws(4 * cout * 4), 4 * cout      # scale | shift | mean | rstd, `vs` bytes apart
+            rec["vs"] = vs
+            d.ldy, d.stats_slots = y_raw.ld, slots
+            if not dw and not direct:
+                d.act, d.flags = 0, L.EPI_STATS
+            # conv + BatchNorm + activation in ONE launch (DYK_EPI_BNFWD) where every workgroup of the conv can be resident at
+            # once: the 32 x 40 and 16 x 20 stages (<= dyk_conv_bnfwd_max_grid() workgroups on the 160-pixel tile).  Saves the
+            # normalise launch (6-10 us + its 5-7 us gap where one stream runs alone) and the re-read of the raw output.
+            fuse_bn = (not dw and not direct and code == L.DYK_BF16 and cout % 8 == 0 and _bnfwd_on()
+                       and ((B * Ho * Wo + 159) // 160) * ((cout + 127) // 128) <= BNFWD_MAX_GRID)
+            if fuse_bn:
+                cnt = new_ws(16)                     # arrivals | error | departures | - : zero at plan creation, re-armed by the
+                                                     # launch itself; NOT in the statistics arena (zeroed every pass), so that an
+                                                     # error word survives until Plan.bnfwd_error() has looked at it
+                plan.bnfwd_counters.append(cnt)
+                d.act, d.flags = act, L.EPI_STATS | L.EPI_BNFWD
+                d.bn_gamma, d.bn_beta = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
+                d.bn_running_mean, d.bn_running_var = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
+                d.bn_count, d.bn_momentum, d.bn_eps = B * Ho * Wo, BN_MOMENTUM, BN_EPS
+                d.ldy2 = z.ld
+                later(lambda d=d, z=z, vecs=vecs, cnt=cnt: (
+                    setattr(d, "y2", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)), setattr(d, "shift", ws.ptr(vecs + vs)),
+                    setattr(d, "bn_save_mean", ws.ptr(vecs + 2 * vs)), setattr(d, "bn_save_rstd", ws.ptr(vecs + 3 * vs)),
+                    setattr(d, "bn_counter", ws.ptr(cnt))))
+                plan.has_bnfwd = True
+            if direct:
+                later(lambda d=d, y_raw=y_raw, stats=stats: (
+                    setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", st_arena.ptr(stats))))
+            else:
+                later(lambda d=d, x_in=x_in, y_raw=y_raw, stats=stats: (
+                    setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(y_raw)), setattr(d, "stats", st_arena.ptr(stats))))
+            plan.fwd.append((conv_op, d))
+            if fuse_bn:
+                rec.update(y_raw=y_raw, z=z, vecs=vecs, conv_desc=d)      # (conv_desc: a plain [shortcut] behind it rides on the epilogue)
                 producer_of[z.tid] = rec
                 return z, rec
-            # eval: running statistics folded into an affine (conv epilogue for the MFMA conv, one more
-            # streaming pass for the depthwise conv)
-            z = out_ref if out_ref is not None else alloc_out(out_layer, B, Ho, Wo, cout)
-            vecs = new_ws(2 * cout * 4)
-            fo = misc()
-            fo.p[0], fo.p[1] = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
-            fo.p[2], fo.p[3] = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
-            fo.i[0], fo.f[0] = cout, BN_EPS
-            later(lambda fo=fo, vecs=vecs: (fo.p.__setitem__(4, ws.ptr(vecs)), fo.p.__setitem__(5, ws.ptr(vecs + 4 * cout))))
-            plan.fwd.append((L.OP_BN_FOLD, fo))
-            if dw:
-                d.ldy = z.ld
-                later(lambda d=d, x_in=x_in, z=z: (setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(z))))
-                plan.fwd.append((conv_op, d))
-                a = ew_desc(a=z, out=z, act=act)
-                later(lambda a=a, vecs=vecs: (setattr(a, "p0", ws.ptr(vecs)), setattr(a, "p1", ws.ptr(vecs + 4 * cout))))
+            f = L.DykBnFinalizeDesc()
+            plan._keep.append(f)
+            f.gamma, f.beta = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
+            f.running_mean, f.running_var = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
+            f.C, f.count, f.momentum, f.eps, f.slots = cout, B * Ho * Wo, BN_MOMENTUM, BN_EPS, slots
+            later(lambda f=f, stats=stats, vecs=vecs, vs=vs: (
+                setattr(f, "stats", st_arena.ptr(stats)), setattr(f, "scale", ws.ptr(vecs)),
+                setattr(f, "shift", ws.ptr(vecs + vs)), setattr(f, "save_mean", ws.ptr(vecs + 2 * vs)),
+                setattr(f, "save_rstd", ws.ptr(vecs + 3 * vs))))
+            if defer_to_dw(i, out_layer, out_ref, B, Ho, Wo, cout, dw, direct):
+                # Normalise + activation ON LOAD in the consumer (VERDICT r4 #3a): this block's only reader is a stride-1
+                # depthwise conv on the LDS-tiled kernel (MobileNet expansion conv -> depthwise, reference models.py:34-62
+                # then :41 groups=C): its forward and its weight gradient form z = dtype(act(scale * u + shift)) from the
+                # raw output while staging (DykDwDesc.pre) -- the same values this pass would have stored -- so z is never
+                # written or read back: two tensor passes over the LARGEST tensors of the net less, per block.  Only
+                # the finalize launch remains.  The output TRef aliases the raw tensor and carries the vectors.
+                plan.fwd.append((L.OP_BN_FINALIZE, f))
+                z = TRef(y_raw.arena, y_raw.off, y_raw.B, y_raw.H, y_raw.W, y_raw.C, y_raw.ld, y_raw.esize)
+                z.pre = (vecs, act)
+                rec.update(y_raw=y_raw, z=z, vecs=vecs, deferred=True)
+                producer_of[z.tid] = rec
+                return z, rec
+            a = ew_desc(a=y_raw, out=z, act=act)
+            later(lambda a=a, vecs=vecs, vs=vs: (setattr(a, "p0", ws.ptr(vecs)), setattr(a, "p1", ws.ptr(vecs + vs))))
+            if slots <= 32:
+                fm = misc()                       # finalize folded into the normalise + activation launch
+                fm.p[0], fm.p[1] = ctypes.addressof(f), ctypes.addressof(a)
+                plan.fwd.append((L.OP_BN_FWD_FUSED, fm))
+            else:
+                plan.fwd.append((L.OP_BN_FINALIZE, f))
                 plan.fwd.append((L.OP_BN_ACT_FWD, a))
-                rec.update(z=z)
-                return z, rec
-            if direct:
-                d.ldy, d.act = z.ld, act
-                later(lambda d=d, z=z, vecs=vecs: (
-                    setattr(d, "y", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)), setattr(d, "shift", ws.ptr(vecs + 4 * cout))))
-                plan.fwd.append((L.OP_STEM_FWD, d))
-                rec.update(z=z)
-                return z, rec
-            d.ldy, d.act, d.flags = z.ld, act, L.EPI_AFFINE
-            later(lambda d=d, x_in=x_in, z=z, vecs=vecs: (
-                setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)),
-                setattr(d, "shift", ws.ptr(vecs + 4 * cout))))
-            plan.fwd.append((L.OP_CONV, d))
-            rec.update(z=z, conv_desc=d)
+            rec.update(y_raw=y_raw, z=z, vecs=vecs, bn_act_desc=a)
+            producer_of[z.tid] = rec
             return z, rec
+        # eval: running statistics folded into an affine (conv epilogue for the MFMA conv, one more
+        # streaming pass for the depthwise conv)
+        z = out_ref if out_ref is not None else alloc_out(out_layer, B, Ho, Wo, cout)
+        vecs = new_ws(2 * cout * 4)
+        fo = misc()
+        fo.p[0], fo.p[1] = store.p_ptr(bnpre + "weight"), store.p_ptr(bnpre + "bias")
+        fo.p[2], fo.p[3] = store.r_ptr(bnm, "running_mean"), store.r_ptr(bnm, "running_var")
+        fo.i[0], fo.f[0] = cout, BN_EPS
+        later(lambda fo=fo, vecs=vecs: (fo.p.__setitem__(4, ws.ptr(vecs)), fo.p.__setitem__(5, ws.ptr(vecs + 4 * cout))))
+        plan.fwd.append((L.OP_BN_FOLD, fo))
         if dw:
-            raise NotImplementedError("depthwise conv without batch_normalize (layer %d)" % i)
-        # no BN: bias epilogue; detection heads go to fp32 rows of HEAD_LD channels
-        is_head = (i + 1 < len(defs) and defs[i + 1]["type"] == "yolo")
-        if is_head:
-            assert cout <= HEAD_LD
-            z = new_act(B, Ho, Wo, cout, ld=HEAD_LD, esize=4)
-            d.flags = L.EPI_AFFINE | L.EPI_OUT_F32
-        else:
-            z = alloc_out(out_layer, B, Ho, Wo, cout)
-            d.flags = L.EPI_AFFINE
-        d.ldy, d.act = z.ld, act
-        d.shift = store.p_ptr(bias_name)
-        later(lambda d=d, x_in=x_in, z=z: (setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(z))))
+            d.ldy = z.ld
+            later(lambda d=d, x_in=x_in, z=z: (setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(z))))
+            plan.fwd.append((conv_op, d))
+            a = ew_desc(a=z, out=z, act=act)
+            later(lambda a=a, vecs=vecs: (setattr(a, "p0", ws.ptr(vecs)), setattr(a, "p1", ws.ptr(vecs + 4 * cout))))
+            plan.fwd.append((L.OP_BN_ACT_FWD, a))
+            rec.update(z=z)
+            return z, rec
+        if direct:
+            d.ldy, d.act = z.ld, act
+            later(lambda d=d, z=z, vecs=vecs: (
+                setattr(d, "y", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)), setattr(d, "shift", ws.ptr(vecs + 4 * cout))))
+            plan.fwd.append((L.OP_STEM_FWD, d))
+            rec.update(z=z)
+            return z, rec
+        d.ldy, d.act, d.flags = z.ld, act, L.EPI_AFFINE
+        later(lambda d=d, x_in=x_in, z=z, vecs=vecs: (
+            setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(z)), setattr(d, "scale", ws.ptr(vecs)),
+            setattr(d, "shift", ws.ptr(vecs + 4 * cout))))
         plan.fwd.append((L.OP_CONV, d))
-        rec.update(z=z, is_head=is_head)
-        if act != 0:
-            raise NotImplementedError("activation on a conv without batch_normalize (layer %d)" % i)
+        rec.update(z=z, conv_desc=d)
         return z, rec
+    if dw:
+        raise NotImplementedError("depthwise conv without batch_normalize (layer %d)" % i)
+    # no BN: bias epilogue; detection heads go to fp32 rows of HEAD_LD channels
+    is_head = (i + 1 < len(defs) and defs[i + 1]["type"] == "yolo")
+    if is_head:
+        assert cout <= HEAD_LD
+        z = new_act(B, Ho, Wo, cout, ld=HEAD_LD, esize=4)
+        d.flags = L.EPI_AFFINE | L.EPI_OUT_F32
+    else:
+        z = alloc_out(out_layer, B, Ho, Wo, cout)
+        d.flags = L.EPI_AFFINE
+    d.ldy, d.act = z.ld, act
+    d.shift = store.p_ptr(bias_name)
+    later(lambda d=d, x_in=x_in, z=z: (setattr(d, "x", ptr_of(x_in)), setattr(d, "y", ptr_of(z))))
+    plan.fwd.append((L.OP_CONV, d))
+    rec.update(z=z, is_head=is_head)
+    if act != 0:
+        raise NotImplementedError("activation on a conv without batch_normalize (layer %d)" % i)
+    return z, rec
 
+def _emit_forward(cx):
+    """The forward command list (compile_plan's first stage): the interpreter loop of reference models.py:291-305 unrolled once,
+    section by section, into resolved descriptors; leaves per section what the backward emission needs (`info`) and the output
+    tensor (`outs`).  Returns the statistics memset descriptor and the index of the first forward command of every section."""
+    (B, alloc_out, concat_slot, consume, conv_forward, defs, device, es, ew_desc, info, joint_of, joint_raw, joint_vecs, later,
+    misc, model, mods, new_act, new_ws, outs, plan, ptr_of, route_buf, second, store, training, v4, ws, yolo_rows) = (cx.B,
+    cx.alloc_out, cx.concat_slot, cx.consume, cx.conv_forward, cx.defs, cx.device, cx.es, cx.ew_desc, cx.info, cx.joint_of,
+    cx.joint_raw, cx.joint_vecs, cx.later, cx.misc, cx.model, cx.mods, cx.new_act, cx.new_ws, cx.outs, cx.plan, cx.ptr_of,
+    cx.route_buf, cx.second, cx.store, cx.training, cx.v4, cx.ws, cx.yolo_rows)
+    cur = None                # current x
+    head_idx = 0
     stats_memset = misc()
     if training:
         plan.fwd.append((L.OP_MEMSET, stats_memset))       # re-arm every BatchNorm statistics replica of the pass
@@ -900,526 +954,517 @@ def compile_plan(model, store, B, H, W, dtype, training, device, dry=False):
                 dd.anchor_vec[q] = v
             plan.fwd.append((L.OP_YOLO_DECODE, dd))
             r0 += rec["na"] * rec["ny"] * rec["nx"]
+    return stats_memset, fwd_start
 
-    # ---------------------------------------------------------------- backward
-    if training:
-        # parameters frozen with requires_grad_(False) (reference train.py:77-82): no weight gradient for them, and no
-        # backward at all for the sections below the first one that owns a trainable parameter
-        frozen = {e.name for e in store.entries if not e.param.requires_grad}
-        first_trainable = min((e.layer for e in store.entries if e.param.requires_grad), default=len(defs))
-        grads = {}           # tid -> TRef in the grad arena
-        ginit = set()        # tids whose gradient buffer holds a value already
-        red_offs = []        # (offset, bytes) fp64 reduction scratch zeroed at the start of backward
+def _emit_backward(cx):
+    """The backward command list of a training plan (compile_plan's second stage): generated statically from the records the
+    forward emission left per section (`info`), store-vs-accumulate resolved here, no autograd graph.  `cx` carries the
+    emission context: the helpers that allocate tensors / descriptors and defer pointer assignments, the arenas, the cfg."""
+    (B, code, concat_slot, cw, defs, es, ew_desc, grad_arena, info, joint_of, kpad_bytes, later, misc, mods, new_ws, nrefs, plan,
+    producer_of, ptr_of, store, tcons, tight, ws) = (cx.B, cx.code, cx.concat_slot, cx.cw, cx.defs, cx.es, cx.ew_desc,
+    cx.grad_arena, cx.info, cx.joint_of, cx.kpad_bytes, cx.later, cx.misc, cx.mods, cx.new_ws, cx.nrefs, cx.plan, cx.producer_of,
+    cx.ptr_of, cx.store, cx.tcons, cx.tight, cx.ws)
+    # parameters frozen with requires_grad_(False) (reference train.py:77-82): no weight gradient for them, and no
+    # backward at all for the sections below the first one that owns a trainable parameter
+    frozen = {e.name for e in store.entries if not e.param.requires_grad}
+    first_trainable = min((e.layer for e in store.entries if e.param.requires_grad), default=len(defs))
+    grads = {}           # tid -> TRef in the grad arena
+    ginit = set()        # tids whose gradient buffer holds a value already
+    red_offs = []        # (offset, bytes) fp64 reduction scratch zeroed at the start of backward
 
-        def gref(t, ld=None, C=None):
-            if t.tid not in grads:
-                ldn = ld or t.ld
-                Cn = C or t.C
-                g = TRef("grad", grad_arena.alloc(t.npix * ldn * es, pad=kpad_bytes(ldn, es)), t.B, t.H, t.W, Cn, ldn, es, tid=t.tid)
-                grads[t.tid] = g
-            return grads[t.tid]
+    def gref(t, ld=None, C=None):
+        if t.tid not in grads:
+            ldn = ld or t.ld
+            Cn = C or t.C
+            g = TRef("grad", grad_arena.alloc(t.npix * ldn * es, pad=kpad_bytes(ldn, es)), t.B, t.H, t.W, Cn, ldn, es, tid=t.tid)
+            grads[t.tid] = g
+        return grads[t.tid]
 
-        def acc_flag(t):
-            """store on first write, accumulate afterwards"""
-            if t.tid in ginit:
-                return L.EW_ACCUM
-            ginit.add(t.tid)
-            return 0
+    def acc_flag(t):
+        """store on first write, accumulate afterwards"""
+        if t.tid in ginit:
+            return L.EW_ACCUM
+        ginit.add(t.tid)
+        return 0
 
-        def new_red(nbytes):
-            off = new_ws(nbytes)
-            red_offs.append((off, nbytes))
-            return off
+    def new_red(nbytes):
+        off = new_ws(nbytes)
+        red_offs.append((off, nbytes))
+        return off
 
-        pending_add = {}     # tid of a skip tensor -> gradient that reaches it over a fused plain [shortcut], not yet added
+    pending_add = {}     # tid of a skip tensor -> gradient that reaches it over a fused plain [shortcut], not yet added
 
-        def chain_consumer(a, before):
-            """the conv whose data gradient can take the [shortcut] gradient of `a` as an addend and reduce the
-            BatchNorm backward of a's producer in its epilogue (DYK_EPI_BNBWD | DYK_EPI_ADDEND): `a` is read by that
-            conv and the [shortcut] only, the conv comes earlier than layer `before` and covers a in one launch"""
-            if os.environ.get("DYK_BNBWD_FUSE", "1") == "0" or os.environ.get("DYK_DEBUG_PLAN"):
-                return None
-            prod = producer_of.get(a.tid)
-            if prod is None or not prod.get("bn"):
-                return None
-            # readers: the conv, this [shortcut] and, when a is itself the output of a fused [shortcut], that section
-            if tcons.get(a.tid, 0) != (3 if prod.get("fused_shortcut") else 2) or a.tid in ginit or a.tid in grads \
-                    or a.C % (16 // es):
-                return None
-            readers = [r for r in info[:before] if r.get("kind") == "conv" and r.get("x") is not None
-                       and r["x"].tid == a.tid]
-            if len(readers) != 1:
-                return None
-            r = readers[0]
-            if r is prod or r.get("dw") or r.get("stem") or r["stride"] != 1 or r["i"] <= prod["i"]:
-                return None
-            if len(dgrad_classes(r["k"], r["pad"], 1, a.H, a.W)) != 1:
-                return None
-            return r
+    def chain_consumer(a, before):
+        """the conv whose data gradient can take the [shortcut] gradient of `a` as an addend and reduce the
+        BatchNorm backward of a's producer in its epilogue (DYK_EPI_BNBWD | DYK_EPI_ADDEND): `a` is read by that
+        conv and the [shortcut] only, the conv comes earlier than layer `before` and covers a in one launch"""
+        if os.environ.get("DYK_BNBWD_FUSE", "1") == "0" or os.environ.get("DYK_DEBUG_PLAN"):
+            return None
+        prod = producer_of.get(a.tid)
+        if prod is None or not prod.get("bn"):
+            return None
+        # readers: the conv, this [shortcut] and, when a is itself the output of a fused [shortcut], that section
+        if tcons.get(a.tid, 0) != (3 if prod.get("fused_shortcut") else 2) or a.tid in ginit or a.tid in grads \
+                or a.C % (16 // es):
+            return None
+        readers = [r for r in info[:before] if r.get("kind") == "conv" and r.get("x") is not None
+                   and r["x"].tid == a.tid]
+        if len(readers) != 1:
+            return None
+        r = readers[0]
+        if r is prod or r.get("dw") or r.get("stem") or r["stride"] != 1 or r["i"] <= prod["i"]:
+            return None
+        if len(dgrad_classes(r["k"], r["pad"], 1, a.H, a.W)) != 1:
+            return None
+        return r
 
-        def emit_conv_backward(rec, dy):
-            """dy: gradient w.r.t. the conv's raw output (dtype), rows zero padded to a multiple of 32 channels"""
-            k, stride, pad, cout, wname = rec["k"], rec["stride"], rec["pad"], rec["cout"], rec["wname"]
-            x_in = rec["x"]
-            if rec["dw"]:
-                wd = L.DykDwDesc()
-                plan._keep.append(wd)
-                wd.dtype, wd.w, wd.dw = code, store.p_ptr(wname), store.g_ptr(wname)
-                wd.B, wd.Hi, wd.Wi, wd.Ho, wd.Wo, wd.C = B, x_in.H, x_in.W, dy.H, dy.W, cout
-                wd.k, wd.stride, wd.pad = k, stride, pad
-                wd.ldx, wd.ldy = x_in.ld, dy.ld
-                later(lambda wd=wd, x=x_in, dy=dy: (setattr(wd, "x", ptr_of(x)), setattr(wd, "y", ptr_of(dy))))
-                pre = getattr(x_in, "pre", None)
-                if pre is not None:                       # (the input is the producer's RAW output: z is formed on load)
-                    wd.pre_act = pre[1]
-                    later(lambda wd=wd, pre=pre: setattr(wd, "pre", ws.ptr(pre[0])))
-                if wname not in frozen:
-                    plan.bwd.append((L.OP_DW_WGRAD, wd))
-                if rec["i"] == first_trainable and rec["entry"]:
-                    return
-                gx = gref(x_in)
-                gd = L.DykDwDesc()
-                plan._keep.append(gd)
-                gd.dtype, gd.w = code, store.p_ptr(wname)
-                gd.B, gd.Hi, gd.Wi, gd.Ho, gd.Wo, gd.C = B, x_in.H, x_in.W, dy.H, dy.W, cout
-                gd.k, gd.stride, gd.pad = k, stride, pad
-                gd.ldx, gd.ldy = gx.ld, dy.ld
-                first = x_in.tid not in ginit
-                gd.flags = acc_flag(x_in)
-                later(lambda gd=gd, gx=gx, dy=dy: (setattr(gd, "x", ptr_of(gx)), setattr(gd, "y", ptr_of(dy))))
-                # BatchNorm-backward reduce of the layer that produced x_in (the expansion conv of a MobileNet block) folded
-                # into this data gradient, under the conditions of the MFMA conv's DYK_EPI_BNBWD (sole reader, first
-                # writer of the gradient) -- LDS-tiled kernel only: stride 1, 3x3 / 5x5, bf16
-                prod = producer_of.get(x_in.tid)
-                if (first and prod is not None and prod is not rec and tcons.get(x_in.tid, 0) == 1
-                        and stride == 1 and k in (3, 5) and code == L.DYK_BF16 and "vecs" in prod and prod["vs"] == 4 * x_in.C
-                        and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
-                        ):
-                    prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
-                    prod["keep_dz"] = False
-                    gd.act, gd.stats_slots, gd.ldr = prod["act"], STAT_SLOTS, prod["y_raw"].ld
-                    later(lambda gd=gd, prod=prod: (
-                        setattr(gd, "res", ptr_of(prod["y_raw"])), setattr(gd, "bn", ws.ptr(prod["vecs"])),
-                        setattr(gd, "stats", ws.ptr(prod["red_fused"]))))
-                plan.bwd.append((L.OP_DW_DGRAD, gd))
-                return
-            if "stem_direct" in rec:
-                if wname in frozen:
-                    return
-                f = rec["stem_direct"]
-                wd = L.DykStemDesc()
-                plan._keep.append(wd)
-                wd.dtype, wd.B, wd.H, wd.W, wd.Cout, wd.k, wd.stride, wd.pad, wd.Ho, wd.Wo = (
-                    code, f.B, f.H, f.W, f.Cout, f.k, f.stride, f.pad, f.Ho, f.Wo)
-                wd.lddy, wd.dw = dy.ld, store.g_ptr(wname)
-                nsegs = f.B * f.Ho * ((f.Wo + 127) // 128)
-                spw = max(1, (nsegs + 4095) // 4096)
-                planes = (nsegs + spw - 1) // spw                            # == dyk_stem_wgrad_planes
-                part = new_ws(planes * f.Cout * 27 * 4)
-                later(lambda wd=wd, dy=dy, part=part: (setattr(wd, "dy", ptr_of(dy)), setattr(wd, "part", ws.ptr(part))))
-                bap = rec.get("_bn_apply")
-                if (bap is not None and bap[5] and code == L.DYK_BF16 and dy.ld == f.Cout and rec["y_raw"].ld == f.Cout
-                        ):
-                    # BatchNorm-backward apply of the stem's own BatchNorm inside this weight gradient (uint8 images: decided per
-                    # call by the engine, dyk_stem_wgrad_bn_fusable): da and the raw output are read instead of dz, the separate
-                    # pass over the largest activation of the net is skipped (DYK_EW_SKIP on its descriptor)
-                    ap, da_ref, red_, vecs_, cout_, _ = bap
-                    wd.bn_slots = STAT_SLOTS
-                    wd.bn_dgamma, wd.bn_dbeta = ap.aux, ap.aux2
-                    later(lambda wd=wd, da_ref=da_ref, yr=rec["y_raw"], red_=red_, vecs_=vecs_: (
-                        setattr(wd, "bn_da", ptr_of(da_ref)), setattr(wd, "bn_yraw", ptr_of(yr)),
-                        setattr(wd, "bn_vecs", ws.ptr(vecs_)), setattr(wd, "bn_red", ws.ptr(red_))))
-                    plan.stem_fuse.append((ap, wd))
-                plan.dyn_in.append((wd, [k_ for (d_, k_) in plan.dyn_in if d_ is f][0]))
-                plan.bwd.append((L.OP_STEM_WGRAD, wd))
-                return
-            wg = rec["wgrad"]
-            wd = L.DykWgradDesc()
+    def emit_conv_backward(rec, dy):
+        """dy: gradient w.r.t. the conv's raw output (dtype), rows zero padded to a multiple of 32 channels"""
+        k, stride, pad, cout, wname = rec["k"], rec["stride"], rec["pad"], rec["cout"], rec["wname"]
+        x_in = rec["x"]
+        if rec["dw"]:
+            wd = L.DykDwDesc()
             plan._keep.append(wd)
-            wd.dtype = code
-            wd.dw = store.g_ptr(wname)
-            wd.ldx, wd.lddy = wg["x"].ld, dy.ld
-            wd.B, wd.Hi, wd.Wi, wd.Cin = B, wg["Hi"], wg["Wi"], wg["Cin"]
-            wd.Ho, wd.Wo, wd.Cout = dy.H, dy.W, cout
-            wd.isy = wd.isx = wg["isy"]
-            wd.ntaps = len(wg["taps"])
-            for q, (ty, tx, wt) in enumerate(wg["taps"]):
-                wd.tdy[q], wd.tdx[q], wd.twt[q] = ty, tx, wt
-            wd.splits, wd.lddw = 0, wg["lddw"]
-            later(lambda wd=wd, x=wg["x"], dy=dy: (setattr(wd, "x", ptr_of(x)), setattr(wd, "dy", ptr_of(dy))))
+            wd.dtype, wd.w, wd.dw = code, store.p_ptr(wname), store.g_ptr(wname)
+            wd.B, wd.Hi, wd.Wi, wd.Ho, wd.Wo, wd.C = B, x_in.H, x_in.W, dy.H, dy.W, cout
+            wd.k, wd.stride, wd.pad = k, stride, pad
+            wd.ldx, wd.ldy = x_in.ld, dy.ld
+            later(lambda wd=wd, x=x_in, dy=dy: (setattr(wd, "x", ptr_of(x)), setattr(wd, "y", ptr_of(dy))))
+            pre = getattr(x_in, "pre", None)
+            if pre is not None:                       # (the input is the producer's RAW output: z is formed on load)
+                wd.pre_act = pre[1]
+                later(lambda wd=wd, pre=pre: setattr(wd, "pre", ws.ptr(pre[0])))
             if wname not in frozen:
-                plan.bwd.append((L.OP_WGRAD, wd))
-            if rec["stem"] or (rec["i"] == first_trainable and rec["entry"]):
-                return                           # nothing trainable upstream: the input gradient is not needed
+                plan.bwd.append((L.OP_DW_WGRAD, wd))
+            if rec["i"] == first_trainable and rec["entry"]:
+                return
             gx = gref(x_in)
+            gd = L.DykDwDesc()
+            plan._keep.append(gd)
+            gd.dtype, gd.w = code, store.p_ptr(wname)
+            gd.B, gd.Hi, gd.Wi, gd.Ho, gd.Wo, gd.C = B, x_in.H, x_in.W, dy.H, dy.W, cout
+            gd.k, gd.stride, gd.pad = k, stride, pad
+            gd.ldx, gd.ldy = gx.ld, dy.ld
             first = x_in.tid not in ginit
-            e = store.by_name[wname]
-            kpad = _ru(cout, 32)
-            if dy.ld < kpad and not tight:
-                raise NotImplementedError("gradient rows narrower than the padded K (layer %d)" % rec["i"])
-            if kpad != cout:
-                wt_ptr = cw["Wt_pad"].data_ptr() + cw["bwd_pad_off"][wname] * es
-            else:
-                wt_ptr = cw["Wt"].data_ptr() + e.offset * es
-            # BatchNorm-backward reduce of the producer of x_in folded into this data gradient (DYK_EPI_BNBWD): possible
-            # when this launch is the only writer of the gradient (sole reader of the tensor, nothing accumulated yet)
+            gd.flags = acc_flag(x_in)
+            later(lambda gd=gd, gx=gx, dy=dy: (setattr(gd, "x", ptr_of(gx)), setattr(gd, "y", ptr_of(dy))))
+            # BatchNorm-backward reduce of the layer that produced x_in (the expansion conv of a MobileNet block) folded
+            # into this data gradient, under the conditions of the MFMA conv's DYK_EPI_BNBWD (sole reader, first
+            # writer of the gradient) -- LDS-tiled kernel only: stride 1, 3x3 / 5x5, bf16
             prod = producer_of.get(x_in.tid)
-            addend = pending_add.pop(x_in.tid, None)
-            if addend is not None and (not first or addend[1] is not rec or addend[0].ld != gx.ld):
-                raise RuntimeError("residual-chain addend of layer %d lost its consumer" % rec["i"])
-            fuse = addend is not None or (
-                first and prod is not None and prod is not rec and tcons.get(x_in.tid, 0) == 1
-                and x_in.C % (16 // es) == 0 and not os.environ.get("DYK_DEBUG_PLAN")
-                and os.environ.get("DYK_BNBWD_FUSE", "1") != "0")
-            if fuse:
+            if (first and prod is not None and prod is not rec and tcons.get(x_in.tid, 0) == 1
+                    and stride == 1 and k in (3, 5) and code == L.DYK_BF16 and "vecs" in prod and prod["vs"] == 4 * x_in.C
+                    and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
+                    ):
                 prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
-                prod["keep_dz"] = addend is not None
-                bw = dict(act=prod["act"], raw=prod["y_raw"], vecs=prod["vecs"], vs=prod["vs"], red=prod["red_fused"])
-            # ... or x_in is the output of the LAST [shortcut] of a residual chain, riding on its conv's normalise pass
-            # (fused_shortcut): this launch is the only writer of that gradient, which the skip branch still needs as dz itself --
-            # the keep-dz (chain) form of the epilogue without an addend (DYK_EPI_ADDEND, add == NULL)
-            zero_chain = (not fuse and addend is None and first and prod is not None and prod is not rec
-                          and prod.get("fused_shortcut") and prod.get("bn") and "vecs" in prod and tcons.get(x_in.tid, 0) == 2
-                          and x_in.C % (16 // es) == 0 and stride == 1 and len(dgrad_classes(k, pad, 1, x_in.H, x_in.W)) == 1
-                          and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
-                          )
-            if zero_chain:
-                fuse = True
-                prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
-                prod["keep_dz"] = True
-                bw = dict(act=prod["act"], raw=prod["y_raw"], vecs=prod["vecs"], vs=prod["vs"], red=prod["red_fused"])
-            # ... or of ALL the conv + BatchNorm sections concatenated into x_in (joint_of, decided in the forward): one launch,
-            # replicas [slots][2][ctot]; every section's apply pass folds its own columns (DykEwDesc.H / W: replica stride and
-            # offset of the second sum)
-            jr = joint_of.get(x_in.tid) if not fuse else None
-            if (jr is not None and first and tcons.get(x_in.tid, 0) == 1 and x_in.C == jr["ctot"] and x_in.C % (16 // es) == 0
-                    and all(tcons.get(pr_["z"].tid, 0) == 1 and pr_["z"].tid not in grads and pr_["z"].tid not in ginit
-                            for pr_, _ in jr["parts"])):
-                fuse = True
-                jred = new_red(STAT_SLOTS * 2 * jr["ctot"] * 8)
-                for pr_, c0_ in jr["parts"]:
-                    pr_["red_fused"], pr_["red_geom"], pr_["keep_dz"] = jred + 8 * c0_, (2 * jr["ctot"], jr["ctot"]), False
-                bw = dict(act=jr["act"], raw=jr["raw"], vecs=jr["vecs"], vs=4 * jr["ctot"], red=jred)
-            classes = dgrad_classes(k, pad, stride, x_in.H, x_in.W)
-            # the parity classes of a strided conv's data gradient in one launch (DykConvDesc.ncls) when they all have
-            # taps, share the launch grid and fit the tap table
-            merged = (len(classes) in (2, 4) and all(c[4] for c in classes)
-                      and len({(c[2], c[3]) for c in classes}) == 1
-                      and sum(len(c[4]) for c in classes) <= L.MAX_TAPS
+                prod["keep_dz"] = False
+                gd.act, gd.stats_slots, gd.ldr = prod["act"], STAT_SLOTS, prod["y_raw"].ld
+                later(lambda gd=gd, prod=prod: (
+                    setattr(gd, "res", ptr_of(prod["y_raw"])), setattr(gd, "bn", ws.ptr(prod["vecs"])),
+                    setattr(gd, "stats", ws.ptr(prod["red_fused"]))))
+            plan.bwd.append((L.OP_DW_DGRAD, gd))
+            return
+        if "stem_direct" in rec:
+            if wname in frozen:
+                return
+            f = rec["stem_direct"]
+            wd = L.DykStemDesc()
+            plan._keep.append(wd)
+            wd.dtype, wd.B, wd.H, wd.W, wd.Cout, wd.k, wd.stride, wd.pad, wd.Ho, wd.Wo = (
+                code, f.B, f.H, f.W, f.Cout, f.k, f.stride, f.pad, f.Ho, f.Wo)
+            wd.lddy, wd.dw = dy.ld, store.g_ptr(wname)
+            nsegs = f.B * f.Ho * ((f.Wo + 127) // 128)
+            spw = max(1, (nsegs + 4095) // 4096)
+            planes = (nsegs + spw - 1) // spw                            # == dyk_stem_wgrad_planes
+            part = new_ws(planes * f.Cout * 27 * 4)
+            later(lambda wd=wd, dy=dy, part=part: (setattr(wd, "dy", ptr_of(dy)), setattr(wd, "part", ws.ptr(part))))
+            bap = rec.get("_bn_apply")
+            if (bap is not None and bap[5] and code == L.DYK_BF16 and dy.ld == f.Cout and rec["y_raw"].ld == f.Cout
+                    ):
+                # BatchNorm-backward apply of the stem's own BatchNorm inside this weight gradient (uint8 images: decided per
+                # call by the engine, dyk_stem_wgrad_bn_fusable): da and the raw output are read instead of dz, the separate
+                # pass over the largest activation of the net is skipped (DYK_EW_SKIP on its descriptor)
+                ap, da_ref, red_, vecs_, cout_, _ = bap
+                wd.bn_slots = STAT_SLOTS
+                wd.bn_dgamma, wd.bn_dbeta = ap.aux, ap.aux2
+                later(lambda wd=wd, da_ref=da_ref, yr=rec["y_raw"], red_=red_, vecs_=vecs_: (
+                    setattr(wd, "bn_da", ptr_of(da_ref)), setattr(wd, "bn_yraw", ptr_of(yr)),
+                    setattr(wd, "bn_vecs", ws.ptr(vecs_)), setattr(wd, "bn_red", ws.ptr(red_))))
+                plan.stem_fuse.append((ap, wd))
+            plan.dyn_in.append((wd, [k_ for (d_, k_) in plan.dyn_in if d_ is f][0]))
+            plan.bwd.append((L.OP_STEM_WGRAD, wd))
+            return
+        wg = rec["wgrad"]
+        wd = L.DykWgradDesc()
+        plan._keep.append(wd)
+        wd.dtype = code
+        wd.dw = store.g_ptr(wname)
+        wd.ldx, wd.lddy = wg["x"].ld, dy.ld
+        wd.B, wd.Hi, wd.Wi, wd.Cin = B, wg["Hi"], wg["Wi"], wg["Cin"]
+        wd.Ho, wd.Wo, wd.Cout = dy.H, dy.W, cout
+        wd.isy = wd.isx = wg["isy"]
+        wd.ntaps = len(wg["taps"])
+        for q, (ty, tx, wt) in enumerate(wg["taps"]):
+            wd.tdy[q], wd.tdx[q], wd.twt[q] = ty, tx, wt
+        wd.splits, wd.lddw = 0, wg["lddw"]
+        later(lambda wd=wd, x=wg["x"], dy=dy: (setattr(wd, "x", ptr_of(x)), setattr(wd, "dy", ptr_of(dy))))
+        if wname not in frozen:
+            plan.bwd.append((L.OP_WGRAD, wd))
+        if rec["stem"] or (rec["i"] == first_trainable and rec["entry"]):
+            return                           # nothing trainable upstream: the input gradient is not needed
+        gx = gref(x_in)
+        first = x_in.tid not in ginit
+        e = store.by_name[wname]
+        kpad = _ru(cout, 32)
+        if dy.ld < kpad and not tight:
+            raise NotImplementedError("gradient rows narrower than the padded K (layer %d)" % rec["i"])
+        if kpad != cout:
+            wt_ptr = cw["Wt_pad"].data_ptr() + cw["bwd_pad_off"][wname] * es
+        else:
+            wt_ptr = cw["Wt"].data_ptr() + e.offset * es
+        # BatchNorm-backward reduce of the producer of x_in folded into this data gradient (DYK_EPI_BNBWD): possible
+        # when this launch is the only writer of the gradient (sole reader of the tensor, nothing accumulated yet)
+        prod = producer_of.get(x_in.tid)
+        addend = pending_add.pop(x_in.tid, None)
+        if addend is not None and (not first or addend[1] is not rec or addend[0].ld != gx.ld):
+            raise RuntimeError("residual-chain addend of layer %d lost its consumer" % rec["i"])
+        fuse = addend is not None or (
+            first and prod is not None and prod is not rec and tcons.get(x_in.tid, 0) == 1
+            and x_in.C % (16 // es) == 0 and not os.environ.get("DYK_DEBUG_PLAN")
+            and os.environ.get("DYK_BNBWD_FUSE", "1") != "0")
+        if fuse:
+            prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
+            prod["keep_dz"] = addend is not None
+            bw = dict(act=prod["act"], raw=prod["y_raw"], vecs=prod["vecs"], vs=prod["vs"], red=prod["red_fused"])
+        # ... or x_in is the output of the LAST [shortcut] of a residual chain, riding on its conv's normalise pass
+        # (fused_shortcut): this launch is the only writer of that gradient, which the skip branch still needs as dz itself --
+        # the keep-dz (chain) form of the epilogue without an addend (DYK_EPI_ADDEND, add == NULL)
+        zero_chain = (not fuse and addend is None and first and prod is not None and prod is not rec
+                      and prod.get("fused_shortcut") and prod.get("bn") and "vecs" in prod and tcons.get(x_in.tid, 0) == 2
+                      and x_in.C % (16 // es) == 0 and stride == 1 and len(dgrad_classes(k, pad, 1, x_in.H, x_in.W)) == 1
+                      and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
                       )
+        if zero_chain:
+            fuse = True
+            prod["red_fused"] = new_red(STAT_SLOTS * 2 * x_in.C * 8)
+            prod["keep_dz"] = True
+            bw = dict(act=prod["act"], raw=prod["y_raw"], vecs=prod["vecs"], vs=prod["vs"], red=prod["red_fused"])
+        # ... or of ALL the conv + BatchNorm sections concatenated into x_in (joint_of, decided in the forward): one launch,
+        # replicas [slots][2][ctot]; every section's apply pass folds its own columns (DykEwDesc.H / W: replica stride and
+        # offset of the second sum)
+        jr = joint_of.get(x_in.tid) if not fuse else None
+        if (jr is not None and first and tcons.get(x_in.tid, 0) == 1 and x_in.C == jr["ctot"] and x_in.C % (16 // es) == 0
+                and all(tcons.get(pr_["z"].tid, 0) == 1 and pr_["z"].tid not in grads and pr_["z"].tid not in ginit
+                        for pr_, _ in jr["parts"])):
+            fuse = True
+            jred = new_red(STAT_SLOTS * 2 * jr["ctot"] * 8)
+            for pr_, c0_ in jr["parts"]:
+                pr_["red_fused"], pr_["red_geom"], pr_["keep_dz"] = jred + 8 * c0_, (2 * jr["ctot"], jr["ctot"]), False
+            bw = dict(act=jr["act"], raw=jr["raw"], vecs=jr["vecs"], vs=4 * jr["ctot"], red=jred)
+        classes = dgrad_classes(k, pad, stride, x_in.H, x_in.W)
+        # the parity classes of a strided conv's data gradient in one launch (DykConvDesc.ncls) when they all have
+        # taps, share the launch grid and fit the tap table
+        merged = (len(classes) in (2, 4) and all(c[4] for c in classes)
+                  and len({(c[2], c[3]) for c in classes}) == 1
+                  and sum(len(c[4]) for c in classes) <= L.MAX_TAPS
+                  )
+        if merged:
+            classes = [(0, 0, classes[0][2], classes[0][3], [t for c in classes for t in c[4]], classes)]
+        for cls in classes:
+            (py, px, Hg, Wg, taps) = cls[:5]
+            if not taps and not first:
+                continue                      # nothing to accumulate for this parity class
+            d = L.DykConvDesc()
+            plan._keep.append(d)
+            d.dtype = code
+            d.w = wt_ptr
+            d.B, d.Hi, d.Wi, d.Cin, d.Cout = B, dy.H, dy.W, kpad, x_in.C
+            d.Hg, d.Wg, d.Ho, d.Wo = Hg, Wg, x_in.H, x_in.W
+            d.isy = d.isx = 1
+            d.osy = d.osx = stride
+            d.ooy, d.oox = py, px
+            d.ntaps = len(taps)
+            for q, (ty, tx, wt) in enumerate(taps):
+                d.tdy[q], d.tdx[q], d.twt[q] = ty, tx, wt
             if merged:
-                classes = [(0, 0, classes[0][2], classes[0][3], [t for c in classes for t in c[4]], classes)]
-            for cls in classes:
-                (py, px, Hg, Wg, taps) = cls[:5]
-                if not taps and not first:
-                    continue                      # nothing to accumulate for this parity class
-                d = L.DykConvDesc()
-                plan._keep.append(d)
-                d.dtype = code
-                d.w = wt_ptr
-                d.B, d.Hi, d.Wi, d.Cin, d.Cout = B, dy.H, dy.W, kpad, x_in.C
-                d.Hg, d.Wg, d.Ho, d.Wo = Hg, Wg, x_in.H, x_in.W
-                d.isy = d.isx = 1
-                d.osy = d.osx = stride
-                d.ooy, d.oox = py, px
-                d.ntaps = len(taps)
-                for q, (ty, tx, wt) in enumerate(taps):
-                    d.tdy[q], d.tdx[q], d.twt[q] = ty, tx, wt
-                if merged:
-                    d.ncls, q0 = len(cls[5]), 0
-                    for c, (cpy, cpx, _, _, ctaps) in enumerate(cls[5]):
-                        d.cls_first[c], d.cls_ntaps[c], d.cls_ooy[c], d.cls_oox[c] = q0, len(ctaps), cpy, cpx
-                        q0 += len(ctaps)
-                d.ldx, d.ldy = dy.ld, gx.ld
-                d.act, d.flags = 0, (0 if first else L.EPI_ACCUM)
-                later(lambda d=d, dy=dy, gx=gx: (setattr(d, "x", ptr_of(dy)), setattr(d, "y", ptr_of(gx))))
-                if fuse:
-                    d.act, d.flags, d.stats_slots, d.ldr = bw["act"], L.EPI_BNBWD, STAT_SLOTS, bw["raw"].ld
-                    if addend is not None:
-                        d.flags |= L.EPI_ADDEND
-                        later(lambda d=d, ad=addend[0]: setattr(d, "add", ptr_of(ad)))
-                    elif zero_chain:
-                        d.flags |= L.EPI_ADDEND           # (add stays NULL)
-                    later(lambda d=d, bw=bw: (
-                        setattr(d, "res", ptr_of(bw["raw"])), setattr(d, "scale", ws.ptr(bw["vecs"])),
-                        setattr(d, "shift", ws.ptr(bw["vecs"] + bw["vs"])), setattr(d, "aux0", ws.ptr(bw["vecs"] + 2 * bw["vs"])),
-                        setattr(d, "aux1", ws.ptr(bw["vecs"] + 3 * bw["vs"])), setattr(d, "stats", ws.ptr(bw["red"]))))
-                plan.bwd.append((L.OP_CONV, d))
-            ginit.add(x_in.tid)
+                d.ncls, q0 = len(cls[5]), 0
+                for c, (cpy, cpx, _, _, ctaps) in enumerate(cls[5]):
+                    d.cls_first[c], d.cls_ntaps[c], d.cls_ooy[c], d.cls_oox[c] = q0, len(ctaps), cpy, cpx
+                    q0 += len(ctaps)
+            d.ldx, d.ldy = dy.ld, gx.ld
+            d.act, d.flags = 0, (0 if first else L.EPI_ACCUM)
+            later(lambda d=d, dy=dy, gx=gx: (setattr(d, "x", ptr_of(dy)), setattr(d, "y", ptr_of(gx))))
+            if fuse:
+                d.act, d.flags, d.stats_slots, d.ldr = bw["act"], L.EPI_BNBWD, STAT_SLOTS, bw["raw"].ld
+                if addend is not None:
+                    d.flags |= L.EPI_ADDEND
+                    later(lambda d=d, ad=addend[0]: setattr(d, "add", ptr_of(ad)))
+                elif zero_chain:
+                    d.flags |= L.EPI_ADDEND           # (add stays NULL)
+                later(lambda d=d, bw=bw: (
+                    setattr(d, "res", ptr_of(bw["raw"])), setattr(d, "scale", ws.ptr(bw["vecs"])),
+                    setattr(d, "shift", ws.ptr(bw["vecs"] + bw["vs"])), setattr(d, "aux0", ws.ptr(bw["vecs"] + 2 * bw["vs"])),
+                    setattr(d, "aux1", ws.ptr(bw["vecs"] + 3 * bw["vs"])), setattr(d, "stats", ws.ptr(bw["red"]))))
+            plan.bwd.append((L.OP_CONV, d))
+        ginit.add(x_in.tid)
 
-        def conv_layer_backward(rec):
-            """BatchNorm+activation backward (train-mode statistics) followed by the conv gradients"""
+    def conv_layer_backward(rec):
+        """BatchNorm+activation backward (train-mode statistics) followed by the conv gradients"""
+        z = rec["z"]
+        if z.tid not in ginit:
+            return                           # no gradient reaches this layer
+        dz = gref(z)
+        if rec["bn"]:
+            cout, vecs, bnpre = rec["cout"], rec["vecs"], rec["bnpre"]
+            fused_red = rec.get("red_fused")          # the producing dgrad already left da and the two sums
+            keep_dz = bool(rec.get("keep_dz"))        # ... or, in a residual chain, dz itself (act' still to apply)
+            act_bwd = 0 if (fused_red is not None and not keep_dz) else rec["act"]
+            if fused_red is not None:
+                red = fused_red
+            else:
+                red = new_red(STAT_SLOTS * 2 * cout * 8)
+                r = ew_desc(a=dz, b=rec["y_raw"], act=rec["act"])
+                r.slots = STAT_SLOTS
+                later(lambda r=r, vecs=vecs, red=red, vs=rec["vs"]: (
+                    setattr(r, "p0", ws.ptr(vecs)), setattr(r, "p1", ws.ptr(vecs + vs)),
+                    setattr(r, "p2", ws.ptr(vecs + 2 * vs)), setattr(r, "p3", ws.ptr(vecs + 3 * vs)),
+                    setattr(r, "red", ws.ptr(red))))
+                plan.bwd.append((L.OP_BN_BWD_REDUCE, r))
+            dyr = dz
+            if os.environ.get("DYK_DEBUG_PLAN") or rec.get("dz_is_addend") or os.environ.get("DYK_KEEP_DZ"):
+                # keep dz intact: per-layer gradient dumps / it is still to be added to the skip tensor's gradient /
+                # DYK_KEEP_DZ: the SAME commands and fusions as the default plan, only the apply pass writes beside
+                # its input instead of over it, so that both sides of every BatchNorm backward stay readable
+                # (tests/test_gpu_bwd_bf16.py holds each section of the backward to the oracle on identical inputs)
+                dyr = TRef("grad", grad_arena.alloc(dz.npix * dz.ld * es, pad=kpad_bytes(dz.ld, es)), dz.B, dz.H, dz.W, dz.C, dz.ld, es)
+            rec["dz_ref"], rec["dy_raw_ref"] = dz, dyr
+            ap = ew_desc(a=dz, b=rec["y_raw"], out=dyr, act=act_bwd)        # in place: dz (or da) -> dy_raw
+            # the apply pass folds the replicas of the reduction itself and adds them to dgamma / dbeta
+            ap.slots = STAT_SLOTS
+            ap.aux, ap.aux2 = store.g_ptr(bnpre + "weight"), store.g_ptr(bnpre + "bias")
+            if rec.get("red_geom"):           # the replicas are columns of a route's joint reduction (emit_conv_backward)
+                ap.H, ap.W = rec["red_geom"]
+            later(lambda ap=ap, vecs=vecs, red=red, vs=rec["vs"]: (
+                setattr(ap, "p0", ws.ptr(vecs)), setattr(ap, "p1", ws.ptr(vecs + vs)),
+                setattr(ap, "p2", ws.ptr(vecs + 2 * vs)), setattr(ap, "p3", ws.ptr(vecs + 3 * vs)),
+                setattr(ap, "red", ws.ptr(red))))
+            plan.bwd.append((L.OP_BN_BWD_APPLY, ap))
+            # (the stem's weight gradient can do this pass on the fly: emit_conv_backward below, DykStemDesc.bn_fused)
+            rec["_bn_apply"] = (ap, dz, red, vecs, cout, fused_red is not None and not keep_dz and act_bwd == 0 and dyr is dz)
+            dz = dyr
+        emit_conv_backward(rec, dz)
+
+    memset_desc = misc()
+    plan.bwd.append((L.OP_MEMSET, memset_desc))          # slot 0: clears the fp64 reduction scratch
+    plan.bwd_marks = []                                  # (number of commands emitted, layer index) in backward order
+    for i in range(len(defs) - 1, -1, -1):
+        rec = info[i]
+        t = rec["kind"]
+        plan.bwd_marks.append((len(plan.bwd), i))
+        if rec.get("alias") or i < first_trainable:
+            continue
+        if t == "yolo":
+            y_in = rec["y"]
+            gy = gref(y_in, ld=HEAD_LD)          # dtype rows of 32 channels, zero padded
+            hd = misc()
+            hd.p[2] = store.g_ptr(info[i - 1]["bias_name"])
+            hd.i[0], hd.i[1], hd.i[2], hd.i[3], hd.i[4], hd.i[5], hd.i[6] = B, rec["ny"], rec["nx"], rec["na"], rec["no"], HEAD_LD, code
+            later(lambda hd=hd, gy=gy: hd.p.__setitem__(1, ptr_of(gy)))
+            plan.dyn_dp.append((hd, rec["head"]))
+            plan.bwd.append((L.OP_HEAD_PERMUTE_BWD, hd))
+            ginit.add(y_in.tid)
+        elif t == "conv":
+            conv_layer_backward(rec)
+        elif t == "dwsep":
+            for sub in reversed(rec["parts"]):
+                conv_layer_backward(sub)
+        elif t == "inception":
             z = rec["z"]
             if z.tid not in ginit:
-                return                           # no gradient reaches this layer
-            dz = gref(z)
-            if rec["bn"]:
-                cout, vecs, bnpre = rec["cout"], rec["vecs"], rec["bnpre"]
-                fused_red = rec.get("red_fused")          # the producing dgrad already left da and the two sums
-                keep_dz = bool(rec.get("keep_dz"))        # ... or, in a residual chain, dz itself (act' still to apply)
-                act_bwd = 0 if (fused_red is not None and not keep_dz) else rec["act"]
-                if fused_red is not None:
-                    red = fused_red
-                else:
-                    red = new_red(STAT_SLOTS * 2 * cout * 8)
-                    r = ew_desc(a=dz, b=rec["y_raw"], act=rec["act"])
-                    r.slots = STAT_SLOTS
-                    later(lambda r=r, vecs=vecs, red=red, vs=rec["vs"]: (
-                        setattr(r, "p0", ws.ptr(vecs)), setattr(r, "p1", ws.ptr(vecs + vs)),
-                        setattr(r, "p2", ws.ptr(vecs + 2 * vs)), setattr(r, "p3", ws.ptr(vecs + 3 * vs)),
-                        setattr(r, "red", ws.ptr(red))))
-                    plan.bwd.append((L.OP_BN_BWD_REDUCE, r))
-                dyr = dz
-                if os.environ.get("DYK_DEBUG_PLAN") or rec.get("dz_is_addend") or os.environ.get("DYK_KEEP_DZ"):
-                    # keep dz intact: per-layer gradient dumps / it is still to be added to the skip tensor's gradient /
-                    # DYK_KEEP_DZ: the SAME commands and fusions as the default plan, only the apply pass writes beside
-                    # its input instead of over it, so that both sides of every BatchNorm backward stay readable
-                    # (tests/test_gpu_bwd_bf16.py holds each section of the backward to the oracle on identical inputs)
-                    dyr = TRef("grad", grad_arena.alloc(dz.npix * dz.ld * es, pad=kpad_bytes(dz.ld, es)), dz.B, dz.H, dz.W, dz.C, dz.ld, es)
-                rec["dz_ref"], rec["dy_raw_ref"] = dz, dyr
-                ap = ew_desc(a=dz, b=rec["y_raw"], out=dyr, act=act_bwd)        # in place: dz (or da) -> dy_raw
-                # the apply pass folds the replicas of the reduction itself and adds them to dgamma / dbeta
-                ap.slots = STAT_SLOTS
-                ap.aux, ap.aux2 = store.g_ptr(bnpre + "weight"), store.g_ptr(bnpre + "bias")
-                if rec.get("red_geom"):           # the replicas are columns of a route's joint reduction (emit_conv_backward)
-                    ap.H, ap.W = rec["red_geom"]
-                later(lambda ap=ap, vecs=vecs, red=red, vs=rec["vs"]: (
-                    setattr(ap, "p0", ws.ptr(vecs)), setattr(ap, "p1", ws.ptr(vecs + vs)),
-                    setattr(ap, "p2", ws.ptr(vecs + 2 * vs)), setattr(ap, "p3", ws.ptr(vecs + 3 * vs)),
-                    setattr(ap, "red", ws.ptr(red))))
-                plan.bwd.append((L.OP_BN_BWD_APPLY, ap))
-                # (the stem's weight gradient can do this pass on the fly: emit_conv_backward below, DykStemDesc.bn_fused)
-                rec["_bn_apply"] = (ap, dz, red, vecs, cout, fused_red is not None and not keep_dz and act_bwd == 0 and dyr is dz)
-                dz = dyr
-            emit_conv_backward(rec, dz)
-
-        memset_desc = misc()
-        plan.bwd.append((L.OP_MEMSET, memset_desc))          # slot 0: clears the fp64 reduction scratch
-        plan.bwd_marks = []                                  # (number of commands emitted, layer index) in backward order
-        for i in range(len(defs) - 1, -1, -1):
-            rec = info[i]
-            t = rec["kind"]
-            plan.bwd_marks.append((len(plan.bwd), i))
-            if rec.get("alias") or i < first_trainable:
                 continue
-            if t == "yolo":
-                y_in = rec["y"]
-                gy = gref(y_in, ld=HEAD_LD)          # dtype rows of 32 channels, zero padded
-                hd = misc()
-                hd.p[2] = store.g_ptr(info[i - 1]["bias_name"])
-                hd.i[0], hd.i[1], hd.i[2], hd.i[3], hd.i[4], hd.i[5], hd.i[6] = B, rec["ny"], rec["nx"], rec["na"], rec["no"], HEAD_LD, code
-                later(lambda hd=hd, gy=gy: hd.p.__setitem__(1, ptr_of(gy)))
-                plan.dyn_dp.append((hd, rec["head"]))
-                plan.bwd.append((L.OP_HEAD_PERMUTE_BWD, hd))
-                ginit.add(y_in.tid)
-            elif t == "conv":
-                conv_layer_backward(rec)
-            elif t == "dwsep":
-                for sub in reversed(rec["parts"]):
+            go = gref(z)
+            for recs, c0, co in rec["branches"]:           # the branch outputs' gradients are slices of the concat's
+                zb = recs[-1]["z"]
+                g = go.chan_slice(c0, co)
+                g.tid = zb.tid
+                grads[zb.tid] = g
+                ginit.add(zb.tid)
+            for recs, c0, co in reversed(rec["branches"]):
+                for sub in reversed(recs):
                     conv_layer_backward(sub)
-            elif t == "inception":
-                z = rec["z"]
-                if z.tid not in ginit:
-                    continue
-                go = gref(z)
-                for recs, c0, co in rec["branches"]:           # the branch outputs' gradients are slices of the concat's
-                    zb = recs[-1]["z"]
-                    g = go.chan_slice(c0, co)
-                    g.tid = zb.tid
-                    grads[zb.tid] = g
-                    ginit.add(zb.tid)
-                for recs, c0, co in reversed(rec["branches"]):
-                    for sub in reversed(recs):
-                        conv_layer_backward(sub)
-                pooled, x_in = rec["pooled"], rec["x"]
-                if pooled.tid in ginit:
-                    pd = ew_desc(a=gref(pooled), out=gref(x_in), Bn=B, Hn=x_in.H, Wn=x_in.W, k=3, flags=acc_flag(x_in))
-                    later(lambda pd=pd, rec=rec: setattr(pd, "aux", ws.ptr(rec["amax"])))
-                    plan.bwd.append((L.OP_MAXPOOL_BWD, pd))
-            elif t == "route":
-                out = rec["out"]
-                if out.tid not in ginit:
-                    continue
-                go = gref(out)
-                for (s, c0), q in zip(rec["parts"], mods[i].layers):
-                    if concat_slot.get(q, (None,))[0] == i and nrefs[q] == 1 and s.tid not in grads:
-                        # produced in place and read by nobody else: its gradient IS the slice of the concat gradient
-                        g = go.chan_slice(c0, s.C)
-                        g.tid = s.tid
-                        grads[s.tid] = g
-                        ginit.add(s.tid)
-                        continue
-                    gs = gref(s)
-                    fl = acc_flag(s)
-                    plan.bwd.append((L.OP_AXPBY, ew_desc(a=go.chan_slice(c0, s.C), out=gs, C=s.C, flags=fl)))
-            elif t == "shortcut":
-                z = rec["z"]
-                if z.tid not in ginit:
-                    continue
-                dz = gref(z)
-                x_in, a = rec["x"], rec["a"]
-                if rec.get("fused"):
-                    # z is the conv's own output: its gradient stays where it is, the skip branch gets a copy --
-                    # or, in a residual chain, the data gradient of the skip tensor's other reader adds it on the fly
-                    r = chain_consumer(a, i)
-                    if r is not None and dz.ld == a.ld:
-                        pending_add[a.tid] = (dz, r)
-                        info[i - 1]["dz_is_addend"] = True
-                        continue
-                    plan.bwd.append((L.OP_AXPBY, ew_desc(a=dz, out=gref(a), flags=acc_flag(a))))
-                    continue
-                # mismatched channel counts: x gets dz whole; a gets the first min(nx, na) channels of dz, and zeros in its
-                # remaining channels when this is the first gradient written into it (nx < na)
-                nx, na = x_in.C, a.C
-                Cm = min(nx, na)
-                dza = dz if nx <= na else dz.chan_slice(0, Cm)
-
-                def a_grad(p0_off=None):
-                    ga = gref(a)
-                    first = a.tid not in ginit
-                    e = ew_desc(a=dza, out=ga if nx >= na else ga.chan_slice(0, Cm), C=Cm, flags=acc_flag(a))
-                    if p0_off is not None:
-                        later(lambda e=e, p0_off=p0_off: setattr(e, "p0", ws.ptr(p0_off)))
-                    plan.bwd.append((L.OP_AXPBY, e))
-                    if nx < na and first:
-                        tail = ga.chan_slice(nx, na - nx)
-                        plan.bwd.append((L.OP_AXPBY, ew_desc(a=tail, out=tail, C=na - nx, alpha=0.0)))     # alpha = 0: `a` is not read
-
-                if rec["weighted"] and nx == na:
-                    # weighted fusion, equal channel counts: per source ONE pass over dz leaves its fusion-weight dot product AND
-                    # its scaled gradient copy (dyk_dot with `out`, round 5: two dots + two scaled copies read dz four times)
-                    red = new_red(16)
-                    weff = rec["weff"]
-                    for q, src in enumerate((x_in, a)):
-                        dq = ew_desc(a=dz, b=src, out=gref(src), flags=acc_flag(src))
-                        later(lambda dq=dq, red=red, weff=weff, q=q: (setattr(dq, "red", ws.ptr(red + 8 * q)), setattr(dq, "p0", ws.ptr(weff + 4 * q))))
-                        plan.bwd.append((L.OP_DOT, dq))
-                    pm = misc()
-                    pm.p[0], pm.p[2] = store.p_ptr("module_list.%d.w" % i), store.g_ptr("module_list.%d.w" % i)
-                    pm.i[0] = 2
-                    later(lambda pm=pm, red=red: pm.p.__setitem__(1, ws.ptr(red)))
-                    plan.bwd.append((L.OP_WFUSE_BWD_PARAMS, pm))
-                elif rec["weighted"]:
-                    red = new_red(16)
-                    d0 = ew_desc(a=dz, b=x_in)
-                    later(lambda d0=d0, red=red: setattr(d0, "red", ws.ptr(red)))
-                    plan.bwd.append((L.OP_DOT, d0))
-                    d1 = ew_desc(a=dza, b=a if nx >= na else a.chan_slice(0, Cm), C=Cm)
-                    later(lambda d1=d1, red=red: setattr(d1, "red", ws.ptr(red + 8)))
-                    plan.bwd.append((L.OP_DOT, d1))
-                    pm = misc()
-                    pm.p[0], pm.p[2] = store.p_ptr("module_list.%d.w" % i), store.g_ptr("module_list.%d.w" % i)
-                    pm.i[0] = 2
-                    later(lambda pm=pm, red=red: pm.p.__setitem__(1, ws.ptr(red)))
-                    plan.bwd.append((L.OP_WFUSE_BWD_PARAMS, pm))
-                    weff = rec["weff"]
-                    e = ew_desc(a=dz, out=gref(x_in), flags=acc_flag(x_in))
-                    later(lambda e=e, weff=weff: setattr(e, "p0", ws.ptr(weff)))
-                    plan.bwd.append((L.OP_AXPBY, e))
-                    a_grad(weff + 4)
-                else:
-                    plan.bwd.append((L.OP_AXPBY, ew_desc(a=dz, out=gref(x_in), flags=acc_flag(x_in))))
-                    a_grad()
-            elif t == "se":
-                z = rec["z"]
-                if z.tid not in ginit:
-                    continue
-                dz = gref(z)
-                x_in, C, Cs = rec["x"], rec["C"], rec["Cs"]
-                dscale = new_ws(B * C * 4)
-                dpooled = new_ws(B * C * 4)
-                fcws = rec["fcws"]
-                pd = ew_desc(a=dz, b=x_in, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W, alpha=1.0)
-                pparts = new_ws(L.SE_POOL_SPLITS * B * C * 4)
-                later(lambda pd=pd, dscale=dscale, pparts=pparts: (setattr(pd, "aux", ws.ptr(dscale)), setattr(pd, "aux2", ws.ptr(pparts))))
-                plan.bwd.append((L.OP_SE_POOL, pd))
-                pre = "module_list.%d." % i
-                fd = L.DykSeFcDesc()
-                plan._keep.append(fd)
-                fd.w1, fd.b1 = store.p_ptr(pre + "fc1.weight"), store.p_ptr(pre + "fc1.bias")
-                fd.w2, fd.b2 = store.p_ptr(pre + "fc2.weight"), store.p_ptr(pre + "fc2.bias")
-                fd.B, fd.C, fd.Cs = B, C, Cs
-                # the data half (dpooled) stays on the chain to dx; the parameter half is a command of its own that the
-                # dependency scheduler places like a weight gradient (one call held the chain for three launches: 24 us on
-                # each of the 19 squeeze-excitation blocks of the MobileNetV3 cfg).  DYK_SE_SPLIT=0: one command, as before
-                split = True
-                fg = L.DykSeFcDesc() if split else fd
-                if split:
-                    plan._keep.append(fg)
-                    fg.w1, fg.b1, fg.w2, fg.b2, fg.B, fg.C, fg.Cs = fd.w1, fd.b1, fd.w2, fd.b2, B, C, Cs
-                fg.dw1, fg.db1 = store.g_ptr(pre + "fc1.weight"), store.g_ptr(pre + "fc1.bias")
-                fg.dw2, fg.db2 = store.g_ptr(pre + "fc2.weight"), store.g_ptr(pre + "fc2.bias")
-
-                def se_ptrs(fd=fd, fg=fg, rec=rec, dscale=dscale, dpooled=dpooled, fcws=fcws):
-                    for q in {id(fd): fd, id(fg): fg}.values():
-                        q.pooled, q.dscale, q.ws = ws.ptr(rec["pooled"]), ws.ptr(dscale), ws.ptr(fcws)
-                    fd.dpooled = ws.ptr(dpooled)
-                later(se_ptrs)
-                plan.bwd.append((L.OP_SE_FC_BWD, fd))
-                if split:
-                    plan.bwd.append((L.OP_SE_FC_BWD, fg))
-                gx = gref(x_in)
-                # BatchNorm-backward reduce of the conv + BatchNorm layer that produced x_in inside this launch (dyk_se_scale
-                # with `red`): this block is the only reader of x_in and writes its gradient first (and last); the gradient
-                # stays dz (keep_dz: the apply pass forms act' itself).  22 launches of the MobileNetV3 / 3 of the target cfg
-                prod = producer_of.get(x_in.tid)
-                fuse = (x_in.tid not in ginit and prod is not None and prod.get("bn") and "vecs" in prod and prod["vs"] == 4 * C
-                        and tcons.get(x_in.tid, 0) == 1 and x_in.C % (16 // es) == 0 and prod["y_raw"].C == C
-                        and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
-                        )
-                sd = ew_desc(a=dz, b=prod["y_raw"] if fuse else None, out=gx, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W,
-                             alpha=1.0 / (x_in.H * x_in.W), flags=acc_flag(x_in), act=prod["act"] if fuse else 0)
-                later(lambda sd=sd, rec=rec, dpooled=dpooled: (setattr(sd, "p0", ws.ptr(rec["scale"])), setattr(sd, "p1", ws.ptr(dpooled))))
-                if fuse:
-                    prod["red_fused"] = new_red(STAT_SLOTS * 2 * C * 8)
-                    prod["keep_dz"] = True
-                    sd.slots = STAT_SLOTS
-                    later(lambda sd=sd, prod=prod: (setattr(sd, "p2", ws.ptr(prod["vecs"])), setattr(sd, "red", ws.ptr(prod["red_fused"]))))
-                plan.bwd.append((L.OP_SE_SCALE, sd))
-            elif t == "maxpool":
-                z = rec["z"]
-                if z.tid not in ginit:
-                    continue
-                dz = gref(z)
-                x_in = rec["x"]
-                gx = gref(x_in)
-                pd = ew_desc(a=dz, out=gx, Bn=B, Hn=x_in.H, Wn=x_in.W, k=rec["k"], flags=acc_flag(x_in))
-                pd.slots = rec["stride"]
+            pooled, x_in = rec["pooled"], rec["x"]
+            if pooled.tid in ginit:
+                pd = ew_desc(a=gref(pooled), out=gref(x_in), Bn=B, Hn=x_in.H, Wn=x_in.W, k=3, flags=acc_flag(x_in))
                 later(lambda pd=pd, rec=rec: setattr(pd, "aux", ws.ptr(rec["amax"])))
                 plan.bwd.append((L.OP_MAXPOOL_BWD, pd))
-            elif t == "upsample":
-                z = rec["z"]
-                if z.tid not in ginit:
+        elif t == "route":
+            out = rec["out"]
+            if out.tid not in ginit:
+                continue
+            go = gref(out)
+            for (s, c0), q in zip(rec["parts"], mods[i].layers):
+                if concat_slot.get(q, (None,))[0] == i and nrefs[q] == 1 and s.tid not in grads:
+                    # produced in place and read by nobody else: its gradient IS the slice of the concat gradient
+                    g = go.chan_slice(c0, s.C)
+                    g.tid = s.tid
+                    grads[s.tid] = g
+                    ginit.add(s.tid)
                     continue
-                dz = gref(z)
-                x_in = rec["x"]
-                gx = gref(x_in)
-                plan.bwd.append((L.OP_UPSAMPLE_BWD, ew_desc(a=dz, out=gx, C=x_in.C, Bn=B, Hn=x_in.H, Wn=x_in.W, flags=acc_flag(x_in))))
-        # zero the fp64 reduction scratch before anything accumulates into it
-        plan.bwd_marks.append((len(plan.bwd), -1))
-        if not red_offs:
-            red_offs.append((new_ws(256), 256))
-        lo = min(o for o, n in red_offs)
-        hi = max(o + n for o, n in red_offs)
-        memset_desc.n, memset_desc.i[0] = hi - lo, 0
-        later(lambda ms=memset_desc, lo=lo: ms.p.__setitem__(0, ws.ptr(lo)))
+                gs = gref(s)
+                fl = acc_flag(s)
+                plan.bwd.append((L.OP_AXPBY, ew_desc(a=go.chan_slice(c0, s.C), out=gs, C=s.C, flags=fl)))
+        elif t == "shortcut":
+            z = rec["z"]
+            if z.tid not in ginit:
+                continue
+            dz = gref(z)
+            x_in, a = rec["x"], rec["a"]
+            if rec.get("fused"):
+                # z is the conv's own output: its gradient stays where it is, the skip branch gets a copy --
+                # or, in a residual chain, the data gradient of the skip tensor's other reader adds it on the fly
+                r = chain_consumer(a, i)
+                if r is not None and dz.ld == a.ld:
+                    pending_add[a.tid] = (dz, r)
+                    info[i - 1]["dz_is_addend"] = True
+                    continue
+                plan.bwd.append((L.OP_AXPBY, ew_desc(a=dz, out=gref(a), flags=acc_flag(a))))
+                continue
+            # mismatched channel counts: x gets dz whole; a gets the first min(nx, na) channels of dz, and zeros in its
+            # remaining channels when this is the first gradient written into it (nx < na)
+            nx, na = x_in.C, a.C
+            Cm = min(nx, na)
+            dza = dz if nx <= na else dz.chan_slice(0, Cm)
 
-    # ---------------------------------------------------------------- the rest is a pipeline of passes over the two lists
-    # allocate + emit (above)  ->  materialise  ->  fuse  ->  tune  ->  group  ->  scratch  ->  schedule metadata
-    _materialise(plan, device, pending, stats_memset if training else None, st_arena)
-    plan.training = training
-    plan.store = store
-    _post_passes(plan, store, device, dry, training, stats_memset, _backbone_force_layers(defs, mods, second))
-    _assign_lanes(plan, defs, mods, second, fwd_start, training)
-    _layer_maps(plan, model, defs, mods, second, fwd_start, training)
-    plan.finalize()
-    plan.info = info
-    plan.grads = grads if training else {}
-    plan.outs = outs
-    plan.shape = (B, H, W)
-    plan.dtype = dtype
-    plan.training = training
-    return plan
+            def a_grad(p0_off=None):
+                ga = gref(a)
+                first = a.tid not in ginit
+                e = ew_desc(a=dza, out=ga if nx >= na else ga.chan_slice(0, Cm), C=Cm, flags=acc_flag(a))
+                if p0_off is not None:
+                    later(lambda e=e, p0_off=p0_off: setattr(e, "p0", ws.ptr(p0_off)))
+                plan.bwd.append((L.OP_AXPBY, e))
+                if nx < na and first:
+                    tail = ga.chan_slice(nx, na - nx)
+                    plan.bwd.append((L.OP_AXPBY, ew_desc(a=tail, out=tail, C=na - nx, alpha=0.0)))     # alpha = 0: `a` is not read
+
+            if rec["weighted"] and nx == na:
+                # weighted fusion, equal channel counts: per source ONE pass over dz leaves its fusion-weight dot product AND
+                # its scaled gradient copy (dyk_dot with `out`, round 5: two dots + two scaled copies read dz four times)
+                red = new_red(16)
+                weff = rec["weff"]
+                for q, src in enumerate((x_in, a)):
+                    dq = ew_desc(a=dz, b=src, out=gref(src), flags=acc_flag(src))
+                    later(lambda dq=dq, red=red, weff=weff, q=q: (setattr(dq, "red", ws.ptr(red + 8 * q)), setattr(dq, "p0", ws.ptr(weff + 4 * q))))
+                    plan.bwd.append((L.OP_DOT, dq))
+                pm = misc()
+                pm.p[0], pm.p[2] = store.p_ptr("module_list.%d.w" % i), store.g_ptr("module_list.%d.w" % i)
+                pm.i[0] = 2
+                later(lambda pm=pm, red=red: pm.p.__setitem__(1, ws.ptr(red)))
+                plan.bwd.append((L.OP_WFUSE_BWD_PARAMS, pm))
+            elif rec["weighted"]:
+                red = new_red(16)
+                d0 = ew_desc(a=dz, b=x_in)
+                later(lambda d0=d0, red=red: setattr(d0, "red", ws.ptr(red)))
+                plan.bwd.append((L.OP_DOT, d0))
+                d1 = ew_desc(a=dza, b=a if nx >= na else a.chan_slice(0, Cm), C=Cm)
+                later(lambda d1=d1, red=red: setattr(d1, "red", ws.ptr(red + 8)))
+                plan.bwd.append((L.OP_DOT, d1))
+                pm = misc()
+                pm.p[0], pm.p[2] = store.p_ptr("module_list.%d.w" % i), store.g_ptr("module_list.%d.w" % i)
+                pm.i[0] = 2
+                later(lambda pm=pm, red=red: pm.p.__setitem__(1, ws.ptr(red)))
+                plan.bwd.append((L.OP_WFUSE_BWD_PARAMS, pm))
+                weff = rec["weff"]
+                e = ew_desc(a=dz, out=gref(x_in), flags=acc_flag(x_in))
+                later(lambda e=e, weff=weff: setattr(e, "p0", ws.ptr(weff)))
+                plan.bwd.append((L.OP_AXPBY, e))
+                a_grad(weff + 4)
+            else:
+                plan.bwd.append((L.OP_AXPBY, ew_desc(a=dz, out=gref(x_in), flags=acc_flag(x_in))))
+                a_grad()
+        elif t == "se":
+            z = rec["z"]
+            if z.tid not in ginit:
+                continue
+            dz = gref(z)
+            x_in, C, Cs = rec["x"], rec["C"], rec["Cs"]
+            dscale = new_ws(B * C * 4)
+            dpooled = new_ws(B * C * 4)
+            fcws = rec["fcws"]
+            pd = ew_desc(a=dz, b=x_in, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W, alpha=1.0)
+            pparts = new_ws(L.SE_POOL_SPLITS * B * C * 4)
+            later(lambda pd=pd, dscale=dscale, pparts=pparts: (setattr(pd, "aux", ws.ptr(dscale)), setattr(pd, "aux2", ws.ptr(pparts))))
+            plan.bwd.append((L.OP_SE_POOL, pd))
+            pre = "module_list.%d." % i
+            fd = L.DykSeFcDesc()
+            plan._keep.append(fd)
+            fd.w1, fd.b1 = store.p_ptr(pre + "fc1.weight"), store.p_ptr(pre + "fc1.bias")
+            fd.w2, fd.b2 = store.p_ptr(pre + "fc2.weight"), store.p_ptr(pre + "fc2.bias")
+            fd.B, fd.C, fd.Cs = B, C, Cs
+            # the data half (dpooled) stays on the chain to dx; the parameter half is a command of its own that the
+            # dependency scheduler places like a weight gradient (one call held the chain for three launches: 24 us on
+            # each of the 19 squeeze-excitation blocks of the MobileNetV3 cfg).  DYK_SE_SPLIT=0: one command, as before
+            split = True
+            fg = L.DykSeFcDesc() if split else fd
+            if split:
+                plan._keep.append(fg)
+                fg.w1, fg.b1, fg.w2, fg.b2, fg.B, fg.C, fg.Cs = fd.w1, fd.b1, fd.w2, fd.b2, B, C, Cs
+            fg.dw1, fg.db1 = store.g_ptr(pre + "fc1.weight"), store.g_ptr(pre + "fc1.bias")
+            fg.dw2, fg.db2 = store.g_ptr(pre + "fc2.weight"), store.g_ptr(pre + "fc2.bias")
+
+            def se_ptrs(fd=fd, fg=fg, rec=rec, dscale=dscale, dpooled=dpooled, fcws=fcws):
+                for q in {id(fd): fd, id(fg): fg}.values():
+                    q.pooled, q.dscale, q.ws = ws.ptr(rec["pooled"]), ws.ptr(dscale), ws.ptr(fcws)
+                fd.dpooled = ws.ptr(dpooled)
+            later(se_ptrs)
+            plan.bwd.append((L.OP_SE_FC_BWD, fd))
+            if split:
+                plan.bwd.append((L.OP_SE_FC_BWD, fg))
+            gx = gref(x_in)
+            # BatchNorm-backward reduce of the conv + BatchNorm layer that produced x_in inside this launch (dyk_se_scale
+            # with `red`): this block is the only reader of x_in and writes its gradient first (and last); the gradient
+            # stays dz (keep_dz: the apply pass forms act' itself).  22 launches of the MobileNetV3 / 3 of the target cfg
+            prod = producer_of.get(x_in.tid)
+            fuse = (x_in.tid not in ginit and prod is not None and prod.get("bn") and "vecs" in prod and prod["vs"] == 4 * C
+                    and tcons.get(x_in.tid, 0) == 1 and x_in.C % (16 // es) == 0 and prod["y_raw"].C == C
+                    and not os.environ.get("DYK_DEBUG_PLAN") and os.environ.get("DYK_BNBWD_FUSE", "1") != "0"
+                    )
+            sd = ew_desc(a=dz, b=prod["y_raw"] if fuse else None, out=gx, C=C, Bn=B, Hn=x_in.H, Wn=x_in.W,
+                         alpha=1.0 / (x_in.H * x_in.W), flags=acc_flag(x_in), act=prod["act"] if fuse else 0)
+            later(lambda sd=sd, rec=rec, dpooled=dpooled: (setattr(sd, "p0", ws.ptr(rec["scale"])), setattr(sd, "p1", ws.ptr(dpooled))))
+            if fuse:
+                prod["red_fused"] = new_red(STAT_SLOTS * 2 * C * 8)
+                prod["keep_dz"] = True
+                sd.slots = STAT_SLOTS
+                later(lambda sd=sd, prod=prod: (setattr(sd, "p2", ws.ptr(prod["vecs"])), setattr(sd, "red", ws.ptr(prod["red_fused"]))))
+            plan.bwd.append((L.OP_SE_SCALE, sd))
+        elif t == "maxpool":
+            z = rec["z"]
+            if z.tid not in ginit:
+                continue
+            dz = gref(z)
+            x_in = rec["x"]
+            gx = gref(x_in)
+            pd = ew_desc(a=dz, out=gx, Bn=B, Hn=x_in.H, Wn=x_in.W, k=rec["k"], flags=acc_flag(x_in))
+            pd.slots = rec["stride"]
+            later(lambda pd=pd, rec=rec: setattr(pd, "aux", ws.ptr(rec["amax"])))
+            plan.bwd.append((L.OP_MAXPOOL_BWD, pd))
+        elif t == "upsample":
+            z = rec["z"]
+            if z.tid not in ginit:
+                continue
+            dz = gref(z)
+            x_in = rec["x"]
+            gx = gref(x_in)
+            plan.bwd.append((L.OP_UPSAMPLE_BWD, ew_desc(a=dz, out=gx, C=x_in.C, Bn=B, Hn=x_in.H, Wn=x_in.W, flags=acc_flag(x_in))))
+    # zero the fp64 reduction scratch before anything accumulates into it
+    plan.bwd_marks.append((len(plan.bwd), -1))
+    if not red_offs:
+        red_offs.append((new_ws(256), 256))
+    lo = min(o for o, n in red_offs)
+    hi = max(o + n for o, n in red_offs)
+    memset_desc.n, memset_desc.i[0] = hi - lo, 0
+    later(lambda ms=memset_desc, lo=lo: ms.p.__setitem__(0, ws.ptr(lo)))
+    return grads
 
 
 # ======================================================================================
