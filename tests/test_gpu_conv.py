@@ -595,6 +595,17 @@ def test_conv_at_baseline_size(case):
     ref = dw_ref.permute(2, 3, 0, 1).reshape(k * k, Cout, Cin)
     err = (dw.cpu() - ref).abs().max().item()
     assert err <= 2e-3 * ref.abs().max().item(), err
+    # round 6: the kernels the plan runs at this size -- row-block (3x3) / pixel-streaming (1x1) -- with one split (single writer,
+    # read-add-write) and with the kernel's own split count (atomics); run twice, the single-split result is bit-reproducible;
+    # linear in dy: wgrad(x, 2 dy) == 2 wgrad(x, dy) bit for bit
+    tune = (2 | (1 << 8) | (2 << 28)) if k == 3 else ((3 << 28) | 3)
+    one = [ops.conv2d_wgrad(xd, dyd, k, 1, pad, tune=tune | (1 << 20), splits=1) for _ in range(2)]
+    assert torch.equal(one[0], one[1])
+    assert (one[0].cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    auto = ops.conv2d_wgrad(xd, dyd, k, 1, pad, tune=tune)
+    assert (auto.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    two = ops.conv2d_wgrad(xd, ops.to_nhwc((2 * dy).cuda(), torch.bfloat16), k, 1, pad, tune=tune | (1 << 20), splits=1)
+    assert torch.equal(two, 2 * one[0])
 
 
 @pytest.mark.parametrize("case", [
