@@ -2284,6 +2284,24 @@ def autotune(plan, cache=None):
                             print("tune", key, " ".join("%#x/%d:%.1f" % (c[0], c[1], 1e3 * t) for t, c in sorted(zip(times, combos))[:10]), flush=True)
                     d.part, d.part_stride, d.splits, d.dw = None, 0, 0, saved_dw
                     best = combos[times.index(min(times))]
+                elif key[0] == "w":
+                    # weight gradients without partial planes (DYK_WGRAD_PARTIALS=0: fp32 atomics into the gradient buffer): the
+                    # candidates as they are, the kernel's own split count, sums kept out of the gradient buffer
+                    saved_dw = d.dw
+                    room_t = torch.zeros(d.ntaps * d.Cout * (d.lddw if d.lddw > 0 else d.Cin), dtype=torch.float32,
+                                         device=torch.device("cuda", torch.cuda.current_device()))
+                    d.dw = room_t.data_ptr()
+
+                    def trial_w(c, reps=3):
+                        d.tune = c
+                        if (c >> 28) & 7 and lib.dyk_conv_wgrad_variant(ctypes.byref(d)) != (c >> 28) & 7:
+                            return float("inf")
+                        return _time_launch(fn, d, stream, reps)
+                    try:
+                        times = _refine(cands, [trial_w(c) for c in cands], trial_w)
+                    finally:
+                        d.dw = saved_dw
+                    best = cands[times.index(min(times))]
                 else:
                     sk_saved = (d.sk_ws, d.sk_cnt, d.sk_ws_bytes, d.sk_cnt_n, d.splitk)
 
